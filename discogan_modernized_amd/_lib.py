@@ -1,0 +1,98 @@
+"""ctypes binding of the C-ABI kernel library (include/discogan_hip.h).
+
+The product path has NO CPU fallback: if ``libdiscogan_hip.so`` is missing or a symbol cannot be
+resolved, importing/using the ops raises.  Build it with ``python -m discogan_modernized_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiscogan_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/discogan_hip.h one to one
+SIGNATURES = {
+    "dg_version": (_i, []),
+    "dg_last_error": (C.c_char_p, []),
+    "dg_set_option": (_i, [C.c_char_p, _i]),
+    "dg_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4_valid_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4_valid_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4_valid_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4s2_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4s2_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4_1to4_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4_1to4_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "dg_convT4x4_1to4_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_c3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dg_conv4x4s2_c3_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dg_c3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "dg_conv4x4s2_c3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_bn_workspace_bytes": (_z, [_i, _i]),
+    "dg_bn_train_stats": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
+    "dg_bn_act_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
+    "dg_bn_act_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
+    "dg_act_fwd": (_i, [_p, _p, _z, _i, _f, _p]),
+    "dg_act_bwd": (_i, [_p, _p, _p, _z, _i, _f, _p]),
+    "dg_loss_workspace_bytes": (_z, []),
+    "dg_mse_fwd": (_i, [_p, _p, _z, _p, _p, _z, _p]),
+    "dg_mse_bwd": (_i, [_p, _p, _z, _p, _p, _p]),
+    "dg_bce_fwd": (_i, [_p, _i, _f, _p, _p, _z, _p]),
+    "dg_bce_bwd": (_i, [_p, _i, _f, _p, _p, _p]),
+    "dg_fm_fwd": (_i, [_p, _p, _i, _z, _p, _p, _p, _z, _p]),
+    "dg_fm_bwd": (_i, [_p, _i, _z, _p, _p, _p, _p]),
+    "dg_adam_advance": (_i, [_p, _d, _d, _d, _p]),
+    "dg_adam_step_flat": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p]),
+    "dg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class DiscoganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiscoganHipError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. "
+            "Run `python -m discogan_modernized_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> missing export
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dg_last_error().decode("utf-8", "replace")
+        raise DiscoganHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def set_option(name: str, value: int):
+    check(load().dg_set_option(name.encode(), int(value)), "dg_set_option")

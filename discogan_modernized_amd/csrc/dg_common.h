@@ -1,0 +1,67 @@
+// Shared helpers for the gfx950 DiscoGAN kernels (internal; the public ABI is include/discogan_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/discogan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (thread-local message, never abort) ---------------------------------------
+extern thread_local char dg_err_buf[512];
+int dg_fail(int code, const char* fmt, ...);
+
+#define DG_CHECK_ARG(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return dg_fail(DG_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define DG_CHECK_LAUNCH(name)                                                                    \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess) return dg_fail(DG_ERR_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int dg_ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline bool dg_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline size_t dg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int dg_get_option(int idx);
+enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_COUNT = 8 };
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ float dg_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double dg_wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0
+__device__ __forceinline__ float dg_block_sum256(float v, float* red /*>=4 floats LDS*/) {
+    v = dg_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float dg_apply_act(float u, int act, float slope) {
+    if (act == DG_ACT_LEAKY) return u > 0.f ? u : u * slope;
+    if (act == DG_ACT_RELU) return u > 0.f ? u : 0.f;
+    if (act == DG_ACT_SIGMOID) return 1.f / (1.f + __expf(-u));
+    return u;
+}

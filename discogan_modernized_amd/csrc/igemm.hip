@@ -1,0 +1,698 @@
+// Implicit-GEMM convolution family for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// Replaces (reference file:line): nn.Conv2d(k4,s2,p1) forward / input-grad / weight-grad
+// (model.py:11-31,83-103 via autograd), nn.ConvTranspose2d(k4,s2,p1) (model.py:118-140; forward ==
+// conv dgrad with the same weight tensor), and the k4 s1 p0 "head" layers (model.py:35,107,114).
+//
+// One kernel template, four addressing modes.  GEMM view  C[M][Ng] = sum_k A[M][k] * B[k][Ng]:
+//   FWD          M = N*Ho*Wo pixels     Ng = K out-ch      k = (r,s,c)      A = im2col(x)  B = w[K][(r,s,c)]
+//   DGRAD_S2     M = N*Ho*Wo per output parity (4 classes, 2x2 taps each)
+//                                       Ng = C in-ch       k = (tap,kout)   A = dy gather   B = w[k][r][s][:]
+//   DGRAD_PLAIN  M = N                  Ng = 16*C          k = kout         A = dy[N][K]    B = w[K][16C]
+//   WGRAD        M = K out-ch           Ng = 16*C (r,s,c)  k = pixel        A = dy^T        B = im2col(x)
+//   FWD_C3       M = N*Ho*Wo pixels     Ng = K out-ch      k = (c,r,s)=48   A = im2col(x NCHW, 3 ch)  B = w[K][48]
+//                (3-channel image side: conv1 forward + fused LeakyReLU, last-convT input-grad)
+// Activations are NHWC, weights KRSC, so every operand tile is a set of rows that are CONTIGUOUS in
+// HBM: 16-byte global loads -> 16-byte ds_write_b128, no transposes anywhere.
+//
+// Tiling: 256 threads = 4 waves (WM x WN), each wave owns a 64x64 output tile = 2x2 MFMA 32x32
+// accumulators (64 VGPRs).  K-tile KT (32 or 16), LDS double buffered, ONE barrier per K-tile:
+//   global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
+//   buffer after them, so HBM/L2 latency hides under 64 (KT=32) MFMAs x 64 cycles.
+// LDS operand images:
+//   "k-contiguous" [row][KT+4]  : lane reads one b128 = its A/B values for FOUR consecutive MFMAs
+//                                 (row stride 36 or 20 floats -> conflict-free b128 reads)
+//   "k-major"      [kk][rows+4] : lane reads b32 per MFMA, 32 consecutive lanes -> conflict-free.
+// The k index inside an 8-wide group is permuted identically for A and B (lane-half h, step j ->
+// kk = 4h + j), which a GEMM is invariant to.
+//
+// Split-K: when the tile grid cannot fill 256 CUs x 2 workgroups, the K loop is split over
+// blockIdx; partial fp32 slabs go to the caller's workspace and a second kernel sums them in a fixed
+// order (bitwise reproducible; no float atomics).
+#include "dg_common.h"
+
+enum { MODE_FWD = 0, MODE_DGRAD_S2 = 1, MODE_DGRAD_PLAIN = 2, MODE_WGRAD = 3, MODE_FWD_C3 = 4 };
+
+struct IgemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    float* part;  // split-K slabs (nullptr when splits == 1)
+    int N, H, W, Cc, K;  // conv geometry: x[N,H,W,Cc], K out channels
+    int Ho, Wo, lgHo, lgWo;
+    int stride, pad;
+    int M, Ng, R;  // GEMM rows, cols; R = reduction length in elements (WGRAD: pixels)
+    int nIt, itPerSplit, splits;
+    int tilesM, tilesN;
+    int accumulate;
+    int act;      // FWD_C3 only: fused activation on the output
+    float slope;
+};
+
+#define NEG_BIG (-(1 << 28))
+
+template <int MODE, int WM, int WN, int KT>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr bool A_KM = (MODE == MODE_WGRAD);
+    constexpr bool B_KM = (MODE != MODE_FWD && MODE != MODE_FWD_C3);
+    constexpr int LDA = A_KM ? (BM + 4) : (KT + 4);
+    constexpr int LDB = B_KM ? (BN + 4) : (KT + 4);
+    constexpr int A_ROWS = A_KM ? KT : BM, A_COLS = A_KM ? BM : KT;
+    constexpr int B_ROWS = B_KM ? KT : BN, B_COLS = B_KM ? BN : KT;
+    constexpr int A_FLOATS = A_ROWS * LDA, B_FLOATS = B_ROWS * LDB;
+    constexpr int STAGE = A_FLOATS + B_FLOATS;
+    constexpr int A_CQ = A_COLS / 4, B_CQ = B_COLS / 4;
+    constexpr int NVA = A_ROWS * A_CQ / 256, NVB = B_ROWS * B_CQ / 256;
+    constexpr int A_RSTEP = 256 / A_CQ, B_RSTEP = 256 / B_CQ;
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
+    static_assert(256 % A_CQ == 0 && 256 % B_CQ == 0, "row mapping");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tn = bid % p.tilesN;
+    bid /= p.tilesN;
+    const int tm = bid % p.tilesM;
+    bid /= p.tilesM;
+    int parity = 0, split = bid;
+    if (MODE == MODE_DGRAD_S2) {
+        parity = bid & 3;
+        split = bid >> 2;
+    }
+    const int ph = parity >> 1, pw = parity & 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int it_begin = split * p.itPerSplit;
+    const int it_end = min(p.nIt, it_begin + p.itPerSplit);
+
+    const float* __restrict__ Ag = p.A;
+    const float* __restrict__ Bg = p.B;
+    const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
+    const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
+
+    const int acq = tid % A_CQ, arow0 = tid / A_CQ;
+    const int bcq = tid % B_CQ, brow0 = tid / B_CQ;
+
+    // ---- per-thread row bookkeeping (fixed over the K loop except in WGRAD) --------------------
+    int a_pix[NVA], a_y[NVA], a_x[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int row = arow0 + i * A_RSTEP;
+        a_pix[i] = 0;
+        a_y[i] = NEG_BIG;
+        a_x[i] = 0;
+        if (MODE == MODE_FWD) {
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                a_y[i] = oy * p.stride - p.pad;
+                a_x[i] = ox * p.stride - p.pad;
+                a_pix[i] = (n * H + a_y[i]) * W + a_x[i];
+            }
+        } else if (MODE == MODE_FWD_C3) {
+            // this thread's float4 is filter row r = acq (4 taps s = 0..3) of channel `it`
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                a_y[i] = oy * 2 - 1 + acq;
+                a_x[i] = ox * 2 - 1;
+                a_pix[i] = (n * 3 * H + a_y[i]) * W + a_x[i];  // channel 0 plane, NCHW
+            }
+        } else if (MODE == MODE_DGRAD_S2) {
+            const int m = m0 + row;
+            if (m < p.M) {
+                a_x[i] = m & (Wo - 1);
+                a_y[i] = (m >> lgWo) & (Ho - 1);
+                a_pix[i] = m;  // (n*Ho + a)*Wo + b == m
+            }
+        } else if (MODE == MODE_DGRAD_PLAIN) {
+            const int m = m0 + row;
+            if (m < p.M) {
+                a_y[i] = 0;
+                a_pix[i] = m;
+            }
+        }
+    }
+    // WGRAD: B columns are (tap, c); fixed per thread
+    int wg_r = 0, wg_s = 0, wg_c = 0;
+    bool wg_colok = true;
+    if (MODE == MODE_WGRAD) {
+        const int j = n0 + bcq * 4;
+        wg_colok = j < p.Ng;
+        const int tap = wg_colok ? j / Cc : 0;
+        wg_c = j - tap * Cc;
+        wg_r = tap >> 2;
+        wg_s = tap & 3;
+    }
+
+    // ---- K-iteration state ------------------------------------------------------------------------
+    // FWD: (tap, chunk) over (16, Cc/KT);  DGRAD_S2: (t, chunk) over (4, K/KT)
+    int kchunks = 1, tap = 0, chunk = 0;
+    if (MODE == MODE_FWD) kchunks = Cc / KT;
+    if (MODE == MODE_DGRAD_S2) kchunks = K / KT;
+    if (MODE == MODE_FWD || MODE == MODE_DGRAD_S2) {
+        tap = it_begin / kchunks;
+        chunk = it_begin - tap * kchunks;
+    }
+
+    f32x4 ra[NVA], rb[NVB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tiles = [&](int it) {
+        if (MODE == MODE_FWD) {
+            const int r = tap >> 2, s = tap & 3, c0 = chunk * KT;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int iy = a_y[i] + r, ix = a_x[i] + s;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const long off = (long)(a_pix[i] + r * W + s) * Cc + c0 + acq * 4;
+                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = n0 + brow0 + i * B_RSTEP;
+                const long off = (long)k * 16 * Cc + (long)it * KT + bcq * 4;
+                rb[i] = (k < K) ? *(const f32x4*)(Bg + off) : zero4;
+            }
+        } else if (MODE == MODE_FWD_C3) {
+            static_assert(MODE != MODE_FWD_C3 || KT == 16, "FWD_C3 iterates one input channel (16 taps) per K-tile");
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const bool rowok = (unsigned)a_y[i] < (unsigned)H;
+                const float* src = Ag + ((long)a_pix[i] + (long)it * H * W);
+                f32x4 v = zero4;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ix = a_x[i] + s;
+                    if (rowok && (unsigned)ix < (unsigned)W) v[s] = src[s];
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = n0 + brow0 + i * B_RSTEP;
+                rb[i] = (k < K) ? *(const f32x4*)(Bg + (long)k * 48 + it * 16 + bcq * 4) : zero4;
+            }
+        } else if (MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1, k0 = chunk * KT;
+            const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+            const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+            const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+            const int s = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int iy = a_y[i] + dyo, ix = a_x[i] + dxo;
+                const bool ok = (unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo;
+                const long off = (long)(a_pix[i] + dyo * Wo + dxo) * K + k0 + acq * 4;
+                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
+            }
+            const int col = n0 + bcq * 4;
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = k0 + brow0 + i * B_RSTEP;
+                const long off = (long)(k * 16 + r * 4 + s) * Cc + col;
+                rb[i] = (col < Cc) ? *(const f32x4*)(Bg + off) : zero4;
+            }
+        } else if (MODE == MODE_DGRAD_PLAIN) {
+            const int k0 = it * KT;
+            const int kcol = k0 + acq * 4;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const bool ok = a_y[i] >= 0 && kcol < K;
+                const long off = (long)a_pix[i] * K + kcol;
+                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
+            }
+            const int col = n0 + bcq * 4;
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = k0 + brow0 + i * B_RSTEP;
+                const long off = (long)k * p.Ng + col;
+                rb[i] = (k < K && col < p.Ng) ? *(const f32x4*)(Bg + off) : zero4;
+            }
+        } else {  // WGRAD: rows of both tiles are reduction pixels
+            const int mm0 = it * KT;
+            const int kcol = m0 + acq * 4;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int mrow = mm0 + arow0 + i * A_RSTEP;
+                const long off = (long)mrow * K + kcol;
+                ra[i] = (mrow < p.R && kcol < K) ? *(const f32x4*)(Ag + off) : zero4;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int mrow = mm0 + brow0 + i * B_RSTEP;
+                const int ox = mrow & (Wo - 1), oy = (mrow >> lgWo) & (Ho - 1), n = mrow >> lgHW;
+                const int iy = oy * p.stride - p.pad + wg_r, ix = ox * p.stride - p.pad + wg_s;
+                const bool ok = wg_colok && mrow < p.R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const long off = (long)((n * H + iy) * W + ix) * Cc + wg_c;
+                rb[i] = ok ? *(const f32x4*)(Bg + off) : zero4;
+            }
+        }
+    };
+    auto advance = [&]() {
+        if (MODE == MODE_FWD || MODE == MODE_DGRAD_S2) {
+            if (++chunk == kchunks) {
+                chunk = 0;
+                ++tap;
+            }
+        }
+    };
+    auto store_tiles = [&](float* stage) {
+        float* As = stage;
+        float* Bs = stage + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) *(f32x4*)(As + (arow0 + i * A_RSTEP) * LDA + acq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) *(f32x4*)(Bs + (brow0 + i * B_RSTEP) * LDB + bcq * 4) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (it_begin < it_end) {
+        load_tiles(it_begin);
+        advance();
+        store_tiles(smem);
+    }
+    __syncthreads();
+
+    for (int it = it_begin; it < it_end; ++it) {
+        const int cur = (it - it_begin) & 1;
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + A_FLOATS;
+        const bool more = (it + 1 < it_end);
+        if (more) {
+            load_tiles(it + 1);
+            advance();
+        }
+#pragma unroll
+        for (int kb = 0; kb < KT / 8; ++kb) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                if (!A_KM) {
+                    const f32x4 v = *(const f32x4*)(As + row * LDA + kb * 8 + 4 * lh);
+                    a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[i][j] = As[(kb * 8 + 4 * lh + j) * LDA + row];
+                }
+                const int col = wn * 64 + i * 32 + l31;
+                if (!B_KM) {
+                    const f32x4 v = *(const f32x4*)(Bs + col * LDB + kb * 8 + 4 * lh);
+                    b[i][0] = v[0]; b[i][1] = v[1]; b[i][2] = v[2]; b[i][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb * 8 + 4 * lh + j) * LDB + col];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+        }
+        if (more) store_tiles(smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][jn][r] -> row (r&3)+8*(r>>2)+4*lh, col l31 of the 32x32 sub-tile --------
+    const bool to_part = p.part != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            float* dst;
+            if (to_part) {
+                const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m
+                                                          : (long)split * p.M + m;
+                dst = p.part + srow * p.Ng;
+            } else if (MODE == MODE_DGRAD_S2) {
+                const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                dst = p.C + (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc;
+            } else {
+                dst = p.C + (long)m * p.Ng;
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int n = n0 + wn * 64 + jn * 32 + l31;
+                if (n < p.Ng) {
+                    float v = acc[i][jn][r];
+                    if (!to_part && p.accumulate) v += dst[n];
+                    if (MODE == MODE_FWD_C3) v = dg_apply_act(v, p.act, p.slope);
+                    dst[n] = v;
+                }
+            }
+        }
+    }
+}
+
+// Sum split-K slabs in a fixed order and scatter to the real output.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, long total4) {
+    const int ng4 = p.Ng >> 2;
+    const long slab = (long)(MODE == MODE_DGRAD_S2 ? 4 : 1) * p.M * p.Ng;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const long row = idx / ng4;
+        const int c4 = (int)(idx - row * ng4);
+        const float* src = p.part + row * p.Ng + c4 * 4;
+        f32x4 s = *(const f32x4*)src;
+        for (int k = 1; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
+        float* dst;
+        if (MODE == MODE_DGRAD_S2) {
+            const int parity = (int)(row / p.M);
+            const int m = (int)(row - (long)parity * p.M);
+            const int b = m & (p.Wo - 1), a = (m >> p.lgWo) & (p.Ho - 1), n = m >> (p.lgWo + p.lgHo);
+            dst = p.C + (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c4 * 4;
+        } else {
+            dst = p.C + row * p.Ng + c4 * 4;
+        }
+        if (p.accumulate) s += *(const f32x4*)dst;
+        *(f32x4*)dst = s;
+    }
+}
+
+// ---- K == 1 head (Discriminator conv8, model.py:35): plain reductions ---------------------------------
+__global__ __launch_bounds__(256) void head1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int J) {
+    __shared__ float red[4];
+    const float* xr = x + (long)blockIdx.x * J;
+    float s = 0.f;
+    for (int j = threadIdx.x * 4; j < J; j += 1024) {
+        const f32x4 a = *(const f32x4*)(xr + j), b = *(const f32x4*)(w + j);
+        s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    s = dg_block_sum256(s, red);
+    if (threadIdx.x == 0) y[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int N, int J) {
+    const long total4 = (long)N * (J >> 2);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int n = (int)(idx / (J >> 2));
+        const int j4 = (int)(idx - (long)n * (J >> 2));
+        const float g = dy[n];
+        const f32x4 b = *(const f32x4*)(w + j4 * 4);
+        *(f32x4*)(dx + (long)n * J + j4 * 4) = b * g;
+    }
+}
+__global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dw, int N, int J, int accumulate) {
+    const int j4 = blockIdx.x * 256 + threadIdx.x;
+    if (j4 * 4 >= J) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) s += *(const f32x4*)(x + (long)n * J + j4 * 4) * dy[n];
+    if (accumulate) s += *(const f32x4*)(dw + j4 * 4);
+    *(f32x4*)(dw + j4 * 4) = s;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+struct ConvGeom {
+    int N, H, W, C, K, stride, pad, Ho, Wo;
+};
+
+static int check_geom(const char* who, int N, int H, int W, int C, int K, int stride, int pad, ConvGeom* g) {
+    DG_CHECK_ARG(N >= 1 && C >= 4 && K >= 1, "%s: bad N/C/K (%d,%d,%d)", who, N, C, K);
+    DG_CHECK_ARG(C % 4 == 0, "%s: C=%d must be a multiple of 4", who, C);
+    DG_CHECK_ARG(K == 1 || K % 4 == 0, "%s: K=%d must be 1 or a multiple of 4", who, K);
+    g->N = N; g->H = H; g->W = W; g->C = C; g->K = K; g->stride = stride; g->pad = pad;
+    if (stride == 2 && pad == 1) {
+        DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "%s: H,W must be powers of two >= 2 (%d,%d)", who, H, W);
+        g->Ho = H / 2; g->Wo = W / 2;
+    } else if (stride == 1 && pad == 0) {
+        DG_CHECK_ARG(H == 4 && W == 4, "%s: stride-1 pad-0 head needs a 4x4 input (%d,%d)", who, H, W);
+        g->Ho = 1; g->Wo = 1;
+    } else {
+        return dg_fail(DG_ERR_INVALID, "%s: unsupported (stride,pad)=(%d,%d)", who, stride, pad);
+    }
+    DG_CHECK_ARG((long)N * H * W < (1L << 31) && (long)N * H * W * (long)C / 4 < (1L << 31), "%s: tensor too large", who);
+    return DG_OK;
+}
+
+struct Plan {
+    int mode, wm, wn, kt;
+    IgemmArgs a;
+    size_t ws_bytes;
+};
+
+static int choose_splits(int base_wgs, int nIt) {
+    int forced = dg_get_option(DG_OPT_SPLITK);
+    int target = dg_get_option(DG_OPT_TARGET_WGS);
+    if (target <= 0) target = 512;
+    int s = 1;
+    if (forced > 0) s = forced;
+    else if (base_wgs < target) s = (target + base_wgs - 1) / base_wgs;
+    const int min_it = 4;  // keep at least a few K-tiles per split
+    if (s > nIt / min_it) s = nIt / min_it;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// op: 0 fwd, 1 dgrad, 2 wgrad
+static void make_plan(int op, const ConvGeom& g, Plan* pl) {
+    IgemmArgs& a = pl->a;
+    a = IgemmArgs();
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cc = g.C; a.K = g.K;
+    a.Ho = g.Ho; a.Wo = g.Wo; a.lgHo = dg_ilog2(g.Ho); a.lgWo = dg_ilog2(g.Wo);
+    a.stride = g.stride; a.pad = g.pad;
+    const int npix = g.N * g.Ho * g.Wo;
+    int kt_opt = dg_get_option(DG_OPT_KT);
+    pl->wm = 2; pl->wn = 2; pl->kt = (kt_opt == 16) ? 16 : 32;
+    int zmul = 1;
+    if (op == 0) {
+        pl->mode = MODE_FWD;
+        a.M = npix; a.Ng = g.K; a.R = 16 * g.C;
+        a.nIt = 16 * g.C / pl->kt;
+    } else if (op == 1 && g.stride == 2) {
+        pl->mode = MODE_DGRAD_S2;
+        a.M = npix; a.Ng = g.C; a.R = 4 * g.K;
+        a.nIt = 4 * g.K / pl->kt;
+        zmul = 4;
+        if (g.C <= 64) { pl->wm = 4; pl->wn = 1; pl->kt = 16; a.nIt = 4 * g.K / 16; }
+    } else if (op == 1) {
+        pl->mode = MODE_DGRAD_PLAIN;
+        a.M = g.N; a.Ng = 16 * g.C; a.R = g.K;
+        a.nIt = (g.K + pl->kt - 1) / pl->kt;
+    } else {
+        pl->mode = MODE_WGRAD;
+        a.M = g.K; a.Ng = 16 * g.C; a.R = npix;
+        a.nIt = (npix + pl->kt - 1) / pl->kt;
+    }
+    const int BM = 64 * pl->wm, BN = 64 * pl->wn;
+    a.tilesM = (a.M + BM - 1) / BM;
+    a.tilesN = (a.Ng + BN - 1) / BN;
+    const int base = a.tilesM * a.tilesN * zmul;
+    a.splits = choose_splits(base, a.nIt);
+    a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
+    a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
+    pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
+}
+
+template <int MODE, int WM, int WN, int KT>
+static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
+    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT>), dim3(grid), dim3(256), 0, st, a);
+}
+
+static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStream_t st) {
+    IgemmArgs& a = pl.a;
+    if (a.splits > 1) {
+        if (ws == nullptr || ws_bytes < pl.ws_bytes)
+            return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", who, ws_bytes, pl.ws_bytes);
+        a.part = (float*)ws;
+    }
+    const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
+    const int key = pl.mode * 100 + pl.wm * 10 + (pl.kt == 32 ? 1 : 0);
+    switch (key) {
+        case MODE_FWD * 100 + 21: launch_igemm<MODE_FWD, 2, 2, 32>(a, zmul, st); break;
+        case MODE_FWD * 100 + 20: launch_igemm<MODE_FWD, 2, 2, 16>(a, zmul, st); break;
+        case MODE_DGRAD_S2 * 100 + 21: launch_igemm<MODE_DGRAD_S2, 2, 2, 32>(a, zmul, st); break;
+        case MODE_DGRAD_S2 * 100 + 20: launch_igemm<MODE_DGRAD_S2, 2, 2, 16>(a, zmul, st); break;
+        case MODE_DGRAD_S2 * 100 + 40: launch_igemm<MODE_DGRAD_S2, 4, 1, 16>(a, zmul, st); break;
+        case MODE_DGRAD_PLAIN * 100 + 21: launch_igemm<MODE_DGRAD_PLAIN, 2, 2, 32>(a, zmul, st); break;
+        case MODE_DGRAD_PLAIN * 100 + 20: launch_igemm<MODE_DGRAD_PLAIN, 2, 2, 16>(a, zmul, st); break;
+        case MODE_WGRAD * 100 + 21: launch_igemm<MODE_WGRAD, 2, 2, 32>(a, zmul, st); break;
+        case MODE_WGRAD * 100 + 20: launch_igemm<MODE_WGRAD, 2, 2, 16>(a, zmul, st); break;
+        default: return dg_fail(DG_ERR_INVALID, "%s: no kernel for mode %d wm %d kt %d", who, pl.mode, pl.wm, pl.kt);
+    }
+    DG_CHECK_LAUNCH(who);
+    if (a.splits > 1) {
+        const long total4 = (long)zmul * a.M * a.Ng / 4;
+        int grid = (int)((total4 + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        switch (pl.mode) {
+            case MODE_DGRAD_S2: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_DGRAD_S2>, dim3(grid), dim3(256), 0, st, a, total4); break;
+            default: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_FWD>, dim3(grid), dim3(256), 0, st, a, total4); break;
+        }
+        DG_CHECK_LAUNCH("splitk_reduce");
+    }
+    return DG_OK;
+}
+
+extern "C" size_t dg_conv_workspace_bytes(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (check_geom("dg_conv_workspace_bytes", N, H, W, C, K, stride, pad, &g) != DG_OK) return 0;
+    if (K == 1) return 0;
+    Plan pl;
+    make_plan(op, g, &pl);
+    return pl.ws_bytes;
+}
+
+extern "C" int dg_conv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                           int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    ConvGeom g;
+    int rc = check_geom("dg_conv_fwd", N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(x && w && y, "dg_conv_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 1) {
+        DG_CHECK_ARG(stride == 1, "dg_conv_fwd: K==1 only for the 4x4 head");
+        hipLaunchKernelGGL(head1_fwd_kernel, dim3(N), dim3(256), 0, st, x, w, y, 16 * C);
+        DG_CHECK_LAUNCH("head1_fwd");
+        return DG_OK;
+    }
+    DG_CHECK_ARG(C % 32 == 0, "dg_conv_fwd: C=%d must be a multiple of 32", C);
+    Plan pl;
+    make_plan(0, g, &pl);
+    pl.a.A = x; pl.a.B = w; pl.a.C = y;
+    return run_plan("dg_conv_fwd", pl, ws, ws_bytes, st);
+}
+
+extern "C" int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                             int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    ConvGeom g;
+    int rc = check_geom("dg_conv_dgrad", N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(dy && w && dx, "dg_conv_dgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 1) {
+        DG_CHECK_ARG(stride == 1, "dg_conv_dgrad: K==1 only for the 4x4 head");
+        const long total4 = (long)N * 4 * C;
+        int grid = (int)((total4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(head1_dgrad_kernel, dim3(grid), dim3(256), 0, st, dy, w, dx, N, 16 * C);
+        DG_CHECK_LAUNCH("head1_dgrad");
+        return DG_OK;
+    }
+    if (stride == 2) DG_CHECK_ARG(K % 32 == 0, "dg_conv_dgrad: K=%d must be a multiple of 32", K);
+    Plan pl;
+    make_plan(1, g, &pl);
+    pl.a.A = dy; pl.a.B = w; pl.a.C = dx;
+    return run_plan("dg_conv_dgrad", pl, ws, ws_bytes, st);
+}
+
+extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
+                             int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    ConvGeom g;
+    int rc = check_geom("dg_conv_wgrad", N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(dy && x && dw, "dg_conv_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 1) {
+        DG_CHECK_ARG(stride == 1, "dg_conv_wgrad: K==1 only for the 4x4 head");
+        const int J = 16 * C;
+        hipLaunchKernelGGL(head1_wgrad_kernel, dim3((J / 4 + 255) / 256), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
+        DG_CHECK_LAUNCH("head1_wgrad");
+        return DG_OK;
+    }
+    Plan pl;
+    make_plan(2, g, &pl);
+    pl.a.A = dy; pl.a.B = x; pl.a.C = dw; pl.a.accumulate = accumulate;
+    return run_plan("dg_conv_wgrad", pl, ws, ws_bytes, st);
+}
+
+// ---- named wrappers --------------------------------------------------------------
+extern "C" int dg_conv4x4s2_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                                void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_fwd(x, w, y, N, H, W, C, K, 2, 1, ws, wsb, s);
+}
+extern "C" int dg_conv4x4s2_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                                  void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_dgrad(dy, w, dx, N, H, W, C, K, 2, 1, ws, wsb, s);
+}
+extern "C" int dg_conv4x4s2_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
+                                  int acc, void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_wgrad(dy, x, dw, N, H, W, C, K, 2, 1, acc, ws, wsb, s);
+}
+extern "C" int dg_conv4x4_valid_fwd(const float* x, const float* w, float* y, int N, int C, int K,
+                                    void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_fwd(x, w, y, N, 4, 4, C, K, 1, 0, ws, wsb, s);
+}
+extern "C" int dg_conv4x4_valid_dgrad(const float* dy, const float* w, float* dx, int N, int C, int K,
+                                      void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_dgrad(dy, w, dx, N, 4, 4, C, K, 1, 0, ws, wsb, s);
+}
+extern "C" int dg_conv4x4_valid_wgrad(const float* dy, const float* x, float* dw, int N, int C, int K,
+                                      int acc, void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_wgrad(dy, x, dw, N, 4, 4, C, K, 1, 0, acc, ws, wsb, s);
+}
+// ConvTranspose2d(Cin,Cout,4,2,1) == dgrad of Conv2d(C=Cout -> K=Cin) on the 2Hin x 2Win grid
+extern "C" int dg_convT4x4s2_fwd(const float* x, const float* w, float* y, int N, int Hin, int Win, int Cin, int Cout,
+                                 void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_dgrad(x, w, y, N, 2 * Hin, 2 * Win, Cout, Cin, 2, 1, ws, wsb, s);
+}
+extern "C" int dg_convT4x4s2_dgrad(const float* dy, const float* w, float* dx, int N, int Hin, int Win, int Cin, int Cout,
+                                   void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_fwd(dy, w, dx, N, 2 * Hin, 2 * Win, Cout, Cin, 2, 1, ws, wsb, s);
+}
+extern "C" int dg_convT4x4s2_wgrad(const float* dy, const float* x, float* dw, int N, int Hin, int Win, int Cin, int Cout,
+                                   int acc, void* ws, size_t wsb, dg_stream_t s) {
+    // dw[cin][r][s][cout] = sum x[.., cin] * dy[.., cout] : roles (dy := x, x := dy)
+    return dg_conv_wgrad(x, dy, dw, N, 2 * Hin, 2 * Win, Cout, Cin, 2, 1, acc, ws, wsb, s);
+}
+extern "C" int dg_convT4x4_1to4_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout,
+                                    void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_dgrad(x, w, y, N, 4, 4, Cout, Cin, 1, 0, ws, wsb, s);
+}
+extern "C" int dg_convT4x4_1to4_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
+                                      void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_fwd(dy, w, dx, N, 4, 4, Cout, Cin, 1, 0, ws, wsb, s);
+}
+extern "C" int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int Cout,
+                                      int acc, void* ws, size_t wsb, dg_stream_t s) {
+    return dg_conv_wgrad(x, dy, dw, N, 4, 4, Cout, Cin, 1, 0, acc, ws, wsb, s);
+}
+
+// ---- 3-channel image side, forward direction (conv1 forward / last-convT input-grad) ----------------
+extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
+                                   int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(x_nchw && w && y_nhwc, "dg_conv4x4s2_c3_fwd: null pointer");
+    DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_fwd: bad N/K (%d,%d)", N, K);
+    DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd: H,W must be powers of two");
+    DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_fwd: tensor too large");
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd: bad act %d", act);
+    IgemmArgs a = IgemmArgs();
+    a.A = x_nchw; a.B = w; a.C = y_nhwc;
+    a.N = N; a.H = H; a.W = W; a.Cc = 3; a.K = K;
+    a.Ho = H / 2; a.Wo = W / 2; a.lgHo = dg_ilog2(a.Ho); a.lgWo = dg_ilog2(a.Wo);
+    a.stride = 2; a.pad = 1;
+    a.M = N * a.Ho * a.Wo; a.Ng = K; a.R = 48;
+    a.nIt = 3; a.itPerSplit = 3; a.splits = 1;
+    a.act = act; a.slope = slope;
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 64) {
+        a.tilesM = (a.M + 255) / 256; a.tilesN = 1;
+        launch_igemm<MODE_FWD_C3, 4, 1, 16>(a, 1, st);
+    } else {
+        a.tilesM = (a.M + 127) / 128; a.tilesN = (K + 127) / 128;
+        launch_igemm<MODE_FWD_C3, 2, 2, 16>(a, 1, st);
+    }
+    DG_CHECK_LAUNCH("dg_conv4x4s2_c3_fwd");
+    return DG_OK;
+}

@@ -1,0 +1,167 @@
+// Loss kernels: scalars stay in device memory, reductions are two-stage with a fixed order
+// (block partials -> one block, fp64) so results are bitwise reproducible.
+//   MSE   nn.MSELoss()            image_translation.py:267,349-350
+//   BCE   nn.BCELoss()            image_translation.py:268,162-166  (log clamp -100; backward guard 1e-12;
+//                                 deliberately NOT fused with the sigmoid)
+//   FM    get_fm_loss, one layer  image_translation.py:136-144 (HingeEmbeddingLoss(x, ones) == mean(x))
+#include "dg_common.h"
+
+#define LOSS_MAX_BLOCKS 1024
+
+extern "C" size_t dg_loss_workspace_bytes(void) { return LOSS_MAX_BLOCKS * sizeof(double); }
+
+__global__ __launch_bounds__(256) void final_sum_kernel(const double* __restrict__ part, int nparts, double scale,
+                                                        float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = dg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+__device__ __forceinline__ void block_partial_store(float v, double* part) {
+    __shared__ double red[4];
+    double d = dg_wave_sum_d((double)v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, long n,
+                                                          double* __restrict__ part) {
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 a = *(const f32x4*)(x + i * 4), b = *(const f32x4*)(t + i * 4);
+        const f32x4 d = a - b;
+        s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long e = n4 * 4; e < n; ++e) s += (x[e] - t[e]) * (x[e] - t[e]);
+    block_partial_store(s, part);
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, long n,
+                                                      const float* __restrict__ gout, float* __restrict__ dx) {
+    const float sc = 2.f * gout[0] / (float)n;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 a = *(const f32x4*)(x + i * 4), b = *(const f32x4*)(t + i * 4);
+        *(f32x4*)(dx + i * 4) = (a - b) * sc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long e = n4 * 4; e < n; ++e) dx[e] = (x[e] - t[e]) * sc;
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, int n, float label, float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = p[i];
+        const float l1 = fmaxf(logf(v), -100.f), l0 = fmaxf(logf(1.f - v), -100.f);
+        s += (double)((label - 1.f) * l0 - label * l1);
+    }
+    s = dg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / n);
+}
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ p, int n, float label,
+                                                      const float* __restrict__ gout, float* __restrict__ dp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = p[i];
+    dp[i] = gout[0] * (v - label) / fmaxf((1.f - v) * v, 1e-12f) / (float)n;
+}
+
+// diff[j] = mean_n real[n][j] - mean_n fake[n][j];  partial sum of diff^2
+__global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake, int N,
+                                                     long J, float* __restrict__ diff, double* __restrict__ part) {
+    float s = 0.f;
+    const long j4n = J >> 2;
+    const float inv = 1.f / (float)N;
+    for (long j4 = (long)blockIdx.x * 256 + threadIdx.x; j4 < j4n; j4 += (long)gridDim.x * 256) {
+        f32x4 sr = {0.f, 0.f, 0.f, 0.f}, sf = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) {
+            sr += *(const f32x4*)(real + (long)n * J + j4 * 4);
+            sf += *(const f32x4*)(fake + (long)n * J + j4 * 4);
+        }
+        const f32x4 d = sr * inv - sf * inv;
+        *(f32x4*)(diff + j4 * 4) = d;
+        s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+    block_partial_store(s, part);
+}
+__global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ diff, int N, long J, const float* __restrict__ gout,
+                                                     float* __restrict__ dreal, float* __restrict__ dfake) {
+    // d loss / d real[n][j] = 2*diff[j] / (N*J);  d/d fake = -that
+    const float sc = 2.f * gout[0] / ((float)N * (float)J);
+    const long j4n = J >> 2;
+    const long total = j4n * N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long n = idx / j4n, j4 = idx - n * j4n;
+        const f32x4 d = *(const f32x4*)(diff + j4 * 4) * sc;
+        if (dreal) *(f32x4*)(dreal + n * J + j4 * 4) = d;
+        if (dfake) *(f32x4*)(dfake + n * J + j4 * 4) = -d;
+    }
+}
+
+static int loss_grid(long work) {
+    long g = (work + 255) / 256;
+    if (g > LOSS_MAX_BLOCKS) g = LOSS_MAX_BLOCKS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int dg_mse_fwd(const float* x, const float* t, size_t n, float* loss, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(x && t && loss && n > 0, "dg_mse_fwd: bad argument");
+    if (!ws || ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_mse_fwd: workspace too small");
+    const int g = loss_grid((long)(n / 4) + 1);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(g), dim3(256), 0, st, x, t, (long)n, (double*)ws);
+    DG_CHECK_LAUNCH("mse_partial");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)n, loss);
+    DG_CHECK_LAUNCH("mse_final");
+    return DG_OK;
+}
+extern "C" int dg_mse_bwd(const float* x, const float* t, size_t n, const float* gout, float* dx, dg_stream_t stream) {
+    DG_CHECK_ARG(x && t && gout && dx && n > 0, "dg_mse_bwd: bad argument");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(loss_grid((long)(n / 4) + 1) * 2), dim3(256), 0, (hipStream_t)stream, x, t, (long)n, gout, dx);
+    DG_CHECK_LAUNCH("mse_bwd");
+    return DG_OK;
+}
+extern "C" int dg_bce_fwd(const float* p, int n, float label, float* loss, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    DG_CHECK_ARG(p && loss && n > 0, "dg_bce_fwd: bad argument");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, label, loss);
+    DG_CHECK_LAUNCH("bce_fwd");
+    return DG_OK;
+}
+extern "C" int dg_bce_bwd(const float* p, int n, float label, const float* gout, float* dp, dg_stream_t stream) {
+    DG_CHECK_ARG(p && gout && dp && n > 0, "dg_bce_bwd: bad argument");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, n, label, gout, dp);
+    DG_CHECK_LAUNCH("bce_bwd");
+    return DG_OK;
+}
+extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss, void* ws,
+                         size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(real && fake && diff && loss && N > 0 && J > 0 && J % 4 == 0, "dg_fm_fwd: bad argument");
+    if (!ws || ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
+    const int g = loss_grid((long)(J / 4));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fm_fwd_kernel, dim3(g), dim3(256), 0, st, real, fake, N, (long)J, diff, (double*)ws);
+    DG_CHECK_LAUNCH("fm_fwd");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)J, loss);
+    DG_CHECK_LAUNCH("fm_final");
+    return DG_OK;
+}
+extern "C" int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t stream) {
+    DG_CHECK_ARG(diff && gout && N > 0 && J > 0 && J % 4 == 0, "dg_fm_bwd: bad argument");
+    const long total = (long)(J / 4) * N;
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(fm_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, dreal, dfake);
+    DG_CHECK_LAUNCH("fm_bwd");
+    return DG_OK;
+}

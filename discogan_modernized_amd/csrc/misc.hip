@@ -1,0 +1,59 @@
+// Error plumbing, options, and NCHW <-> NHWC layout helpers (tests / ingest of foreign tensors;
+// not on the training hot path).
+#include "dg_common.h"
+#include <string.h>
+
+thread_local char dg_err_buf[512] = "";
+static int g_options[DG_OPT_COUNT] = {0};
+
+int dg_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dg_err_buf, sizeof(dg_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int dg_get_option(int idx) { return (idx >= 0 && idx < DG_OPT_COUNT) ? g_options[idx] : 0; }
+
+extern "C" int dg_version(void) { return 100; }
+extern "C" const char* dg_last_error(void) { return dg_err_buf; }
+extern "C" int dg_set_option(const char* name, int value) {
+    if (!name) return dg_fail(DG_ERR_INVALID, "dg_set_option: null name");
+    if (!strcmp(name, "splitk")) g_options[DG_OPT_SPLITK] = value;
+    else if (!strcmp(name, "kt")) g_options[DG_OPT_KT] = value;
+    else if (!strcmp(name, "target_wgs")) g_options[DG_OPT_TARGET_WGS] = value;
+    else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);
+    return DG_OK;
+}
+
+// 32x32 tile transpose through LDS between the [C] and [H*W] axes of one image
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int Cn) {
+    // x: [B][R][Cn] -> y: [B][Cn][R]
+    __shared__ float tile[32][33];
+    const long boff = (long)blockIdx.z * R * Cn;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < R && c < Cn) tile[j][tx] = x[boff + (long)r * Cn + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < R && c < Cn) y[boff + (long)c * R + r] = tile[tx][j];
+    }
+}
+static int launch_transpose(const float* x, float* y, int B, int R, int Cn, hipStream_t st) {
+    dim3 grid((Cn + 31) / 32, (R + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, x, y, R, Cn);
+    DG_CHECK_LAUNCH("transpose");
+    return DG_OK;
+}
+extern "C" int dg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s) {
+    DG_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && N < 65536, "dg_nchw_to_nhwc: bad argument");
+    return launch_transpose(x, y, N, C, H * W, (hipStream_t)s);  // [N][C][HW] -> [N][HW][C]
+}
+extern "C" int dg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s) {
+    DG_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && N < 65536, "dg_nhwc_to_nchw: bad argument");
+    return launch_transpose(x, y, N, H * W, C, (hipStream_t)s);  // [N][HW][C] -> [N][C][HW]
+}

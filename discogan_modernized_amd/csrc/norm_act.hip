@@ -1,0 +1,314 @@
+// Training-mode BatchNorm2d + activation on NHWC [M][C] tensors, and stand-alone activations.
+// Replaces nn.BatchNorm2d + in-place LeakyReLU(0.2)/ReLU (model.py:12-13,...,115-116) and their
+// autograd backward; nn.Sigmoid / first-layer LeakyReLU backward (model.py:9,36).
+// All kernels are HBM-bound streaming passes: 16-byte loads, lanes along the channel axis.
+//
+//   stats   : per-channel sum / sum-of-squares, fp32 per-thread partials over short row runs,
+//             block partials to the workspace, finalised in fp64 (fixed order -> deterministic)
+//   apply   : z = act((y - mean) * (gamma*invstd) + beta)
+//   backward: g = dz * act'(u) with u recomputed bit-identically from y;
+//             dbeta = sum g, dgamma = sum g*xhat, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+#include "dg_common.h"
+
+#define BN_TX 32  // float4 lanes along channels -> 128 channels per block
+#define BN_TY 8   // row lanes
+
+__device__ __forceinline__ float bn_norm(float y, float mean, float gs, float beta) { return fmaf(y - mean, gs, beta); }
+
+static void bn_grid(int M, int C, int* cchunks, int* rchunks) {
+    *cchunks = (C + 4 * BN_TX - 1) / (4 * BN_TX);
+    int rc = 2048 / *cchunks;
+    int maxrc = (M + BN_TY - 1) / BN_TY;  // at least one row per row-lane
+    if (rc > maxrc) rc = maxrc;
+    if (rc < 1) rc = 1;
+    *rchunks = rc;
+}
+
+// part layout: [2][rchunks][C]  (0: sum, 1: sumsq)
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
+                                                               int M, int C, int rchunks) {
+    __shared__ f32x4 red[2][BN_TY][BN_TX];
+    const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+    const int c = (blockIdx.x * BN_TX + tx) * 4;
+    const int rows_per = (M + rchunks - 1) / rchunks;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int r = r0 + ty; r < r1; r += BN_TY) {
+            const f32x4 v = *(const f32x4*)(y + (long)r * C + c);
+            s += v;
+            q += v * v;
+        }
+    }
+    red[0][ty][tx] = s;
+    red[1][ty][tx] = q;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+        for (int j = 1; j < BN_TY; ++j) {
+            s += red[0][j][tx];
+            q += red[1][j][tx];
+        }
+        *(f32x4*)(part + (long)blockIdx.y * C + c) = s;
+        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int M, int C, int rchunks,
+                                                                float eps, float momentum, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                float* __restrict__ saved) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rchunks; ++r) {
+        s += (double)part[(long)r * C + c];
+        q += (double)part[((long)rchunks + r) * C + c];
+    }
+    const double mean = s / M;
+    double var = q / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    saved[c] = (float)mean;
+    saved[C + c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, long total4,
+                                                         int C, const float* __restrict__ saved,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, float slope) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) * 4;
+        const f32x4 v = *(const f32x4*)(y + idx * 4);
+        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
+        *(f32x4*)(z + idx * 4) = o;
+    }
+}
+
+__device__ __forceinline__ float act_grad(float u, int act, float slope) {
+    // derivative taken from the sign of the activation input == sign of its output (in-place
+    // semantics of the reference: leaky_relu_backward(result), threshold_backward(result))
+    if (act == DG_ACT_LEAKY) return u > 0.f ? 1.f : slope;
+    if (act == DG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// part layout: [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                             float* __restrict__ part, int M, int C, int rchunks,
+                                                             const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act, float slope) {
+    __shared__ f32x4 red[2][BN_TY][BN_TX];
+    const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+    const int c = (blockIdx.x * BN_TX + tx) * 4;
+    const int rows_per = (M + rchunks - 1) / rchunks;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        for (int r = r0 + ty; r < r1; r += BN_TY) {
+            const f32x4 v = *(const f32x4*)(y + (long)r * C + c);
+            const f32x4 d = *(const f32x4*)(dz + (long)r * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = bn_norm(v[j], mean[j], g[j] * istd[j], b[j]);
+                const float gg = d[j] * act_grad(u, act, slope);
+                s[j] += gg;
+                q[j] += gg * ((v[j] - mean[j]) * istd[j]);
+            }
+        }
+    }
+    red[0][ty][tx] = s;
+    red[1][ty][tx] = q;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+        for (int j = 1; j < BN_TY; ++j) {
+            s += red[0][j][tx];
+            q += red[1][j][tx];
+        }
+        *(f32x4*)(part + (long)blockIdx.y * C + c) = s;
+        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
+    }
+}
+
+// coef: [2][C] = dbeta/M, dgamma/M  (kept in the workspace after the partials)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int M, int C, int rchunks,
+                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rchunks; ++r) {
+        s += (double)part[(long)r * C + c];
+        q += (double)part[((long)rchunks + r) * C + c];
+    }
+    coef[c] = (float)(s / M);
+    coef[C + c] = (float)(q / M);
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                           float* __restrict__ dy, long total4, int C,
+                                                           const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ coef,
+                                                           int act, float slope) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) * 4;
+        const f32x4 v = *(const f32x4*)(y + idx * 4);
+        const f32x4 d = *(const f32x4*)(dz + idx * 4);
+        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
+        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+        const f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + C + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gs = g[j] * istd[j];
+            const float u = bn_norm(v[j], mean[j], gs, b[j]);
+            const float gg = d[j] * act_grad(u, act, slope);
+            const float xhat = (v[j] - mean[j]) * istd[j];
+            o[j] = gs * (gg - c1[j] - xhat * c2[j]);
+        }
+        *(f32x4*)(dy + idx * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total4,
+                                                      long n, int act, float slope) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        if (idx * 4 + 3 < n) {
+            const f32x4 v = *(const f32x4*)(x + idx * 4);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = act == DG_ACT_SIGMOID ? 1.f / (1.f + expf(-v[j])) : dg_apply_act(v[j], act, slope);
+            *(f32x4*)(y + idx * 4) = o;
+        } else {
+            for (long e = idx * 4; e < n; ++e)
+                y[e] = act == DG_ACT_SIGMOID ? 1.f / (1.f + expf(-x[e])) : dg_apply_act(x[e], act, slope);
+        }
+    }
+}
+
+__device__ __forceinline__ float act_bwd_one(float dy, float out, int act, float slope) {
+    if (act == DG_ACT_SIGMOID) return dy * (1.f - out) * out;  // sigmoid_backward: grad * (1 - y) * y
+    if (act == DG_ACT_LEAKY) return out > 0.f ? dy : dy * slope;
+    if (act == DG_ACT_RELU) return out > 0.f ? dy : 0.f;
+    return dy;
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                      float* __restrict__ dx, long total4, long n, int act, float slope) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        if (idx * 4 + 3 < n) {
+            const f32x4 d = *(const f32x4*)(dy + idx * 4), o = *(const f32x4*)(out + idx * 4);
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = act_bwd_one(d[j], o[j], act, slope);
+            *(f32x4*)(dx + idx * 4) = r;
+        } else {
+            for (long e = idx * 4; e < n; ++e) dx[e] = act_bwd_one(dy[e], out[e], act, slope);
+        }
+    }
+}
+
+static int stream_grid(long total4) {
+    long g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" size_t dg_bn_workspace_bytes(int M, int C) {
+    int cc, rc;
+    bn_grid(M, C, &cc, &rc);
+    return ((size_t)2 * rc * C + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
+                                 float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
+                                 dg_stream_t stream) {
+    DG_CHECK_ARG(y && saved, "dg_bn_train_stats: null pointer");
+    DG_CHECK_ARG(M >= 2, "dg_bn_train_stats: Expected more than 1 value per channel when training (M=%d)", M);
+    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_train_stats: C=%d must be a multiple of 4", C);
+    if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
+        return dg_fail(DG_ERR_WORKSPACE, "dg_bn_train_stats: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
+    int cc, rc;
+    bn_grid(M, C, &cc, &rc);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc);
+    DG_CHECK_LAUNCH("bn_stats_partial");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, M, C, rc, eps,
+                       momentum, running_mean, running_var, nbt, saved);
+    DG_CHECK_LAUNCH("bn_stats_finalize");
+    return DG_OK;
+}
+
+extern "C" int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
+                             const float* beta, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
+    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_fwd: C=%d must be a multiple of 4", C);
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
+    const long total4 = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
+                       saved, gamma, beta, act, slope);
+    DG_CHECK_LAUNCH("bn_act_fwd");
+    return DG_OK;
+}
+
+extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
+                             const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                             int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
+    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_bwd: C=%d must be a multiple of 4", C);
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
+    if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
+        return dg_fail(DG_ERR_WORKSPACE, "dg_bn_act_bwd: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
+    int cc, rc;
+    bn_grid(M, C, &cc, &rc);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* coef = part + (size_t)2 * rc * C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, saved, gamma, beta, act, slope);
+    DG_CHECK_LAUNCH("bn_bwd_partial");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, M, C, rc, coef,
+                       dgamma, dbeta, accumulate);
+    DG_CHECK_LAUNCH("bn_bwd_finalize");
+    const long total4 = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
+                       beta, (const float*)coef, act, slope);
+    DG_CHECK_LAUNCH("bn_bwd_apply");
+    return DG_OK;
+}
+
+extern "C" int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(x && y, "dg_act_fwd: null pointer");
+    DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_fwd: bad act %d", act);
+    if (n == 0) return DG_OK;
+    const long total4 = (long)((n + 3) / 4);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, (long)n, act, slope);
+    DG_CHECK_LAUNCH("act_fwd");
+    return DG_OK;
+}
+extern "C" int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(dy && out && dx, "dg_act_bwd: null pointer");
+    DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_bwd: bad act %d", act);
+    if (n == 0) return DG_OK;
+    const long total4 = (long)((n + 3) / 4);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, total4, (long)n, act, slope);
+    DG_CHECK_LAUNCH("act_bwd");
+    return DG_OK;
+}

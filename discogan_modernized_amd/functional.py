@@ -1,0 +1,198 @@
+"""torch.autograd glue: each Function's forward/backward is one or two C-ABI kernel calls.
+
+Autograd only sequences the calls (the reference relies on ``loss.backward()``,
+image_translation.py:385-390); no arithmetic is done by ATen except gradient accumulation into
+``.grad`` buffers.  Functions skip work autograd does not need (``ctx.needs_input_grad``), which is
+how the dead backward work of the reference disappears when the caller freezes the
+side that is not stepped.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class ConvFn(Function):
+    """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        x = ops.as_nhwc(x)
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        return ops.conv_fwd(x, w, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        dy = ops.as_nhwc(dy)
+        dx = ops.conv_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(dy, x, stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class ConvTransposeFn(Function):
+    """nn.ConvTranspose2d(Cin,Cout,4,stride,pad,bias=False), interior: forward = conv dgrad with the
+    same weight tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        x = ops.as_nhwc(x)
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        hin, win = x.shape[2], x.shape[3]
+        hout, wout = (hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4
+        ctx.out_hw = (hout, wout)
+        return ops.conv_dgrad(x, w, (hout, wout), stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        dy = ops.as_nhwc(dy)
+        dx = ops.conv_fwd(dy, w, stride, pad) if ctx.needs_input_grad[0] else None
+        # dw[cin][r][s][cout] = sum x[..cin] * dy[..cout]: conv wgrad with roles (dy := x, x := dy)
+        dw = ops.conv_wgrad(x, dy, stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class ConvC3Fn(Function):
+    """First layer nn.Conv2d(3,K,4,2,1) on the NCHW image, with the following in-place
+    LeakyReLU fused (model.py:8-9, 80-81)."""
+
+    @staticmethod
+    def forward(ctx, x, w, act, slope):
+        y = ops.c3_fwd(x, w, act, slope)
+        ctx.save_for_backward(x, w, y)
+        ctx.act = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, slope = ctx.act
+        g = ops.act_bwd(dy, y, act, slope) if act != ops.ACT_NONE else ops.as_nhwc(dy)
+        dx = ops.c3_dgrad(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
+        dw = ops.c3_wgrad(g, x) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class ConvTransposeC3Fn(Function):
+    """Last layer nn.ConvTranspose2d(K,3,4,2,1) + Sigmoid producing the NCHW image (model.py:142-143)."""
+
+    @staticmethod
+    def forward(ctx, x, w, act):
+        x = ops.as_nhwc(x)
+        out = ops.c3_dgrad(x, w, act)
+        ctx.save_for_backward(x, w, out)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        g = ops.act_bwd(dout, out, ctx.act) if ctx.act != ops.ACT_NONE else dout.contiguous()
+        dx = ops.c3_fwd(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
+        dw = ops.c3_wgrad(x, g) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class BatchNormActFn(Function):
+    """nn.BatchNorm2d (+ in-place LeakyReLU / ReLU).  Training mode updates the running buffers in
+    the kernel exactly like PyTorch (momentum 0.1, unbiased running_var, num_batches_tracked += 1)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope):
+        y = ops.as_nhwc(y)
+        if training:
+            saved = ops.bn_train_stats(y, running_mean, running_var, nbt, eps, momentum)
+        else:
+            saved = torch.stack([running_mean, torch.rsqrt(running_var + eps)])
+        z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope)
+        ctx.save_for_backward(y, saved, gamma, beta)
+        ctx.cfg = (act, slope, training)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, saved, gamma, beta = ctx.saved_tensors
+        act, slope, training = ctx.cfg
+        if not training:
+            raise RuntimeError("BatchNormActFn: backward in eval mode is not supported")
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p)
+        return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, None, None, None)
+
+
+class ActFn(Function):
+    """Stand-alone LeakyReLU / ReLU / Sigmoid (backward from the OUTPUT, in-place semantics)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        out = ops.act_fwd(x, act, slope)
+        ctx.save_for_backward(out)
+        ctx.cfg = (act, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        return ops.act_bwd(dy, out, act, slope), None, None
+
+
+class MSELossFn(Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        loss, xd, td = ops.mse_fwd(x, t)
+        ctx.save_for_backward(xd, td)
+        ctx.in_strides = x.stride()
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        xd, td = ctx.saved_tensors
+        gout = gout.contiguous()
+        dx = ops.mse_bwd(xd, td, gout) if ctx.needs_input_grad[0] else None
+        dt = None
+        if ctx.needs_input_grad[1]:
+            dt = ops.mse_bwd(td, xd, gout)
+        return dx, dt
+
+
+class BCELossFn(Function):
+    """nn.BCELoss against a constant label tensor (image_translation.py:157-166)."""
+
+    @staticmethod
+    def forward(ctx, p, label):
+        shape = p.shape
+        loss, pc = ops.bce_fwd(p.reshape(-1), label)
+        ctx.save_for_backward(pc)
+        ctx.cfg = (label, shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pc,) = ctx.saved_tensors
+        label, shape = ctx.cfg
+        return ops.bce_bwd(pc, label, gout.contiguous()).reshape(shape), None
+
+
+class FeatureMatchFn(Function):
+    """One layer of get_fm_loss: mean((real.mean(0) - fake.mean(0))**2)."""
+
+    @staticmethod
+    def forward(ctx, real, fake):
+        loss, diff, rd, fd = ops.fm_fwd(real, fake)
+        ctx.save_for_backward(diff, rd, fd)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        diff, rd, fd = ctx.saved_tensors
+        dreal, dfake = ops.fm_bwd(diff, rd, fd, gout.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dreal, dfake

@@ -1,0 +1,236 @@
+"""Drop-in ``Generator`` / ``Discriminator`` (reference model.py:5-225) on the HIP kernels.
+
+Same constructor signatures, attribute names (``conv1..conv8``, ``bn2..bn7``, ``encoder``,
+``decoder``, ``main``), parameter order, state_dict keys / logical shapes and return types as the
+reference, so checkpoints (``gen_A_*.pth`` ...) interoperate.  The optional
+``image_size`` argument applies the depth rule: the default 512 IS the
+reference network; 64 gives the original DiscoGAN 64 px network the reference CLI defaults to
+but cannot build (model.py:8-35 is hard-wired to 512).
+
+Layer modules hold the parameters; ``forward`` fuses each [conv, BatchNorm, activation] group into
+kernel calls.  Interior feature maps are logical NCHW tensors with NHWC memory; the image side is
+plain NCHW as in the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import ops
+
+
+def stage_channels(image_size: int):
+    n = int(round(math.log2(image_size))) - 2
+    if n < 1 or 2 ** (n + 2) != image_size:
+        raise ValueError(f"image_size must be a power of two >= 8, got {image_size}")
+    return [min(64 * 2 ** i, 2048) for i in range(n)]
+
+
+def _init_weight(shape):
+    """Same RNG consumption and values as nn.Conv2d / nn.ConvTranspose2d.reset_parameters
+    (kaiming_uniform_(a=sqrt(5)) on the logical [d0,d1,4,4] tensor)."""
+    w = torch.empty(shape)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    return w
+
+
+class _FlatGradMixin:
+    """Keeps ``.grad`` views of a flat gradient buffer alive across ``zero_grad`` (see optim.Adam)."""
+
+    def zero_grad(self, set_to_none: bool = True):  # noqa: D401
+        for p in self.parameters():
+            flat = getattr(p, "_dg_flat_grad", None)
+            if flat is not None:
+                flat.zero_()
+                p.grad = flat
+            elif p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_()
+                    p.grad.zero_()
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(in,out,4,stride,pad,bias=False) (model.py:8,11,...,35)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=4, stride=2, padding=1, bias=False):
+        super().__init__()
+        if kernel_size != 4 or bias or (stride, padding) not in ((2, 1), (1, 0)):
+            raise ValueError("only Conv2d(k=4, (s,p) in {(2,1),(1,0)}, bias=False) exists in the DiscoGAN path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.stride, self.padding = stride, padding
+        w = _init_weight((out_channels, in_channels, 4, 4))
+        if in_channels != 3:
+            w = ops.krsc_param(w)  # memory [K][4][4][C], logical shape unchanged
+        self.weight = nn.Parameter(w)
+
+    def forward(self, x, fused_act=ops.ACT_NONE, slope=0.2):
+        if self.in_channels == 3:
+            return F.ConvC3Fn.apply(x, self.weight, fused_act, slope)
+        return F.ConvFn.apply(x, self.weight, self.stride, self.padding)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=(4, 4), stride={self.stride}, padding={self.padding}, bias=False"
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d(in,out,4,stride,pad,bias=False) (model.py:114,118,...,142)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=4, stride=2, padding=1, bias=False):
+        super().__init__()
+        if kernel_size != 4 or bias or (stride, padding) not in ((2, 1), (1, 0)):
+            raise ValueError("only ConvTranspose2d(k=4, (s,p) in {(2,1),(1,0)}, bias=False) exists in the DiscoGAN path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.stride, self.padding = stride, padding
+        w = _init_weight((in_channels, out_channels, 4, 4))
+        if out_channels != 3:
+            w = ops.krsc_param(w)  # memory [Cin][4][4][Cout]
+        self.weight = nn.Parameter(w)
+
+    def forward(self, x, fused_act=ops.ACT_NONE):
+        if self.out_channels == 3:
+            return F.ConvTransposeC3Fn.apply(x, self.weight, fused_act)
+        return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=(4, 4), stride={self.stride}, padding={self.padding}, bias=False"
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d(C): eps 1e-5, momentum 0.1, affine, track_running_stats (model.py:12,...)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2):
+        if self.training and y.shape[0] * y.shape[2] * y.shape[3] <= 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
+        return F.BatchNormActFn.apply(y, self.weight, self.bias, self.running_mean, self.running_var,
+                                      self.num_batches_tracked, self.training, self.eps, self.momentum, fused_act, slope)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine=True, track_running_stats=True"
+
+
+class _Act(nn.Module):
+    act = ops.ACT_NONE
+
+    def __init__(self, slope=0.0, inplace=False):
+        super().__init__()
+        self.negative_slope, self.inplace = slope, inplace
+
+    def forward(self, x):
+        return F.ActFn.apply(x, self.act, self.negative_slope)
+
+
+class LeakyReLU(_Act):
+    act = ops.ACT_LEAKY
+
+    def __init__(self, negative_slope=0.01, inplace=False):
+        super().__init__(negative_slope, inplace)
+
+
+class ReLU(_Act):
+    act = ops.ACT_RELU
+
+    def __init__(self, inplace=False):
+        super().__init__(0.0, inplace)
+
+
+class Sigmoid(_Act):
+    act = ops.ACT_SIGMOID
+
+    def __init__(self):
+        super().__init__(0.0, False)
+
+
+def _run_fused(layers, x):
+    """Walk a list of layer modules fusing [conv][BatchNorm][activation] groups into kernel calls."""
+    i, n = 0, len(layers)
+    while i < n:
+        conv = layers[i]
+        bn = layers[i + 1] if i + 1 < n and isinstance(layers[i + 1], BatchNorm2d) else None
+        j = i + (2 if bn is not None else 1)
+        act_mod = layers[j] if j < n and isinstance(layers[j], _Act) else None
+        act = act_mod.act if act_mod is not None else ops.ACT_NONE
+        slope = act_mod.negative_slope if act_mod is not None else 0.0
+        if bn is not None:
+            x = bn(conv(x), act, slope)
+        elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
+            x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
+        elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
+            x = conv(x, act)                                # last convT + Sigmoid in one kernel
+        else:
+            x = conv(x)
+            if act_mod is not None:
+                x = act_mod(x)
+        i = j + (1 if act_mod is not None else 0)
+    return x
+
+
+class Discriminator(_FlatGradMixin, nn.Module):
+    """Reference model.py:5-69.  Returns ``(sigmoid [N,1,1,1], [relu2, ..., relu_n])``."""
+
+    def __init__(self, image_size: int = 512):
+        super().__init__()
+        ch = stage_channels(image_size)
+        self.image_size, self.n_stages = image_size, len(ch)
+        cin = 3
+        for i, c in enumerate(ch, start=1):
+            setattr(self, f"conv{i}", Conv2d(cin, c, 4, 2, 1, bias=False))
+            if i >= 2:
+                setattr(self, f"bn{i}", BatchNorm2d(c))
+            setattr(self, f"relu{i}", LeakyReLU(0.2, inplace=True))
+            cin = c
+        setattr(self, f"conv{len(ch) + 1}", Conv2d(cin, 1, 4, 1, 0, bias=False))
+        self.sigmoid = Sigmoid()
+
+    def forward(self, input_tensor):
+        feats = []
+        h = self.conv1(input_tensor, ops.ACT_LEAKY, self.relu1.negative_slope)
+        for i in range(2, self.n_stages + 1):
+            relu = getattr(self, f"relu{i}")
+            h = getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h), ops.ACT_LEAKY, relu.negative_slope)
+            feats.append(h)
+        out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))
+        return out, feats
+
+
+class Generator(_FlatGradMixin, nn.Module):
+    """Reference model.py:72-225 (``extra_layers`` True/False build the same network there too)."""
+
+    def __init__(self, extra_layers: bool = False, image_size: int = 512):
+        super().__init__()
+        ch = stage_channels(image_size)
+        self.image_size = image_size
+        enc = []
+        cin = 3
+        for i, c in enumerate(ch):
+            enc.append(Conv2d(cin, c, 4, 2, 1, bias=False))
+            if i >= 1:
+                enc.append(BatchNorm2d(c))
+            enc.append(LeakyReLU(0.2, inplace=True))
+            cin = c
+        enc += [Conv2d(cin, 100, 4, 1, 0, bias=False), BatchNorm2d(100), LeakyReLU(0.2, inplace=True)]
+        self.encoder = nn.Sequential(*enc)
+        dec = [ConvTranspose2d(100, ch[-1], 4, 1, 0, bias=False), BatchNorm2d(ch[-1]), ReLU(True)]
+        for i in range(len(ch) - 1, 0, -1):
+            dec += [ConvTranspose2d(ch[i], ch[i - 1], 4, 2, 1, bias=False), BatchNorm2d(ch[i - 1]), ReLU(True)]
+        dec += [ConvTranspose2d(ch[0], 3, 4, 2, 1, bias=False), Sigmoid()]
+        self.decoder = nn.Sequential(*dec)
+        self.main = None  # legacy hook, model.py:215-220
+
+    def forward(self, input_tensor):
+        if self.main is not None:
+            return self.main(input_tensor)
+        return _run_fused(list(self.decoder), _run_fused(list(self.encoder), input_tensor))

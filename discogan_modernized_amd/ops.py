@@ -1,0 +1,333 @@
+"""Tensor-level wrappers over the C ABI (device pointers + sizes; torch only supplies memory/streams).
+
+Layout conventions (see include/discogan_hip.h):
+  * interior activations: logical [N,C,H,W] tensors whose MEMORY is NHWC (torch channels_last);
+  * image side (3 channels): plain contiguous NCHW;
+  * Conv2d weight logical [K,C,4,4] stored KRSC; ConvTranspose2d weight logical [Cin,Cout,4,4] stored
+    [Cin,4,4,Cout]; 3-channel edge weights stay logically contiguous.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DiscoganHipError(
+                "discogan_modernized_amd ops need CUDA/HIP tensors (no CPU fallback exists); got a CPU tensor")
+        if t.dtype != torch.float32:
+            raise _lib.DiscoganHipError(f"fp32 tensors required, got {t.dtype}")
+
+
+# ---- layout helpers -------------------------------------------------------------------------------------
+def empty_nhwc(n, c, h, w, device):
+    """Logical [n,c,h,w] tensor backed by NHWC memory."""
+    return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def is_nhwc(x):
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def as_nhwc(x):
+    """Return x (logical NCHW) with NHWC memory; converts with the library's own transpose kernel."""
+    if is_nhwc(x):
+        return x
+    _check_dev(x)
+    xc = x.contiguous()
+    n, c, h, w = xc.shape
+    y = empty_nhwc(n, c, h, w, x.device)
+    _lib.check(_lib.load().dg_nchw_to_nhwc(_ptr(xc), _ptr(y), n, c, h, w, _stream()), "dg_nchw_to_nhwc")
+    return y
+
+
+def to_nchw_contiguous(x):
+    """Logical NCHW tensor with plain contiguous memory (for export / comparisons)."""
+    if x.is_contiguous():
+        return x
+    if is_nhwc(x):
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().dg_nhwc_to_nchw(_ptr(x), _ptr(y), n, c, h, w, _stream()), "dg_nhwc_to_nchw")
+        return y
+    return x.contiguous()
+
+
+def krsc_param(w_logical):
+    """[K,C,4,4] contiguous -> same logical tensor whose memory is [K,4,4,C] (dim 1 innermost)."""
+    return w_logical.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def is_krsc(w):
+    return w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _krsc(w):
+    return w if is_krsc(w) else krsc_param(w)
+
+
+def empty_krsc(k, c, device):
+    return torch.empty((k, 4, 4, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def _ws(nbytes, device):
+    if nbytes == 0:
+        return None, 0
+    t = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+    return t, t.numel() * 4
+
+
+# ---- interior convolutions ------------------------------------------------------------------------------
+def _out_hw(h, w, stride, pad):
+    return (h + 2 * pad - 4) // stride + 1, (w + 2 * pad - 4) // stride + 1
+
+
+def conv_fwd(x, w, stride, pad):
+    """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC."""
+    _check_dev(x, w)
+    x = as_nhwc(x)
+    w = _krsc(w)
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    ho, wo = _out_hw(h, wd, stride, pad)
+    y = empty_nhwc(n, k, ho, wo, x.device)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
+    _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+               "dg_conv_fwd")
+    return y
+
+
+def conv_dgrad(dy, w, x_hw, stride, pad):
+    """Input-gradient of that Conv2d == ConvTranspose2d forward. dy [N,K,Ho,Wo]; returns [N,C,H,W]."""
+    _check_dev(dy, w)
+    dy = as_nhwc(dy)
+    w = _krsc(w)
+    n, k = dy.shape[0], dy.shape[1]
+    c = w.shape[1]
+    h, wd = x_hw
+    dx = empty_nhwc(n, c, h, wd, dy.device)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
+    _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+               "dg_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
+    """Weight-gradient of that Conv2d: returns logical [K,C,4,4] (KRSC memory)."""
+    _check_dev(dy, x)
+    dy = as_nhwc(dy)
+    x = as_nhwc(x)
+    n, c, h, wd = x.shape
+    k = dy.shape[1]
+    dw = out if out is not None else empty_krsc(k, c, x.device)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
+    _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
+                               _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
+    return dw
+
+
+# ---- 3-channel edge layers ------------------------------------------------------------------------------
+def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
+    """x contiguous NCHW [N,3,H,W], w contiguous [K,3,4,4] -> NHWC-memory [N,K,H/2,W/2] (act fused)."""
+    _check_dev(x_nchw, w)
+    x = x_nchw.contiguous()
+    w = w.contiguous()
+    n, _, h, wd = x.shape
+    k = w.shape[0]
+    y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
+    _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
+               "dg_conv4x4s2_c3_fwd")
+    return y
+
+
+def c3_dgrad(dy, w, act=ACT_NONE):
+    """dy NHWC-memory [N,K,Ho,Wo], w contiguous [K,3,4,4] -> contiguous NCHW [N,3,2Ho,2Wo] (act fused)."""
+    _check_dev(dy, w)
+    dy = as_nhwc(dy)
+    w = w.contiguous()
+    n, k, ho, wo = dy.shape
+    dx = torch.empty((n, 3, 2 * ho, 2 * wo), device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _stream()),
+               "dg_conv4x4s2_c3_dgrad")
+    return dx
+
+
+def c3_wgrad(dy, x_nchw):
+    """dw [K,3,4,4] contiguous from dy NHWC-memory [N,K,Ho,Wo] and x NCHW [N,3,H,W]."""
+    _check_dev(dy, x_nchw)
+    dy = as_nhwc(dy)
+    x = x_nchw.contiguous()
+    n, k, ho, wo = dy.shape
+    h, wd = x.shape[2], x.shape[3]
+    dw = torch.empty((k, 3, 4, 4), device=dy.device, dtype=torch.float32)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_c3_wgrad_workspace_bytes(n, h, wd, k), dy.device)
+    _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, 0, _ptr(ws), wsb, _stream()),
+               "dg_conv4x4s2_c3_wgrad")
+    return dw
+
+
+# ---- BatchNorm + activation -----------------------------------------------------------------------------
+def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
+    _check_dev(y)
+    y = as_nhwc(y)
+    n, c, h, w = y.shape
+    m = n * h * w
+    saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
+    _lib.check(L.dg_bn_train_stats(_ptr(y), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                   _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
+    return saved
+
+
+def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
+    y = as_nhwc(y)
+    n, c, h, w = y.shape
+    z = empty_nhwc(n, c, h, w, y.device)
+    _lib.check(_lib.load().dg_bn_act_fwd(_ptr(y), _ptr(z), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+                                         act, slope, _stream()), "dg_bn_act_fwd")
+    return z
+
+
+def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True):
+    dz = as_nhwc(dz)
+    y = as_nhwc(y)
+    n, c, h, w = y.shape
+    m = n * h * w
+    dy = empty_nhwc(n, c, h, w, y.device)
+    dgamma = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
+    dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
+    _lib.check(L.dg_bn_act_bwd(_ptr(dz), _ptr(y), _ptr(dy), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act, slope,
+                               _ptr(dgamma), _ptr(dbeta), 0, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
+    return dy, dgamma, dbeta
+
+
+def _dense_like(x):
+    """empty tensor with x's shape AND memory layout (x must be dense)."""
+    return torch.empty_like(x, memory_format=torch.preserve_format)
+
+
+def _dense(x):
+    if x.is_contiguous() or is_nhwc(x):
+        return x
+    return x.contiguous()
+
+
+def act_fwd(x, act, slope=0.2):
+    _check_dev(x)
+    x = _dense(x)
+    y = _dense_like(x)
+    _lib.check(_lib.load().dg_act_fwd(_ptr(x), _ptr(y), x.numel(), act, slope, _stream()), "dg_act_fwd")
+    return y
+
+
+def act_bwd(dy, out, act, slope=0.2):
+    """Elementwise; dy is brought to out's memory layout first."""
+    _check_dev(dy, out)
+    out = _dense(out)
+    if dy.stride() != out.stride():
+        dyl = _dense_like(out)
+        dyl.copy_(dy)
+        dy = dyl
+    dx = _dense_like(out)
+    _lib.check(_lib.load().dg_act_bwd(_ptr(dy), _ptr(out), _ptr(dx), out.numel(), act, slope, _stream()), "dg_act_bwd")
+    return dx
+
+
+# ---- losses ---------------------------------------------------------------------------------------------
+def _loss_ws(device):
+    L = _lib.load()
+    return _ws(L.dg_loss_workspace_bytes(), device)
+
+
+def same_layout_pair(a, b):
+    """Bring b to a's dense memory layout (elementwise kernels index memory linearly)."""
+    a = _dense(a)
+    if b.stride() != a.stride():
+        bl = _dense_like(a)
+        bl.copy_(b)
+        b = bl
+    return a, b
+
+
+def mse_fwd(x, t):
+    _check_dev(x, t)
+    x, t = same_layout_pair(x, t)
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    ws, wsb = _loss_ws(x.device)
+    _lib.check(_lib.load().dg_mse_fwd(_ptr(x), _ptr(t), x.numel(), _ptr(loss), _ptr(ws), wsb, _stream()), "dg_mse_fwd")
+    return loss, x, t
+
+
+def mse_bwd(x, t, gout):
+    dx = _dense_like(x)
+    _lib.check(_lib.load().dg_mse_bwd(_ptr(x), _ptr(t), x.numel(), _ptr(gout), _ptr(dx), _stream()), "dg_mse_bwd")
+    return dx
+
+
+def bce_fwd(p, label):
+    _check_dev(p)
+    p = p.contiguous()
+    loss = torch.empty((), device=p.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_bce_fwd(_ptr(p), p.numel(), float(label), _ptr(loss), None, 0, _stream()), "dg_bce_fwd")
+    return loss, p
+
+
+def bce_bwd(p, label, gout):
+    dp = torch.empty_like(p)
+    _lib.check(_lib.load().dg_bce_bwd(_ptr(p), p.numel(), float(label), _ptr(gout), _ptr(dp), _stream()), "dg_bce_bwd")
+    return dp
+
+
+def fm_fwd(real, fake):
+    """One layer of get_fm_loss; real/fake logical [N,C,H,W] with identical dense layouts."""
+    _check_dev(real, fake)
+    real, fake = same_layout_pair(real, fake)
+    n = real.shape[0]
+    j = real.numel() // n
+    diff = torch.empty(j, device=real.device, dtype=torch.float32)
+    loss = torch.empty((), device=real.device, dtype=torch.float32)
+    ws, wsb = _loss_ws(real.device)
+    _lib.check(_lib.load().dg_fm_fwd(_ptr(real), _ptr(fake), n, j, _ptr(diff), _ptr(loss), _ptr(ws), wsb, _stream()),
+               "dg_fm_fwd")
+    return loss, diff, real, fake
+
+
+def fm_bwd(diff, like_real, like_fake, gout, need_real, need_fake):
+    n = like_fake.shape[0]
+    j = diff.numel()
+    dreal = _dense_like(like_real) if need_real else None
+    dfake = _dense_like(like_fake) if need_fake else None
+    _lib.check(_lib.load().dg_fm_bwd(_ptr(diff), n, j, _ptr(gout), _ptr(dreal), _ptr(dfake), _stream()), "dg_fm_bwd")
+    return dreal, dfake
+
+
+# ---- Adam -----------------------------------------------------------------------------------------------
+def adam_advance(state, lr, beta1, beta2):
+    _lib.check(_lib.load().dg_adam_advance(_ptr(state), lr, beta1, beta2, _stream()), "dg_adam_advance")
+
+
+def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _lib.check(_lib.load().dg_adam_step_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2,
+                                             eps, weight_decay, grad_scale, _stream()), "dg_adam_step_flat")

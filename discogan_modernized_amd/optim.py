@@ -1,0 +1,87 @@
+"""Adam over ONE flat fp32 buffer per parameter group (optim.Adam, image_translation.py:272-287).
+
+All parameters handed to ``Adam`` are moved (keeping each one's memory layout) into a single flat
+buffer; ``.grad`` of every parameter is a view of a matching flat gradient buffer.  One optimiser step
+is then two kernel launches (scalar advance + multi-tensor update), and data parallelism all-reduces
+the flat gradient buffer as one message.  Step count and bias corrections live on the device so a
+step can be captured in a hipGraph.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+_ALIGN = 64  # floats (256 B)
+
+
+class Adam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("discogan_modernized_amd.optim.Adam needs parameters on a HIP device (no CPU fallback)")
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.param_groups = [dict(params=self.params, **self.defaults)]
+        offs, total = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("all parameters must be fp32 on one device")
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.flat_p = torch.zeros(total, device=dev)
+        self.flat_g = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        self.state = torch.zeros(4, device=dev, dtype=torch.float64)
+        self.offsets = offs
+        with torch.no_grad():
+            for p, off in zip(self.params, offs):
+                n = p.numel()
+                view = self.flat_p[off:off + n].as_strided(p.shape, p.stride())
+                view.copy_(p.data)
+                p.data = view
+                gview = self.flat_g[off:off + n].as_strided(p.shape, p.stride())
+                p._dg_flat_grad = gview
+                p.grad = gview
+
+    # -- torch.optim.Optimizer surface used by the reference loop ------------------------------------
+    def zero_grad(self, set_to_none: bool = True):
+        self.flat_g.zero_()
+        for p in self.params:
+            if p.grad is not p._dg_flat_grad:
+                p.grad = p._dg_flat_grad
+
+    def _sync_foreign_grads(self):
+        # a caller may have replaced .grad (e.g. zero_grad(set_to_none=True) on a plain nn.Module)
+        for p in self.params:
+            if p.grad is None:
+                p._dg_flat_grad.zero_()
+                p.grad = p._dg_flat_grad
+            elif p.grad is not p._dg_flat_grad and p.grad.data_ptr() != p._dg_flat_grad.data_ptr():
+                p._dg_flat_grad.copy_(p.grad)
+                p.grad = p._dg_flat_grad
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0):
+        g = self.param_groups[0]
+        self._sync_foreign_grads()
+        ops.adam_advance(self.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+        ops.adam_step_flat(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.state,
+                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                           float(grad_scale))
+
+    def state_dict(self):
+        return dict(step=self.state[0:1].clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.state.zero_()
+        self.state[0:1].copy_(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = v

@@ -1,0 +1,201 @@
+"""The DiscoGAN training iteration, re-hosted on the HIP kernels.
+
+Mirrors the loop body of the reference (image_translation.py:336-390; DDP variant
+distributed_image_translation.py:466-518): 4 generator passes, 2 reconstruction losses, 4
+discriminator passes, GAN + feature-matching losses, the curriculum loss mix, then backward + Adam
+of ONE side (D when ``iters % update_interval == 0`` else G).
+
+Differences that do not change any result:
+  * dead backward work is skipped: in a D-step the generators run without an autograd graph and the
+    fakes are detached; in a G-step the discriminator parameters are frozen, so no D weight-grads
+    and no backward through the real passes.  The reference computes those and discards them.
+  * data parallelism averages ONLY the stepped side's flat gradient buffer (one RCCL all-reduce),
+    never broadcasts BatchNorm buffers (the reference's per-forward broadcast is what makes its DDP
+    backward raise), and keeps BN / feature-matching statistics rank-local like DDP does.
+  * steady-state iterations replay a captured hipGraph (zero_grad + forward + backward) instead of
+    re-dispatching ~600 kernels from Python.
+"""
+from __future__ import annotations
+
+from itertools import chain
+from types import SimpleNamespace
+
+import torch
+
+from . import losses as L
+from . import optim
+from .model import Discriminator, Generator
+
+LOG_KEYS = ("gen_loss_A", "gen_loss_B", "fm_loss_A", "fm_loss_B", "recon_loss_A", "recon_loss_B",
+            "dis_loss_A", "dis_loss_B", "gen_loss", "dis_loss")
+
+DEFAULTS = dict(learning_rate=2e-4, beta1=0.5, beta2=0.999, weight_decay=0.00001, gan_curriculum=10000,
+                starting_rate=0.01, default_rate=0.5, update_interval=3, model_arch="discogan")
+
+
+def default_args(**over):
+    d = dict(DEFAULTS)
+    d.update(over)
+    return SimpleNamespace(**d)
+
+
+class DiscoGANTrainer:
+    def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
+                 use_graph=False, skip_dead_work=True):
+        self.args = args or default_args()
+        for k, v in DEFAULTS.items():
+            if not hasattr(self.args, k):
+                setattr(self.args, k, v)
+        self.device = torch.device(device)
+        self.image_size = image_size
+        self.pg = process_group
+        self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.use_graph = use_graph
+        self.skip_dead_work = skip_dead_work
+        if seed is not None:
+            torch.manual_seed(seed)                      # distributed_image_translation.py:372
+        # construction order G_A, G_B, D_A, D_B on the host RNG (identical replicas on every rank)
+        self.generator_A = Generator(extra_layers=True, image_size=image_size).to(self.device)
+        self.generator_B = Generator(extra_layers=True, image_size=image_size).to(self.device)
+        self.discriminator_A = Discriminator(image_size=image_size).to(self.device)
+        self.discriminator_B = Discriminator(image_size=image_size).to(self.device)
+        self.nets = dict(gen_A=self.generator_A, gen_B=self.generator_B,
+                         dis_A=self.discriminator_A, dis_B=self.discriminator_B)
+        self.recon_criterion = L.MSELoss()
+        self.gan_criterion = L.BCELoss()
+        self.feat_criterion = L.HingeEmbeddingLoss()
+        a = self.args
+        self.optim_gen = optim.Adam(chain(self.generator_A.parameters(), self.generator_B.parameters()),
+                                    lr=a.learning_rate, betas=(a.beta1, a.beta2), weight_decay=a.weight_decay)
+        self.optim_dis = optim.Adam(chain(self.discriminator_A.parameters(), self.discriminator_B.parameters()),
+                                    lr=a.learning_rate, betas=(a.beta1, a.beta2), weight_decay=a.weight_decay)
+        self._graphs = {}
+        self._static = None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.world_size > 1 else None
+
+    # ---------------------------------------------------------------------------------------------
+    def is_dis_step(self, iters):
+        return iters % self.args.update_interval == 0          # image_translation.py:385
+
+    def rate(self, iters):
+        a = self.args
+        return a.starting_rate if iters < a.gan_curriculum else a.default_rate   # :367
+
+    def _set_requires_grad(self, dstep):
+        if not self.skip_dead_work:
+            return
+        for p in self.optim_dis.params:
+            p.requires_grad_(dstep)
+
+    def forward_losses(self, A, B, iters):
+        """image_translation.py:342-382."""
+        a = self.args
+        dstep = self.is_dis_step(iters)
+        skip = self.skip_dead_work
+        gen_ctx = torch.no_grad() if (skip and dstep) else torch.enable_grad()
+        with gen_ctx:
+            AB = self.generator_B(A)
+            BA = self.generator_A(B)
+            ABA = self.generator_A(AB)
+            BAB = self.generator_B(BA)
+            recon_loss_A = self.recon_criterion(ABA, A)
+            recon_loss_B = self.recon_criterion(BAB, B)
+        A_dis_real, A_feats_real = self.discriminator_A(A)
+        A_dis_fake, A_feats_fake = self.discriminator_A(BA)
+        dis_loss_A, gen_loss_A = L.get_gan_loss(A_dis_real, A_dis_fake, self.gan_criterion, self.device)
+        fm_loss_A = L.get_fm_loss(A_feats_real, A_feats_fake, self.feat_criterion, self.device)
+        B_dis_real, B_feats_real = self.discriminator_B(B)
+        B_dis_fake, B_feats_fake = self.discriminator_B(AB)
+        dis_loss_B, gen_loss_B = L.get_gan_loss(B_dis_real, B_dis_fake, self.gan_criterion, self.device)
+        fm_loss_B = L.get_fm_loss(B_feats_real, B_feats_fake, self.feat_criterion, self.device)
+        rate = self.rate(iters)
+        gen_loss_A_total = (fm_loss_B * 0.9 + gen_loss_B * 0.1) * (1 - rate) + recon_loss_A * rate
+        gen_loss_B_total = (fm_loss_A * 0.9 + gen_loss_A * 0.1) * (1 - rate) + recon_loss_B * rate
+        if a.model_arch == "discogan":
+            gen_loss = gen_loss_A_total + gen_loss_B_total
+            dis_loss = dis_loss_A + dis_loss_B
+        elif a.model_arch == "recongan":
+            gen_loss = gen_loss_A_total
+            dis_loss = dis_loss_B
+        elif a.model_arch == "gan":
+            gen_loss = gen_loss_B * 0.1 + fm_loss_B * 0.9
+            dis_loss = dis_loss_B
+        else:
+            raise ValueError(f"unknown model_arch {a.model_arch}")
+        return SimpleNamespace(
+            gen_loss=gen_loss, dis_loss=dis_loss, gen_loss_A=gen_loss_A, gen_loss_B=gen_loss_B,
+            fm_loss_A=fm_loss_A, fm_loss_B=fm_loss_B, recon_loss_A=recon_loss_A, recon_loss_B=recon_loss_B,
+            dis_loss_A=dis_loss_A, dis_loss_B=dis_loss_B, AB=AB, BA=BA, ABA=ABA, BAB=BAB,
+            A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
+            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake)
+
+    def _fwd_bwd(self, A, B, iters):
+        dstep = self.is_dis_step(iters)
+        self._set_requires_grad(dstep)
+        self.optim_gen.zero_grad()                       # image_translation.py:336-339
+        self.optim_dis.zero_grad()
+        out = self.forward_losses(A, B, iters)
+        (out.dis_loss if dstep else out.gen_loss).backward()
+        return out
+
+    def _graph_key(self, iters):
+        return ("D" if self.is_dis_step(iters) else "G", self.rate(iters))
+
+    def _fwd_bwd_graphed(self, A, B, iters):
+        if self._static is None:
+            self._static = (torch.empty_like(A), torch.empty_like(B))
+        sA, sB = self._static
+        sA.copy_(A)
+        sB.copy_(B)
+        key = self._graph_key(iters)
+        ent = self._graphs.get(key)
+        if ent is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                out = self._fwd_bwd(sA, sB, iters)
+            ent = (g, out)
+            self._graphs[key] = ent
+        ent[0].replay()
+        return ent[1]
+
+    def train_iteration(self, A, B, iters, do_step=True):
+        """One full iteration; returns the namespace of (device) loss scalars."""
+        dstep = self.is_dis_step(iters)
+        opt = self.optim_dis if dstep else self.optim_gen
+        if self.use_graph and iters >= self.args.update_interval:   # first cycle runs eagerly (warm-up)
+            out = self._fwd_bwd_graphed(A, B, iters)
+        else:
+            out = self._fwd_bwd(A, B, iters)
+        scale = 1.0
+        if self.world_size > 1:
+            # gradients of the stepped side only: one flat message, summed then divided by W
+            torch.distributed.all_reduce(opt.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            scale = 1.0 / self.world_size
+        if do_step:
+            opt.step(grad_scale=scale)
+        return out
+
+    # ---------------------------------------------------------------------------------------------
+    def losses_to_floats(self, out):
+        vals = torch.stack([getattr(out, k).detach().reshape(()) for k in LOG_KEYS]).cpu().tolist()
+        return dict(zip(LOG_KEYS, vals))
+
+    def format_log(self, iters, total, out):
+        f = self.losses_to_floats(out)
+        return (f"Iter [{iters}/{total}] "
+                f"GEN: {f['gen_loss_A']:.4f}/{f['gen_loss_B']:.4f}, "
+                f"FM: {f['fm_loss_A']:.4f}/{f['fm_loss_B']:.4f}, "
+                f"RECON: {f['recon_loss_A']:.4f}/{f['recon_loss_B']:.4f}, "
+                f"DIS: {f['dis_loss_A']:.4f}/{f['dis_loss_B']:.4f}")
+
+    def state_dicts(self):
+        return {k: v.state_dict() for k, v in self.nets.items()}
+
+
+def synthetic_batch(n, image_size, seed, device):
+    """rand in [0,1) like dataset.py:65 (/255); A then B from one host generator."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.rand(n, 3, image_size, image_size, generator=g)
+    B = torch.rand(n, 3, image_size, image_size, generator=g)
+    return A.to(device), B.to(device)

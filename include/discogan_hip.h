@@ -1,0 +1,171 @@
+/*
+ * discogan_hip.h -- C ABI of the MI355X (gfx950) DiscoGAN training-step kernels.
+ *
+ * The reference (fasion-image-generator-project/discogan_modernized) has no FFI of its own: its
+ * hot path is `torch.nn` calls made from model.py / image_translation.py.  Each entry point below
+ * replaces the ATen/cuDNN op the cited reference line dispatches; a binding is a ctypes stub
+ * (see INTEGRATION.md and discogan_modernized_amd/_lib.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DG_ERR_* code otherwise; the message is
+ *     available from dg_last_error() (thread-local).  Nothing aborts or throws across the ABI.
+ *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every buffer
+ *     (parameters, activations, gradients, workspace).  The library never allocates or frees device
+ *     memory and keeps no pointer past a call.
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (no synchronisation) and
+ *     are capturable into a hipGraph.
+ *   - ACTIVATION LAYOUT: interior feature maps are "NHWC" = [N][H][W][C] contiguous (the physical
+ *     layout of a torch channels_last tensor of logical shape [N,C,H,W]).  The 3-channel image side
+ *     (network input / output, model.py:8,80,142) stays NCHW exactly as the reference hands it over.
+ *   - WEIGHT LAYOUT: a Conv2d weight of logical shape [K,C,4,4] (model.py:11...) is stored "KRSC" =
+ *     [K][4][4][C]; a ConvTranspose2d weight of logical shape [Cin,Cout,4,4] (model.py:118...) is
+ *     stored [Cin][4][4][Cout] (the same rule: dim1 moved innermost).  The 3-channel edge weights
+ *     ([64,3,4,4]) stay in logical contiguous order.
+ *   - spatial sizes must be powers of two; channel counts multiples of 4.
+ */
+#ifndef DISCOGAN_HIP_H
+#define DISCOGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_OK 0
+#define DG_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define DG_ERR_WORKSPACE (-2)   /* workspace too small            */
+#define DG_ERR_HIP (-3)         /* HIP runtime error              */
+
+#define DG_ACT_NONE 0
+#define DG_ACT_LEAKY 1   /* LeakyReLU(slope)   model.py:9      */
+#define DG_ACT_RELU 2    /* ReLU               model.py:116    */
+#define DG_ACT_SIGMOID 3 /* Sigmoid            model.py:36,143 */
+
+typedef void* dg_stream_t;
+
+int dg_version(void);
+const char* dg_last_error(void);
+
+/* ---- tuning knobs (process-global, for benchmarking; 0 = heuristic) ------------------------ */
+int dg_set_option(const char* name, int value);
+
+/* ---- interior convolutions: implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------
+ * Geometry is that of the *Conv2d*: x[N,H,W,C] --(k4, stride, pad)--> y[N,Ho,Wo,K].
+ * Supported: (stride 2, pad 1)  Ho=H/2      -- nn.Conv2d(C,K,4,2,1)      model.py:11-31,83-103
+ *            (stride 1, pad 0)  H=W=4,Ho=1  -- nn.Conv2d(C,K,4,1,0)      model.py:35,107
+ * ConvTranspose2d(Cin,Cout,4,s,p) (model.py:114-142) is the dgrad of that Conv2d with the same
+ * weight tensor: forward = dg_conv_dgrad, input-grad = dg_conv_fwd, weight-grad = dg_conv_wgrad
+ * with the roles (x := grad_out, dy := input).  The named wrappers below spell this out.
+ */
+size_t dg_conv_workspace_bytes(int op /*0 fwd,1 dgrad,2 wgrad*/, int N, int H, int W, int C, int K,
+                               int stride, int pad);
+int dg_conv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                  int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+/* dw (+)= sum_pixels dy (x) im2col(x); accumulate!=0 adds into dw */
+int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
+                  int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+
+/* named wrappers; H,W always name the LARGER spatial side of the layer */
+int dg_conv4x4s2_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                     void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4s2_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                       void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4s2_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
+                       int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4_valid_fwd(const float* x, const float* w, float* y, int N, int C, int K,
+                         void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4_valid_dgrad(const float* dy, const float* w, float* dx, int N, int C, int K,
+                           void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4_valid_wgrad(const float* dy, const float* x, float* dw, int N, int C, int K,
+                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+/* ConvTranspose2d(Cin,Cout,4,2,1): x[N,Hin,Win,Cin] -> y[N,2Hin,2Win,Cout]; w [Cin][4][4][Cout] */
+int dg_convT4x4s2_fwd(const float* x, const float* w, float* y, int N, int Hin, int Win, int Cin, int Cout,
+                      void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_convT4x4s2_dgrad(const float* dy, const float* w, float* dx, int N, int Hin, int Win, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_convT4x4s2_wgrad(const float* dy, const float* x, float* dw, int N, int Hin, int Win, int Cin, int Cout,
+                        int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+/* ConvTranspose2d(Cin,Cout,4,1,0) on a 1x1 input: x[N,Cin] -> y[N,4,4,Cout] */
+int dg_convT4x4_1to4_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout,
+                         void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_convT4x4_1to4_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
+                           void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw, int N, int Cin, int Cout,
+                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+
+/* ---- 3-channel edge layers (image side stays NCHW) ------------------------------------------
+ * w is the logical contiguous [K][3][4][4] tensor in all three (Conv2d(3,K) weight, model.py:8,80;
+ * ConvTranspose2d(K,3) weight, model.py:142).
+ * c3_fwd  : y_nhwc[N,H/2,W/2,K] = act(conv_s2(x_nchw[N,3,H,W], w))        conv1 forward (act=LEAKY)
+ *                                                                        / last-convT input-grad
+ * c3_dgrad: dx_nchw[N,3,H,W] = act(conv_s2_dgrad(dy_nhwc[N,H/2,W/2,K], w)) last-convT forward
+ *                                                                        (act=SIGMOID) / conv1 dgrad
+ * c3_wgrad: dw[K][3][4][4] (+)= sum dy_nhwc (x) im2col(x_nchw)
+ */
+int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
+                        int act, float slope, dg_stream_t s);
+int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                          int act, dg_stream_t s);
+size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K);
+int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
+                          int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+
+/* ---- BatchNorm2d (training mode) + activation, NHWC [M][C], M = N*H*W ------------------------
+ * nn.BatchNorm2d (model.py:12...; eps 1e-5, momentum 0.1, biased batch var for normalisation,
+ * unbiased for running_var, num_batches_tracked int64 += 1) fused with the in-place
+ * LeakyReLU(0.2)/ReLU that follows it (model.py:13,116).
+ * saved: [2][C] = mean, invstd (kept for backward).
+ */
+size_t dg_bn_workspace_bytes(int M, int C);
+int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float* saved, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
+                  const float* beta, int act, float slope, dg_stream_t s);
+/* dy = BN'(act'(dz)); dgamma/dbeta (+)= ; dy may alias dz */
+int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
+                  const float* gamma, const float* beta, int act, float slope,
+                  float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+
+/* ---- stand-alone activations ------------------------------------------------------------------ */
+int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t s);
+/* out = output of the activation (in-place semantics of the reference, model.py:9,36) */
+int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, dg_stream_t s);
+
+/* ---- losses: scalars stay in device memory ----------------------------------------------------
+ * gout points to the upstream gradient scalar (device).  ws: >= dg_loss_workspace_bytes().
+ */
+size_t dg_loss_workspace_bytes(void);
+/* nn.MSELoss()  image_translation.py:267,349 */
+int dg_mse_fwd(const float* x, const float* t, size_t n, float* loss, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_mse_bwd(const float* x, const float* t, size_t n, const float* gout, float* dx, dg_stream_t s);
+/* nn.BCELoss() against a constant label (image_translation.py:157-166), log clamped at -100 */
+int dg_bce_fwd(const float* p, int n, float label, float* loss, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_bce_bwd(const float* p, int n, float label, const float* gout, float* dp, dg_stream_t s);
+/* one layer of get_fm_loss (image_translation.py:136-144): mean_j (mean_n real - mean_n fake)^2,
+ * real/fake [N][J]; diff[J] kept for backward */
+int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss,
+              void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);
+
+/* ---- Adam over flat buffers (optim.Adam, image_translation.py:275-287) ------------------------
+ * state (device, 4 x float64): [0] step count, [1] lr/(1-b1^t), [2] sqrt(1-b2^t), [3] spare.
+ * dg_adam_advance increments the step and refreshes the scalars ON DEVICE (graph-capturable).
+ */
+int dg_adam_advance(double* state, double lr, double beta1, double beta2, dg_stream_t s);
+int dg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, const double* state,
+                      float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      dg_stream_t s);
+
+/* ---- layout helpers --------------------------------------------------------------------------- */
+int dg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);
+int dg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCOGAN_HIP_H */

@@ -1,0 +1,305 @@
+"""Per-kernel parity: every C-ABI op against torch CPU fp32 ops on the same seeded inputs.
+
+Tolerances: forward ops  |got-ref| <= 1e-4*max|ref| + 1e-5,
+gradients 1e-3 relative to the tensor max-norm (we hold them to 2e-4 in practice).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from discogan_modernized_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def close(got, ref, rtol=1e-4, atol=1e-5, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    bound = rtol * ref.abs().max().item() + atol
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e} (max|ref| {ref.abs().max().item():.3e})"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def nhwc(t):
+    """CPU logical NCHW -> GPU tensor with NHWC memory."""
+    return t.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def krsc(w):
+    return ops.krsc_param(w.to(DEV))
+
+
+# (N, C, K, H) interior stride-2 layers: small, ragged-M, split-K, C=64 path, wide
+S2_SHAPES = [
+    (2, 64, 128, 8),      # M=32 (one masked tile)
+    (3, 64, 128, 16),     # M=192, non-power-of-two batch
+    (2, 128, 256, 8),     # split-K in fwd
+    (4, 256, 512, 8),
+    (2, 512, 1024, 4),    # 4x4 -> 2x2
+    (1, 2048, 2048, 8),   # deepest reference layer, N=1
+    (8, 64, 128, 32),     # M=2048
+    (2, 128, 64, 16),     # K=64 (dgrad of a 64->128 convT role)
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", S2_SHAPES)
+def test_conv_s2_fwd_dgrad_wgrad(N, C, K, H):
+    x = rnd(N, C, H, H, seed=1)
+    w = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    dy = rnd(N, K, H // 2, H // 2, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, stride=2, padding=1)
+    yr.backward(dy)
+    xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+    y = ops.conv_fwd(xg, wg, 2, 1)
+    close(y, yr, what="conv_fwd")
+    dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+    close(dx, xr.grad, rtol=2e-4, what="conv_dgrad")
+    dw = ops.conv_wgrad(dyg, xg, 2, 1)
+    close(dw, wr.grad, rtol=2e-4, what="conv_wgrad")
+    # accumulate path
+    dw2 = ops.conv_wgrad(dyg, xg, 2, 1, out=dw.clone(), accumulate=True)
+    close(dw2, 2 * wr.grad, rtol=2e-4, what="conv_wgrad accumulate")
+
+
+@pytest.mark.parametrize("kt,splitk", [(16, 0), (32, 3), (32, 1)])
+def test_conv_s2_options(kt, splitk):
+    """Force the other K-tile / split-K configurations through the same checks."""
+    _lib.set_option("kt", kt)
+    _lib.set_option("splitk", splitk)
+    try:
+        test_conv_s2_fwd_dgrad_wgrad(2, 128, 256, 8)
+        test_conv_s2_fwd_dgrad_wgrad(3, 64, 128, 16)
+    finally:
+        _lib.set_option("kt", 0)
+        _lib.set_option("splitk", 0)
+
+
+@pytest.mark.parametrize("N,C,K", [(2, 128, 100), (5, 512, 100), (4, 2048, 100), (2, 128, 1), (7, 512, 1), (32, 2048, 1)])
+def test_conv_head_valid(N, C, K):
+    """Conv2d(C,K,4,1,0) on a 4x4 input (model.py:35,107): fwd / dgrad / wgrad."""
+    x = rnd(N, C, 4, 4, seed=1)
+    w = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    dy = rnd(N, K, 1, 1, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, wr)
+    yr.backward(dy)
+    xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+    close(ops.conv_fwd(xg, wg, 1, 0), yr, what="head fwd")
+    close(ops.conv_dgrad(dyg, wg, (4, 4), 1, 0), xr.grad, rtol=2e-4, what="head dgrad")
+    close(ops.conv_wgrad(dyg, xg, 1, 0), wr.grad, rtol=2e-4, what="head wgrad")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hin", [(2, 128, 64, 4), (3, 256, 128, 8), (2, 2048, 2048, 4), (4, 512, 256, 4), (2, 128, 64, 16)])
+def test_convT_s2(N, Cin, Cout, Hin):
+    """ConvTranspose2d(Cin,Cout,4,2,1) (model.py:118-140) through the autograd Function."""
+    from discogan_modernized_amd import functional as F
+    x = rnd(N, Cin, Hin, Hin, seed=1)
+    w = rnd(Cin, Cout, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * Cout))
+    dy = rnd(N, Cout, 2 * Hin, 2 * Hin, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv_transpose2d(xr, wr, stride=2, padding=1)
+    yr.backward(dy)
+    xg = nhwc(x).requires_grad_(True)
+    wg = krsc(w).requires_grad_(True)
+    y = F.ConvTransposeFn.apply(xg, wg, 2, 1)
+    close(y, yr, what="convT fwd")
+    y.backward(nhwc(dy))
+    close(xg.grad, xr.grad, rtol=2e-4, what="convT dgrad")
+    close(wg.grad, wr.grad, rtol=2e-4, what="convT wgrad")
+
+
+@pytest.mark.parametrize("N,Cout", [(2, 128), (5, 512), (3, 2048)])
+def test_convT_head(N, Cout):
+    """ConvTranspose2d(100,Cout,4,1,0) on a 1x1 input (model.py:114)."""
+    from discogan_modernized_amd import functional as F
+    x = rnd(N, 100, 1, 1, seed=1)
+    w = rnd(100, Cout, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * Cout))
+    dy = rnd(N, Cout, 4, 4, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv_transpose2d(xr, wr)
+    yr.backward(dy)
+    xg = nhwc(x).requires_grad_(True)
+    wg = krsc(w).requires_grad_(True)
+    y = F.ConvTransposeFn.apply(xg, wg, 1, 0)
+    close(y, yr, what="convT head fwd")
+    y.backward(nhwc(dy))
+    close(xg.grad, xr.grad, rtol=2e-4, what="convT head dgrad")
+    close(wg.grad, wr.grad, rtol=2e-4, what="convT head wgrad")
+
+
+@pytest.mark.parametrize("N,H,K", [(2, 16, 64), (3, 8, 64), (1, 64, 64), (2, 32, 128), (5, 16, 64)])
+def test_c3_edge(N, H, K):
+    """3-channel image side: conv1 (+LeakyReLU), its dgrad / wgrad, last convT (+Sigmoid)."""
+    x = torch.rand(N, 3, H, H, generator=torch.Generator().manual_seed(1))
+    w = rnd(K, 3, 4, 4, seed=2, scale=1.0 / math.sqrt(48))
+    dy = rnd(N, K, H // 2, H // 2, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, stride=2, padding=1)
+    yr.backward(dy)
+    xg, wg, dyg = x.to(DEV), w.to(DEV), nhwc(dy)
+    close(ops.c3_fwd(xg, wg, ops.ACT_NONE), yr, what="c3 fwd")
+    close(ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2), TF.leaky_relu(yr, 0.2), what="c3 fwd + lrelu")
+    close(ops.c3_dgrad(dyg, wg, ops.ACT_NONE), xr.grad, rtol=2e-4, what="c3 dgrad")
+    close(ops.c3_wgrad(dyg, xg), wr.grad, rtol=2e-4, what="c3 wgrad")
+    # last ConvTranspose2d(K,3) + sigmoid == sigmoid(dgrad)
+    ref = torch.sigmoid(TF.conv_transpose2d(dy, w, stride=2, padding=1))
+    close(ops.c3_dgrad(dyg, wg, ops.ACT_SIGMOID), ref, what="c3 convT + sigmoid")
+
+
+@pytest.mark.parametrize("N,C,H,act", [(2, 128, 8, "leaky"), (4, 64, 16, "relu"), (2, 100, 1, "leaky"),
+                                       (3, 2048, 4, "relu"), (2, 256, 32, "leaky"), (6, 512, 2, "none")])
+def test_batchnorm_act(N, C, H, act):
+    y = rnd(N, C, H, H, seed=1, scale=2.0) + 0.3
+    gamma = rnd(C, seed=2) + 1.5
+    beta = rnd(C, seed=3)
+    dz = rnd(N, C, H, H, seed=4)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    yr = y.clone().requires_grad_(True)
+    u = bn(yr)
+    zr = {"leaky": lambda t: TF.leaky_relu(t, 0.2), "relu": TF.relu, "none": lambda t: t}[act](u)
+    zr.backward(dz)
+    code = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act]
+    yg = nhwc(y)
+    rm = torch.zeros(C, device=DEV)
+    rv = torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    gg, bg = gamma.to(DEV), beta.to(DEV)
+    saved = ops.bn_train_stats(yg, rm, rv, nbt, 1e-5, 0.1)
+    z = ops.bn_act_fwd(yg, saved, gg, bg, code, 0.2)
+    close(z, zr, what="bn fwd")
+    close(rm, bn.running_mean, what="running_mean")
+    close(rv, bn.running_var, what="running_var")
+    assert int(nbt) == 1
+    dy, dgamma, dbeta = ops.bn_act_bwd(nhwc(dz), yg, saved, gg, bg, code, 0.2)
+    close(dy, yr.grad, rtol=5e-4, atol=1e-6, what="bn dx")
+    close(dgamma, bn.weight.grad, rtol=5e-4, what="bn dgamma")
+    close(dbeta, bn.bias.grad, rtol=5e-4, what="bn dbeta")
+
+
+def test_bn_needs_two_values():
+    y = nhwc(rnd(1, 100, 1, 1))
+    with pytest.raises(_lib.DiscoganHipError, match="more than 1 value"):
+        ops.bn_train_stats(y, None, None, None, 1e-5, 0.1)
+
+
+@pytest.mark.parametrize("act", ["leaky", "relu", "sigmoid"])
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_activations(act, n):
+    x = rnd(n, seed=1, scale=20.0)
+    dy = rnd(n, seed=2)
+    xr = x.clone().requires_grad_(True)
+    fn = {"leaky": lambda t: TF.leaky_relu(t, 0.2), "relu": TF.relu, "sigmoid": torch.sigmoid}[act]
+    yr = fn(xr)
+    yr.backward(dy)
+    code = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU, "sigmoid": ops.ACT_SIGMOID}[act]
+    yg = ops.act_fwd(x.to(DEV), code, 0.2)
+    close(yg, yr, rtol=1e-6, atol=1e-7, what="act fwd")
+    close(ops.act_bwd(dy.to(DEV), yg, code, 0.2), xr.grad, rtol=1e-5, atol=1e-7, what="act bwd")
+
+
+def test_sigmoid_saturation():
+    x = torch.tensor([-200.0, -100.0, -40.0, -17.0, 0.0, 17.0, 18.0, 40.0, 100.0])
+    y = ops.act_fwd(x.to(DEV), ops.ACT_SIGMOID).cpu()
+    ref = torch.sigmoid(x)
+    assert y[-1] == 1.0 and y[-2] == 1.0 and y[0] == 0.0
+    assert torch.allclose(y, ref, rtol=1e-6, atol=1e-30)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (4, 3, 64, 64), (1, 3, 5, 7)])
+def test_mse(shape):
+    x, t = torch.rand(shape, generator=torch.Generator().manual_seed(1)), torch.rand(shape, generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_(True)
+    lr = TF.mse_loss(xr, t)
+    (lr * 0.37).backward()
+    loss, xd, td = ops.mse_fwd(x.to(DEV), t.to(DEV))
+    close(loss, lr, rtol=1e-6, atol=1e-8, what="mse")
+    g = torch.tensor(0.37, device=DEV)
+    close(ops.mse_bwd(xd, td, g), xr.grad, rtol=1e-5, atol=1e-10, what="mse bwd")
+
+
+@pytest.mark.parametrize("label", [1.0, 0.0])
+def test_bce_including_saturation(label):
+    """-100 log clamp (forward) and the 1e-12 guard (backward) are on the parity-critical path."""
+    p = torch.tensor([0.3, 0.9, 1.0, 0.0, 1e-30, 4e-18, 0.5, 0.9999999])
+    pr = p.clone().requires_grad_(True)
+    lr = TF.binary_cross_entropy(pr.view(-1, 1), torch.full((8, 1), label))
+    (lr * 0.1).backward()
+    loss, pc = ops.bce_fwd(p.to(DEV), label)
+    close(loss, lr, rtol=1e-6, atol=1e-7, what="bce")
+    dp = ops.bce_bwd(pc, label, torch.tensor(0.1, device=DEV)).cpu()
+    ref = pr.grad
+    assert torch.allclose(dp, ref, rtol=1e-5, atol=0), (dp, ref)
+
+
+@pytest.mark.parametrize("N,C,H", [(2, 128, 8), (4, 256, 4), (3, 64, 16)])
+def test_feature_matching(N, C, H):
+    real, fake = rnd(N, C, H, H, seed=1), rnd(N, C, H, H, seed=2)
+    rr, fr = real.clone().requires_grad_(True), fake.clone().requires_grad_(True)
+    l2 = (rr.mean(0) - fr.mean(0)) * (rr.mean(0) - fr.mean(0))
+    lr = torch.nn.HingeEmbeddingLoss()(l2, torch.ones(l2.size()))
+    (lr * 0.9).backward()
+    loss, diff, rd, fd = ops.fm_fwd(nhwc(real), nhwc(fake))
+    close(loss, lr, rtol=1e-5, atol=1e-9, what="fm")
+    dreal, dfake = ops.fm_bwd(diff, rd, fd, torch.tensor(0.9, device=DEV), True, True)
+    close(dreal, rr.grad, rtol=1e-4, atol=1e-10, what="fm dreal")
+    close(dfake, fr.grad, rtol=1e-4, atol=1e-10, what="fm dfake")
+
+
+def test_adam_flat_matches_torch():
+    """Op-wise Adam parity with oracle gradients over several steps."""
+    from discogan_modernized_amd import optim
+    torch.manual_seed(0)
+    shapes = [(64, 3, 4, 4), (128,), (100, 128, 4, 4), (7,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s) * 0.05) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ro = torch.optim.Adam(ref_p, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    mo = optim.Adam(my_p, lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-5)
+    for step in range(5):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape) * (10.0 ** (-step))
+            rp.grad = g.clone()
+            mp.grad.copy_(g.to(DEV))
+        ro.step()
+        mo.step()
+        for rp, mp in zip(ref_p, my_p):
+            assert (mp.detach().cpu() - rp.detach()).abs().max().item() <= 2e-7, f"step {step}"
+    assert float(mo.state[0]) == 5.0
+
+
+def test_layout_roundtrip():
+    x = rnd(3, 20, 6, 10, seed=5).to(DEV)
+    y = ops.as_nhwc(x)
+    assert ops.is_nhwc(y) and torch.equal(y.cpu(), x.cpu())
+    z = ops.to_nchw_contiguous(y)
+    assert z.is_contiguous() and torch.equal(z.cpu(), x.cpu())
+
+
+def test_errors_are_reported_not_fatal():
+    x = nhwc(rnd(2, 48, 8, 8))                     # C=48 is not a multiple of 32
+    w = krsc(rnd(64, 48, 4, 4))
+    with pytest.raises(_lib.DiscoganHipError, match="multiple of 32"):
+        ops.conv_fwd(x, w, 2, 1)
+    with pytest.raises(_lib.DiscoganHipError, match="unsupported"):
+        ops.conv_fwd(nhwc(rnd(2, 64, 8, 8)), krsc(rnd(64, 64, 4, 4)), 1, 1)
+    with pytest.raises(_lib.DiscoganHipError, match="CPU"):
+        ops.conv_fwd(rnd(2, 64, 8, 8), rnd(64, 64, 4, 4), 2, 1)

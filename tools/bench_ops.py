@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Per-layer kernel timing at the BASELINE shapes (not the headline bench; a tuning aid).
+
+    python tools/bench_ops.py --size 64 --batch 256 [--kt 16] [--splitk 0]
+Prints ms and TFLOP/s (2*MACs) for conv fwd / dgrad / wgrad of every interior layer + edge kernels.
+"""
+import argparse
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from discogan_modernized_amd import _lib, ops  # noqa: E402
+from discogan_modernized_amd.model import stage_channels  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--kt", type=int, default=0)
+    ap.add_argument("--splitk", type=int, default=0)
+    ap.add_argument("--target_wgs", type=int, default=0)
+    a = ap.parse_args()
+    _lib.set_option("kt", a.kt)
+    _lib.set_option("splitk", a.splitk)
+    _lib.set_option("target_wgs", a.target_wgs)
+    dev = "cuda"
+    ch = stage_channels(a.size)
+    N, S = a.batch, a.size
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    totf = 0.0
+    print(f"# size {S} batch {N} kt {a.kt} splitk {a.splitk}")
+    print(f"{'layer':28s} {'GFLOP':>9s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
+    h = S // 2
+    for i in range(1, len(ch)):
+        C, K, H = ch[i - 1], ch[i], h
+        x = ops.empty_nhwc(N, C, H, H, dev).normal_()
+        w = ops.empty_krsc(K, C, dev).normal_()
+        dy = ops.empty_nhwc(N, K, H // 2, H // 2, dev).normal_()
+        gf = 2.0 * N * (H // 2) ** 2 * K * C * 16 / 1e9
+        t1 = timeit(lambda: ops.conv_fwd(x, w, 2, 1))
+        t2 = timeit(lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1))
+        t3 = timeit(lambda: ops.conv_wgrad(dy, x, 2, 1))
+        print(f"conv s2 {C:4d}->{K:4d} @{H:3d}       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
+        tot["fwd"] += t1; tot["dgrad"] += t2; tot["wgrad"] += t3; totf += gf
+        h //= 2
+    # heads
+    C = ch[-1]
+    for K in (100, 1):
+        x = ops.empty_nhwc(N, C, 4, 4, dev).normal_()
+        w = ops.empty_krsc(K, C, dev).normal_()
+        dy = ops.empty_nhwc(N, K, 1, 1, dev).normal_()
+        gf = 2.0 * N * K * C * 16 / 1e9
+        t1 = timeit(lambda: ops.conv_fwd(x, w, 1, 0))
+        t2 = timeit(lambda: ops.conv_dgrad(dy, w, (4, 4), 1, 0))
+        t3 = timeit(lambda: ops.conv_wgrad(dy, x, 1, 0))
+        print(f"head    {C:4d}->{K:4d} @  4       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
+    # edge
+    K = ch[0]
+    x = torch.rand(N, 3, S, S, device=dev)
+    w = torch.randn(K, 3, 4, 4, device=dev)
+    dy = ops.empty_nhwc(N, K, S // 2, S // 2, dev).normal_()
+    gf = 2.0 * N * (S // 2) ** 2 * K * 48 / 1e9
+    t1 = timeit(lambda: ops.c3_fwd(x, w, ops.ACT_LEAKY, 0.2))
+    t2 = timeit(lambda: ops.c3_dgrad(dy, w, ops.ACT_SIGMOID))
+    t3 = timeit(lambda: ops.c3_wgrad(dy, x))
+    mb = (x.numel() + dy.numel()) * 4 / 1e6
+    print(f"edge c3    3->{K:4d} @{S:3d}       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}   ({mb:.0f} MB -> {mb / t1 / 1e3:.2f}/{mb / t2 / 1e3:.2f}/{mb / t3 / 1e3:.2f} TB/s)")
+    # BN + act streaming
+    C, H = ch[1], S // 4
+    y = ops.empty_nhwc(N, C, H, H, dev).normal_()
+    dz = ops.empty_nhwc(N, C, H, H, dev).normal_()
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    saved = ops.bn_train_stats(y, None, None, None, 1e-5, 0.1)
+    mbt = y.numel() * 4 / 1e6
+    t1 = timeit(lambda: ops.bn_train_stats(y, None, None, None, 1e-5, 0.1))
+    t2 = timeit(lambda: ops.bn_act_fwd(y, saved, g, b, ops.ACT_LEAKY, 0.2))
+    t3 = timeit(lambda: ops.bn_act_bwd(dz, y, saved, g, b, ops.ACT_LEAKY, 0.2))
+    print(f"bn [{N}x{H}x{H}x{C}] {mbt:.0f} MB: stats {t1:.3f} ms ({mbt / t1 / 1e3:.2f} TB/s)  apply {t2:.3f} ms ({2 * mbt / t2 / 1e3:.2f} TB/s)  bwd {t3:.3f} ms ({5 * mbt / t3 / 1e3:.2f} TB/s)")
+    print(f"interior totals: {totf:.1f} GFLOP each dir | fwd {tot['fwd']:.3f} ms ({totf / tot['fwd']:.1f} TF/s) dgrad {tot['dgrad']:.3f} ms ({totf / tot['dgrad']:.1f}) wgrad {tot['wgrad']:.3f} ms ({totf / tot['wgrad']:.1f})")
+
+
+if __name__ == "__main__":
+    main()
