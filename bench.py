@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the DiscoGAN training step on MI355X.
+
+    python bench.py --gpus 1 --steps 30 --warmup 9
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): edges2shoes / discogan / image_size=64 / batch_size=256 PER GPU,
+fp32, synthetic uniform [0,1) batches resident in HBM, models from torch.manual_seed(1234).  A "step"
+is one training iteration (4 G passes + 4 D passes forward, backward + Adam of the side selected by
+``iters % 3``; image_translation.py:336-390).  K steps walk the D,G,G cycle; images = batch x ranks
+per step (one (A,B) index = one image, dataset.py:210-213).  Weak scaling: per-GPU batch is fixed.
+
+One JSON line on rank 0 with the contract fields plus
+  roofline     : the dominant kernel family (igemm_kernel, fp32 MFMA): algorithmic conv FLOPs of every
+                 launch in one D,G,G cycle / summed HIP-event durations of those launches
+  cpu_baseline : oracle/discogan_ref.py (PyTorch-CPU restatement of the reference step, pinned to the
+                 reference's golden vectors) timed on the host cores for a bounded sample
+  extra        : the 512 px / batch 32 configuration (BASELINE configs[3]) for a few steps
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=9)
+    ap.add_argument("--image_size", type=int, default=64)
+    ap.add_argument("--batch_size", type=int, default=256, help="per GPU")
+    ap.add_argument("--no_graph", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_512", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_run(trainer, A, B, steps, warmup, world, start_iter=0):
+    it = start_iter
+    for _ in range(warmup):
+        trainer.train_iteration(A, B, it)
+        it += 1
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_iteration(A, B, it)
+        it += 1
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, it
+
+
+def roofline_pass(trainer, A, B, start_iter):
+    """One instrumented D,G,G cycle (eager dispatch): HIP events around every igemm launch."""
+    from discogan_modernized_amd import ops
+    ui = trainer.args.update_interval
+    start_iter = (start_iter + ui - 1) // ui * ui            # align to a D-step
+    was_graph = trainer.use_graph
+    trainer.use_graph = False
+    ops.PROFILE = []
+    for k in range(ui):
+        trainer.train_iteration(A, B, start_iter + k)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    rec = [r for r in rec if r[0] != "head1"]   # K==1 head uses plain reduction kernels, not the MFMA family
+    trainer.use_graph = was_graph
+    flops = sum(r[1] for r in rec)
+    ms = sum(r[2].elapsed_time(r[3]) for r in rec)
+    by = {}
+    for name, f, e0, e1 in rec:
+        d = by.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += f
+        d[2] += e0.elapsed_time(e1)
+    return flops, ms, len(rec), by
+
+
+def cpu_baseline(image_size, batch, update_interval=3):
+    """Oracle step on the host cores: 1 warm-up iteration + one D,G,G cycle."""
+    from oracle import discogan_ref as O
+    st = O.build_state(image_size=image_size, seed=1234)
+    A, B = O.synthetic_batch(batch, image_size, seed=1000)
+    O.train_iteration(st, A, B, 1)                      # warm-up (G-step; allocs, oneDNN primitives)
+    t0 = time.perf_counter()
+    for it in range(update_interval, 2 * update_interval):
+        O.train_iteration(st, A, B, it)
+    dt = time.perf_counter() - t0
+    return batch * update_interval / dt, dt
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        pg = dist.group.WORLD
+    from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
+    dev = torch.device("cuda", local)
+
+    trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
+                              use_graph=not a.no_graph)
+    A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
+    log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
+    dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
+    log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
+    images = a.batch_size * world * a.steps
+    value = images / dt
+
+    roof = None
+    if not a.no_roofline:
+        flops, ms, nlaunch, by = roofline_pass(trainer, A, B, it)
+        log(f"roofline pass done: {flops / ms / 1e9:.1f} TFLOP/s over {nlaunch} igemm launches")
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)",
+                    achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                    launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
+                    avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
+                    by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
+                                   tflops=round(v[1] / max(v[2], 1e-9) / 1e9, 1)) for k, v in by.items()})
+    extra = {}
+    del trainer
+    torch.cuda.empty_cache()
+    if not a.no_512:
+        tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
+                                use_graph=not a.no_graph)
+        A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
+        log("512px models built")
+        dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)
+        log(f"512px done: {dt5 / 6 * 1e3:.1f} ms/step")
+        extra = dict(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
+                     note="BASELINE configs[3]: tops2hanbok image_size=512 batch_size=32 per GPU, fp32, 6 timed steps")
+        del tr512, A5, B5
+        torch.cuda.empty_cache()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        torch.set_num_threads(min(16, os.cpu_count() or 1))   # the 1-GPU box's CPU share is 16 cores
+        log("cpu baseline (oracle) ...")
+        v, cdt = cpu_baseline(a.image_size, 64)
+        cpu = dict(value=round(v, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"oracle/discogan_ref.py, image_size={a.image_size} batch 64 (BASELINE configs[0]), "
+                          f"one D,G,G cycle after 1 warm-up iteration, {cdt:.1f} s")
+    if rank == 0:
+        line = dict(metric="images/sec per DiscoGAN train step", value=round(value, 2), unit="images/s",
+                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=f"edges2shoes discogan image_size={a.image_size} batch_size={a.batch_size} per GPU "
+                                         f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped",
+                                global_batch=a.batch_size * world, parallelism=f"dp{world}",
+                                hipgraph=not a.no_graph),
+                    roofline=roof, cpu_baseline=cpu, extra=extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,14 +17,15 @@ __device__ __forceinline__ float bn_norm(float y, float mean, float gs, float be
 
 static void bn_grid(int M, int C, int* cchunks, int* rchunks) {
     *cchunks = (C + 4 * BN_TX - 1) / (4 * BN_TX);
-    int rc = 2048 / *cchunks;
+    int rc = 1024 / *cchunks;
+    if (rc > 256) rc = 256;  // the finalize kernels walk this many partials per channel
     int maxrc = (M + BN_TY - 1) / BN_TY;  // at least one row per row-lane
     if (rc > maxrc) rc = maxrc;
     if (rc < 1) rc = 1;
     *rchunks = rc;
 }
 
-// part layout: [2][rchunks][C]  (0: sum, 1: sumsq)
+// part layout: [2][rchunks][C]  (0: sum of (y - shift), 1: sum of (y - shift)^2; shift = y[row 0])
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
                                                                int M, int C, int rchunks) {
     __shared__ f32x4 red[2][BN_TY][BN_TX];
@@ -34,10 +35,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
+        // shifted sums: d = y - y[row 0]; var = E[d^2] - E[d]^2 has no catastrophic cancellation
+        // because the shift is itself a sample of the channel (|mean - shift| ~ std).
+        const f32x4 sh = *(const f32x4*)(y + c);
         for (int r = r0 + ty; r < r1; r += BN_TY) {
-            const f32x4 v = *(const f32x4*)(y + (long)r * C + c);
-            s += v;
-            q += v * v;
+            const f32x4 d = *(const f32x4*)(y + (long)r * C + c) - sh;
+            s += d;
+            q += d * d;
         }
     }
     red[0][ty][tx] = s;
@@ -54,20 +58,45 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int M, int C, int rchunks,
+// Finalize helper: a 256-thread block owns 8 channels; 32 lanes per channel walk the row-chunk
+// partials in a fixed order and are combined in fp64 through LDS (deterministic).  Returns the
+// channel for the lane that holds the totals, -1 for every other thread.
+#define BN_FIN_CH 8
+__device__ __forceinline__ int bn_reduce_partials(const float* __restrict__ part, int C, int rchunks, double* s_out, double* q_out) {
+    __shared__ double red[2][32][BN_FIN_CH];
+    const int cl = threadIdx.x % BN_FIN_CH, pl = threadIdx.x / BN_FIN_CH;
+    const int c = blockIdx.x * BN_FIN_CH + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int r = pl; r < rchunks; r += 32) {
+            s += (double)part[(long)r * C + c];
+            q += (double)part[((long)rchunks + r) * C + c];
+        }
+    }
+    red[0][pl][cl] = s;
+    red[1][pl][cl] = q;
+    __syncthreads();
+    if (pl != 0 || c >= C) return -1;
+    for (int j = 1; j < 32; ++j) {
+        s += red[0][j][cl];
+        q += red[1][j][cl];
+    }
+    *s_out = s;
+    *q_out = q;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ y, const float* __restrict__ part, int M, int C, int rchunks,
                                                                 float eps, float momentum, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                                 float* __restrict__ saved) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    double s, q;
+    const int c = bn_reduce_partials(part, C, rchunks, &s, &q);
+    if (c < 0) return;
     if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rchunks; ++r) {
-        s += (double)part[(long)r * C + c];
-        q += (double)part[((long)rchunks + r) * C + c];
-    }
-    const double mean = s / M;
-    double var = q / M - mean * mean;
+    const double dm = s / M;
+    const double mean = (double)y[c] + dm;
+    double var = q / M - dm * dm;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     saved[c] = (float)mean;
@@ -148,13 +177,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int M, int C, int rchunks,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < rchunks; ++r) {
-        s += (double)part[(long)r * C + c];
-        q += (double)part[((long)rchunks + r) * C + c];
-    }
+    double s, q;
+    const int c = bn_reduce_partials(part, C, rchunks, &s, &q);
+    if (c < 0) return;
     coef[c] = (float)(s / M);
     coef[C + c] = (float)(q / M);
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
@@ -251,7 +276,7 @@ extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc);
     DG_CHECK_LAUNCH("bn_stats_partial");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, M, C, rc, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
                        momentum, running_mean, running_var, nbt, saved);
     DG_CHECK_LAUNCH("bn_stats_finalize");
     return DG_OK;
@@ -284,7 +309,7 @@ extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, 
     float* coef = part + (size_t)2 * rc * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, saved, gamma, beta, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_partial");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)part, M, C, rc, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const float*)part, M, C, rc, coef,
                        dgamma, dbeta, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long total4 = (long)M * C / 4;

@@ -14,6 +14,30 @@ from . import _lib
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
+# bench.py's roofline leg sets this to a list: every launch of the MFMA implicit-GEMM family then
+# appends (op, algorithmic FLOPs, start event, end event), recorded on the launch stream.
+PROFILE = None
+
+
+class _prof:
+    def __init__(self, name, flops):
+        self.on = PROFILE is not None
+        if self.on:
+            self.name, self.flops = name, flops
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -108,8 +132,9 @@ def conv_fwd(x, w, stride, pad):
     y = empty_nhwc(n, k, ho, wo, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
-    _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-               "dg_conv_fwd")
+    with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
+        _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                   "dg_conv_fwd")
     return y
 
 
@@ -124,8 +149,9 @@ def conv_dgrad(dy, w, x_hw, stride, pad):
     dx = empty_nhwc(n, c, h, wd, dy.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
-    _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-               "dg_conv_dgrad")
+    with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
+        _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                   "dg_conv_dgrad")
     return dx
 
 
@@ -139,8 +165,9 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
-    _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
-                               _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
+    with _prof("conv_wgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
+        _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
+                                   _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
     return dw
 
 
@@ -153,8 +180,9 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
     n, _, h, wd = x.shape
     k = w.shape[0]
     y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
-    _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
-               "dg_conv4x4s2_c3_fwd")
+    with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48):
+        _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
+                   "dg_conv4x4s2_c3_fwd")
     return y
 
 

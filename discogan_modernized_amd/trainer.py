@@ -22,6 +22,7 @@ from types import SimpleNamespace
 
 import torch
 
+from . import dp
 from . import losses as L
 from . import optim
 from .model import Discriminator, Generator
@@ -167,11 +168,8 @@ class DiscoGANTrainer:
             out = self._fwd_bwd_graphed(A, B, iters)
         else:
             out = self._fwd_bwd(A, B, iters)
-        scale = 1.0
-        if self.world_size > 1:
-            # gradients of the stepped side only: one flat message, summed then divided by W
-            torch.distributed.all_reduce(opt.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            scale = 1.0 / self.world_size
+        # gradients of the stepped side only: one flat message, summed; the /W rides in the Adam kernel
+        scale, _ = dp.all_reduce_flat(opt.flat_g, self.pg) if self.world_size > 1 else (1.0, None)
         if do_step:
             opt.step(grad_scale=scale)
         return out

@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the header
+declares; module structure / seeded init / checkpoint keys; CLI surface; loud failures."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from discogan_modernized_amd import _lib, losses, model, ops
+from discogan_modernized_amd import image_translation as it
+from discogan_modernized_amd import distributed_image_translation as dit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "discogan_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dg_[a-zA-Z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 40
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/discogan_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES.keys()) == syms, "ctypes SIGNATURES and the header disagree"
+    L = _lib.load()
+    assert L.dg_version() >= 100
+    assert L.dg_loss_workspace_bytes() > 0
+    assert L.dg_conv_workspace_bytes(0, 2, 8, 8, 512, 1024, 2, 1) > 0      # split-K plan, no GPU needed
+    assert L.dg_set_option(b"nonsense", 1) != 0 and b"unknown option" in L.dg_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdiscogan_hip.so")
+    with pytest.raises(_lib.DiscoganHipError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(_lib.DiscoganHipError, match="no CPU fallback"):
+        ops.conv_fwd(torch.zeros(2, 64, 8, 8), torch.zeros(64, 64, 4, 4), 2, 1)
+    g = model.Generator(image_size=16)
+    with pytest.raises(_lib.DiscoganHipError):
+        g(torch.rand(2, 3, 16, 16))
+    from discogan_modernized_amd import optim
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        optim.Adam(g.parameters())
+
+
+@pytest.mark.parametrize("S", [16, 64])
+def test_seeded_init_matches_fixture(S):
+    """Same RNG consumption order and values as the oracle/reference construction (host side only)."""
+    fix = json.load(open(os.path.join(GOLD, f"oracle_s{S}_n4.json")))
+    torch.manual_seed(1234)
+    nets = dict(gen_A=model.Generator(True, image_size=S), gen_B=model.Generator(True, image_size=S),
+                dis_A=model.Discriminator(image_size=S), dis_B=model.Discriminator(image_size=S))
+    for name, net in nets.items():
+        assert list(net.state_dict().keys()) == fix["meta"]["state_dict_keys"][name]
+        for k, v in net.state_dict().items():
+            if v.dtype.is_floating_point:
+                f = v.reshape(-1)
+                ref = fix["init"][name][k]
+                assert list(v.shape) == ref["shape"]
+                idx = [int((i * 2654435761) % f.numel()) for i in range(1, 9)]
+                assert [float(f[i]) for i in idx] == ref["samples"], f"{name}.{k}"
+
+
+def test_reference_512_state_dict_contract():
+    """Appendix B: 86 / 38 entries, parameter order and logical shapes of the reference checkpoints."""
+    fix = json.load(open(os.path.join(GOLD, "ref_s512_n2.json")))
+    keys_g, keys_d = fix["meta"]["state_dict_keys"]["gen_A"], fix["meta"]["state_dict_keys"]["dis_A"]
+    assert len(keys_g) == 86 and len(keys_d) == 38
+    ch = model.stage_channels(512)
+    assert ch == [64, 128, 256, 512, 1024, 2048, 2048]
+    # build on the meta device: no 2.7 GB allocation
+    with torch.device("meta"):
+        g, d = model.Generator(True), model.Discriminator()
+    assert list(g.state_dict().keys()) == keys_g and list(d.state_dict().keys()) == keys_d
+    for k, v in g.state_dict().items():
+        if k in fix["init"]["gen_A"]:
+            assert list(v.shape) == fix["init"]["gen_A"][k]["shape"], k
+    assert sum(p.numel() for p in g.parameters()) == 230192968
+    assert sum(p.numel() for p in d.parameters()) == 111852288
+    assert g.main is None and isinstance(g.encoder, torch.nn.Sequential) and isinstance(g.decoder, torch.nn.Sequential)
+
+
+def test_weight_memory_layout():
+    g = model.Generator(image_size=16)
+    w = g.encoder[2].weight                      # Conv2d(64,128): logical [128,64,4,4], memory KRSC
+    assert tuple(w.shape) == (128, 64, 4, 4) and ops.is_krsc(w)
+    assert g.encoder[0].weight.is_contiguous()  # 3-channel edge weight stays logical
+    wt = g.decoder[0].weight                     # ConvTranspose2d(100,128): logical [100,128,4,4]
+    assert tuple(wt.shape) == (100, 128, 4, 4) and ops.is_krsc(wt)
+    sd = g.state_dict()
+    g2 = model.Generator(image_size=16)
+    g2.load_state_dict({k: v.contiguous() for k, v in sd.items()})
+    assert ops.is_krsc(g2.encoder[2].weight) and torch.equal(g2.encoder[2].weight, w)
+
+
+def test_cli_surface_matches_reference_defaults():
+    a = it.parse_args([])
+    expect = dict(device="cuda", task_name="facescrub", results_dir="./results/", models_dir="./models/",
+                  model_arch="discogan", epochs=100, batch_size=64, learning_rate=0.0002, beta1=0.5, beta2=0.999,
+                  image_size=64, gan_curriculum=10000, starting_rate=0.01, default_rate=0.5, style_A=None,
+                  style_B=None, constraint=None, constraint_type=None, n_test=200, update_interval=3,
+                  log_interval=50, image_save_interval=1000, model_save_interval=10000)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+    b = dit.parse_args(["--task_name", "celebA", "--style_A", "Male", "--style_B", "Smiling", "--batch_size", "64"])
+    assert b.task_name == "celebA" and b.style_A == "Male" and b.distributed is False and b.local_rank == 0
+    for flag in ("load_gen_A", "load_gen_B", "load_dis_A", "load_dis_B"):
+        assert getattr(b, flag) is None
+    with pytest.raises(SystemExit):
+        it.parse_args(["--model_arch", "nope"])
+
+
+def test_loss_helper_signatures():
+    import inspect
+    assert list(inspect.signature(losses.get_fm_loss).parameters)[:4] == ["real_feats", "fake_feats", "criterion", "device"]
+    assert list(inspect.signature(losses.get_gan_loss).parameters)[:4] == ["dis_real", "dis_fake", "criterion", "device"]
+
+
+def test_graft_entry_build():
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(_lib.LIB_PATH)

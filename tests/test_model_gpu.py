@@ -1,0 +1,327 @@
+"""Module- and step-level parity of the HIP path.
+
+  * Generator / Discriminator forward+backward against the oracle nets (same seeded weights)
+  * 3 training iterations (D,G,G) against the committed golden fixtures:
+      tests/golden/ref_s512_n2.json   -- outputs of the TRUE reference (512 px, the only size it runs)
+      tests/golden/oracle_s64_n4.json / oracle_s16_n4.json -- oracle, derived nets
+  * hipGraph replay == eager dispatch; dead-work skipping changes no result
+  * size-independent properties at the benchmark shapes (adjoint identities of the conv kernels)
+
+Tolerances: step-0 losses rtol 1e-4; steps 1-2 rtol 1e-2 (discriminator saturates,
+BCE clamp regime); gradients 1e-3 of the tensor norm.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from discogan_modernized_amd import model as M  # noqa: E402
+from discogan_modernized_amd import ops  # noqa: E402
+from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch  # noqa: E402
+from oracle import discogan_ref as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sample_idx(numel, k=8):
+    return [int((i * 2654435761) % numel) for i in range(1, k + 1)]
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def max_close(got, ref, rtol, atol, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max().item()
+    bound = rtol * ref.abs().max().item() + atol
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e}"
+
+
+def build_pair(image_size, seed=1234):
+    torch.manual_seed(seed)
+    og, od = O.Generator(True, image_size=image_size), O.Discriminator(image_size=image_size)
+    torch.manual_seed(seed)
+    mg, md = M.Generator(True, image_size=image_size), M.Discriminator(image_size=image_size)
+    return og, od, mg.to(DEV), md.to(DEV)
+
+
+@pytest.mark.parametrize("S,N", [(16, 4), (64, 3)])
+def test_seeded_weights_and_state_dict_match_oracle(S, N):
+    og, od, mg, md = build_pair(S)
+    for o, m in ((og, mg), (od, md)):
+        so, sm = o.state_dict(), m.state_dict()
+        assert list(so.keys()) == list(sm.keys())
+        for k in so:
+            assert tuple(so[k].shape) == tuple(sm[k].shape), k
+            assert torch.equal(so[k], sm[k].cpu()), f"seeded init differs for {k}"
+        assert [n for n, _ in o.named_parameters()] == [n for n, _ in m.named_parameters()]
+
+
+@pytest.mark.parametrize("S,N", [(16, 4), (64, 3)])
+def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
+    og, od, mg, md = build_pair(S)
+    x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(3))
+    # ---- generator
+    yo = og(x)
+    ym = mg(x.to(DEV))
+    assert ym.shape == yo.shape and ym.is_contiguous()
+    max_close(ym, yo, 1e-4, 1e-5, "G forward")
+    gout = torch.rand(yo.shape, generator=torch.Generator().manual_seed(4)) - 0.5
+    yo.backward(gout)
+    ym.backward(gout.to(DEV))
+    for (n, po), (_, pm) in zip(og.named_parameters(), mg.named_parameters()):
+        assert rel_err(pm.grad, po.grad) < 2e-3, f"G grad {n}: rel err {rel_err(pm.grad, po.grad):.2e}"
+    for (n, bo), (_, bm) in zip(og.named_buffers(), mg.named_buffers()):
+        max_close(bm.float(), bo.float(), 1e-4, 1e-6, f"G buffer {n}")
+    # ---- discriminator (input requires grad: the fake pass back-props into the generator)
+    xo = x.clone().requires_grad_(True)
+    xm = x.clone().to(DEV).requires_grad_(True)
+    po_, fo = od(xo)
+    pm_, fm = md(xm)
+    assert pm_.shape == po_.shape == (N, 1, 1, 1)
+    max_close(pm_, po_, 1e-4, 1e-6, "D out")
+    assert len(fm) == len(fo)
+    lo, lm = po_.sum() * 0.7, pm_.sum() * 0.7
+    for i, (a, b) in enumerate(zip(fm, fo)):
+        max_close(a, b, 1e-4, 1e-5, f"D feat {i}")
+        wgt = torch.rand(b.shape, generator=torch.Generator().manual_seed(10 + i)) - 0.5
+        lo = lo + (b * wgt).sum() * 0.01
+        lm = lm + (a * wgt.to(DEV)).sum() * 0.01
+    lo.backward()
+    lm.backward()
+    assert rel_err(xm.grad, xo.grad) < 2e-3, f"D input grad rel err {rel_err(xm.grad, xo.grad):.2e}"
+    for (n, po), (_, pm) in zip(od.named_parameters(), md.named_parameters()):
+        assert rel_err(pm.grad, po.grad) < 2e-3, f"D grad {n}: rel err {rel_err(pm.grad, po.grad):.2e}"
+
+
+def test_unfused_sequential_matches_fused():
+    """Calling the nn.Sequential containers directly (module-by-module kernels) gives the fused result."""
+    _, _, mg, _ = build_pair(16)
+    x = torch.rand(4, 3, 16, 16, device=DEV)
+    mg.eval()  # keep running stats fixed so both calls see the same BN state
+    with torch.no_grad():
+        a = mg(x)
+        b = mg.decoder(mg.encoder(x))
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_load_reference_format_checkpoint():
+    """state_dict written by the oracle/reference layout loads into the HIP modules (Appendix B)."""
+    torch.manual_seed(7)
+    og = O.Generator(True, image_size=16)
+    mg = M.Generator(True, image_size=16).to(DEV)
+    mg.load_state_dict(og.state_dict())
+    assert ops.is_krsc(mg.encoder[2].weight)              # memory layout survives load_state_dict
+    x = torch.rand(4, 3, 16, 16)
+    max_close(mg(x.to(DEV)), og(x), 1e-4, 1e-5, "forward after load_state_dict")
+    sd = {k: v.cpu() for k, v in mg.state_dict().items()}
+    og2 = O.Generator(True, image_size=16)
+    og2.load_state_dict(sd)                                 # and back
+
+
+def check_init_against_fixture(tr, fix):
+    """Seeded init must equal the fixture's source (sum / samples are exact functions of it)."""
+    for name, net in tr.nets.items():
+        for k, v in net.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            ref = fix["init"][name][k]
+            f = v.detach().reshape(-1).cpu()
+            assert abs(float(f.double().sum()) - ref["sum"]) <= 1e-12 * ref["abssum"] + 1e-300, f"init {name}.{k}"
+            assert [float(f[i]) for i in sample_idx(f.numel())] == ref["samples"], f"init {name}.{k}"
+
+
+def run_and_compare(fix, S, N):
+    """Free-running 3 iterations against a golden fixture.
+
+    Iteration 0 (D-step from the seeded init) is held to the tight tolerances.  From iteration 1 on the
+    discriminators are saturated (D(real) == 1.0, D(fake) ~ e^-40, BCE -100 clamp): the generator
+    gradient is proportional to e^logit, and one Adam step ~ lr*sign(g) on 10^8 weights turns fp32
+    rounding noise into logit shifts, so free-running trajectories legitimately drift by percents
+    (SURVEY.md 7(v),(vi)).  Those iterations are therefore checked loosely here and TIGHTLY in
+    test_teacher_forced_iterations_vs_oracle, where every iteration starts from identical weights."""
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+    check_init_against_fixture(tr, fix)
+    A, B = synthetic_batch(N, S, 0, DEV)
+    for it, rec in enumerate(fix["iters"]):
+        out = tr.train_iteration(A, B, it, do_step=False)
+        strict = it == 0
+        rtol = 1e-4 if strict else 0.15
+        got = tr.losses_to_floats(out)
+        for k, v in rec["losses"].items():
+            assert got[k] == got[k], f"iter {it} {k} is NaN"
+            if strict or not k.startswith(("gen_loss", "dis_loss")):
+                assert abs(got[k] - v) <= rtol * abs(v) + 1e-6, f"iter {it} {k}: {got[k]} vs {v}"
+        if strict:
+            for k, v in rec["dis_out"].items():
+                t = getattr(out, {"A_real": "A_dis_real", "A_fake": "A_dis_fake", "B_real": "B_dis_real", "B_fake": "B_dis_fake"}[k])
+                assert torch.allclose(t.detach().reshape(-1).cpu(), torch.tensor(v), rtol=1e-3, atol=1e-6), f"iter {it} D out {k}"
+            for k in ("AB", "ABA"):
+                f = getattr(out, k).detach().reshape(-1).cpu()
+                ref = rec["outputs"][k]
+                assert abs(float(f.double().sum()) - ref["sum"]) <= 1e-4 * ref["abssum"], f"iter {it} {k} sum"
+            live = ("dis_A", "dis_B") if rec["step"] == "D" else ("gen_A", "gen_B")
+            worst = 0.0
+            for name in live:
+                for pn, p in tr.nets[name].named_parameters():
+                    ref_norm = rec["grad_norms"][name][pn]
+                    gn = float(p.grad.double().norm())
+                    assert abs(gn - ref_norm) <= 2e-3 * ref_norm + 1e-9, f"iter {it} grad norm {name}.{pn}: {gn} vs {ref_norm}"
+                    gs = torch.tensor([float(p.grad.reshape(-1)[i]) for i in sample_idx(p.numel())])
+                    rs = torch.tensor(rec["grad_samples"][name][pn])
+                    worst = max(worst, float((gs - rs).abs().max() / max(ref_norm, 1e-12)))
+            assert worst < 1e-3, f"iter {it}: sampled grad elements off by {worst:.2e} of the tensor norm"
+        (tr.optim_dis if rec["step"] == "D" else tr.optim_gen).step()
+        if strict:
+            live = ("dis_A", "dis_B") if rec["step"] == "D" else ("gen_A", "gen_B")
+            bad = tot = 0
+            for name in live:
+                for pn, p in tr.nets[name].named_parameters():
+                    ps = torch.tensor([float(p.detach().reshape(-1)[i]) for i in sample_idx(p.numel())])
+                    rs = torch.tensor(rec["after_step"][name][pn])
+                    d = (ps - rs).abs()
+                    assert float(d.max()) <= 4.1e-4, f"iter {it} after_step {name}.{pn}"   # <= 2*lr (a sign flip)
+                    bad += int((d > 2e-6).sum())
+                    tot += d.numel()
+            assert bad <= max(2, tot // 50), f"{bad}/{tot} sampled weights differ by more than 2e-6 after the first Adam step"
+        for name, net in tr.nets.items():
+            for bn_, b in net.named_buffers():
+                ref = rec["buffers"][name][bn_]
+                if b.dtype == torch.int64:
+                    assert int(b) == ref, f"iter {it} {name}.{bn_}: {int(b)} vs {ref}"
+                elif strict:
+                    f = b.detach().reshape(-1).cpu()
+                    assert abs(float(f.double().sum()) - ref["sum"]) <= 1e-4 * ref["abssum"] + 1e-6, f"iter {it} {name}.{bn_}"
+    return tr
+
+
+@pytest.mark.parametrize("S", [16, 64])
+def test_three_iterations_vs_oracle_fixture(S):
+    fix = json.load(open(os.path.join(GOLD, f"oracle_s{S}_n4.json")))
+    run_and_compare(fix, S, 4)
+
+
+def test_three_iterations_vs_reference_golden_512():
+    """The only size the reference itself can execute (model.py is hard-wired to 512 px)."""
+    fix = json.load(open(os.path.join(GOLD, "ref_s512_n2.json")))
+    assert fix["meta"]["source"].startswith("reference")
+    run_and_compare(fix, 512, 2)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("S,N", [(16, 4), (64, 4), (128, 2)])
+def test_teacher_forced_iterations_vs_oracle(S, N):
+    """Every iteration starts from the ORACLE's current weights/buffers, so the comparison stays
+    well-conditioned through the saturated-discriminator regime (iterations 1, 2): losses, D outputs,
+    per-tensor gradients, BN buffers, and the Adam update op-wise on the oracle's gradients."""
+    st = O.build_state(image_size=S, seed=1234)
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+    A, B = O.synthetic_batch(N, S, seed=0)
+    Ag, Bg = A.to(DEV), B.to(DEV)
+    for it in range(4):
+        for k in st.nets:
+            tr.nets[k].load_state_dict(st.nets[k].state_dict())
+        ref = O.train_iteration(st, A, B, it, do_step=False)
+        out = tr.train_iteration(Ag, Bg, it, do_step=False)
+        got, want = tr.losses_to_floats(out), O.losses_to_floats(ref)
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-6, f"iter {it} {k}: {got[k]} vs {v}"
+        for k in ("A_dis_real", "A_dis_fake", "B_dis_real", "B_dis_fake"):
+            assert torch.allclose(getattr(out, k).detach().reshape(-1).cpu(), getattr(ref, k).detach().reshape(-1),
+                                  rtol=2e-3, atol=1e-30), f"iter {it} {k}"
+        dstep = O.is_dis_step(it, st.args)
+        live = ("dis_A", "dis_B") if dstep else ("gen_A", "gen_B")
+        for name in live:
+            for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
+                e = rel_err(pm.grad, po.grad)
+                assert e < 2e-3, f"iter {it} grad {name}.{pn}: rel err {e:.2e}"
+        for name in st.nets:
+            for (bn_, bo), (_, bm) in zip(st.nets[name].named_buffers(), tr.nets[name].named_buffers()):
+                if bo.dtype == torch.int64:
+                    assert int(bo) == int(bm), f"iter {it} {name}.{bn_}"
+                else:
+                    max_close(bm, bo, 2e-4, 1e-6, f"iter {it} buffer {name}.{bn_}")
+        # Adam op-wise: feed the oracle's gradients to the device optimiser
+        for name in live:
+            for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
+                pm.grad.copy_(po.grad.to(DEV))
+        (st.optim_dis if dstep else st.optim_gen).step()
+        (tr.optim_dis if dstep else tr.optim_gen).step()
+        for name in live:
+            for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
+                d = float((pm.detach().cpu() - po.detach()).abs().max())
+                assert d <= 1e-6, f"iter {it} Adam {name}.{pn}: max diff {d:.2e}"
+
+
+def test_graph_replay_equals_eager():
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for graph in (False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234, use_graph=graph)
+        vals = []
+        for it in range(9):
+            out = tr.train_iteration(A, B, it)
+            vals.append(tr.losses_to_floats(out))
+        res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert a == b, "hipGraph replay must be bitwise identical to eager dispatch"
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_skipping_dead_work_changes_nothing():
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for skip in (False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234, skip_dead_work=skip)
+        vals = []
+        for it in range(6):
+            out = tr.train_iteration(A, B, it)
+            vals.append(tr.losses_to_floats(out))
+        res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-6 * abs(a[k]) + 1e-9, (k, a[k], b[k])
+    assert torch.allclose(res[0][1], res[1][1], rtol=0, atol=1e-6)
+    assert torch.allclose(res[0][2], res[1][2], rtol=0, atol=1e-6)
+
+
+# ---- size-independent properties at the benchmark shapes (oracle would take minutes there) ----------------
+@pytest.mark.parametrize("N,C,K,H", [(256, 64, 128, 32), (256, 256, 512, 8), (32, 64, 128, 256), (32, 2048, 2048, 8)])
+def test_conv_adjoint_identities_full_size(N, C, K, H):
+    """<conv(x), dy> == <x, dgrad(dy)> == <w, wgrad(dy, x)> for the bilinear map conv(x; w)."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = ops.empty_nhwc(N, C, H, H, DEV).uniform_(-1, 1, generator=g)
+    w = ops.empty_krsc(K, C, DEV).uniform_(-1, 1, generator=g) / (16 * C) ** 0.5
+    dy = ops.empty_nhwc(N, K, H // 2, H // 2, DEV).uniform_(-1, 1, generator=g)
+    y = ops.conv_fwd(x, w, 2, 1)
+    dx = ops.conv_dgrad(dy, w, (H, H), 2, 1)
+    dw = ops.conv_wgrad(dy, x, 2, 1)
+    a = (y.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = (y.double().norm() * dy.double().norm()).item()
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    # linearity in x
+    y2 = ops.conv_fwd(x * 0.5, w, 2, 1)
+    assert torch.allclose(y2, y * 0.5, rtol=1e-5, atol=1e-6)
+
+
+def test_full_batch_iteration_is_finite_and_deterministic():
+    """BASELINE config 2 shape (64 px, batch 256): two identical runs agree bitwise (no atomics)."""
+    A, B = synthetic_batch(256, 64, 0, DEV)
+    vals = []
+    for _ in range(2):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234)
+        outs = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(3)]
+        vals.append((outs, tr.optim_gen.flat_p.clone()))
+    for o in vals[0][0]:
+        assert all(v == v and abs(v) < 1e4 for v in o.values()), o
+    assert vals[0][0] == vals[1][0]
+    assert torch.equal(vals[0][1], vals[1][1])
