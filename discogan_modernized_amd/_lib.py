@@ -54,6 +54,7 @@ SIGNATURES = {
     "dg_mse_bwd": (_i, [_p, _p, _z, _p, _p, _p]),
     "dg_bce_fwd": (_i, [_p, _i, _f, _p, _p, _z, _p]),
     "dg_bce_bwd": (_i, [_p, _i, _f, _p, _p, _p]),
+    "dg_fm_workspace_bytes": (_z, [_i, _z]),
     "dg_fm_fwd": (_i, [_p, _p, _i, _z, _p, _p, _p, _z, _p]),
     "dg_fm_bwd": (_i, [_p, _i, _z, _p, _p, _p, _p]),
     "dg_adam_advance": (_i, [_p, _d, _d, _d, _p]),

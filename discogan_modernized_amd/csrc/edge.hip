@@ -1,15 +1,28 @@
-// 3-channel edge layers, image side NCHW (reference hands over / receives NCHW images:
+// 3-channel edge layers, image side NCHW (the reference hands over / receives NCHW images:
 // image_translation.py:332-333, model.py:8,80,142).  The forward direction (3 -> K) lives in
-// igemm.hip (MODE_FWD_C3, MFMA).  Here: the K -> 3 direction and the [K][3][4][4] weight gradient.
-// Both are HBM-bound (AI ~ 20 FLOP/B) and run on the VALU.
+// igemm.hip (MODE_FWD_C3).  Here: the K -> 3 direction and the [K][3][4][4] weight gradient.
+// All are HBM-bound (AI ~ 20 FLOP/B); both hot kernels feed the matrix cores so the VALU stays free.
+//
+//   c3_dgrad (K == 64): out[n,c,2a+ph,2b+pw] for a 2x2 output quad is a [9 neighbours x 64 k] . [576 x 12]
+//       product: M = quads, N = 12 (c,ph,pw) padded to 16, K = 576, on v_mfma_f32_16x16x4_f32.  The
+//       [576][16] weight image is structurally 4/9 dense (each output parity uses 2x2 of the 3x3
+//       neighbours) and is built once per workgroup in LDS from w[K][3][4][4].
+//   c3_wgrad: dw[64][48] = dy^T [64 x pixels] . im2col(x) [pixels x 48] on v_mfma_f32_32x32x2_f32; the four
+//       waves of a workgroup split each 32-pixel tile (intra-workgroup split-K), per-wave partial slabs
+//       are summed by a fixed-order reduction kernel (deterministic, no atomics).
 #include "dg_common.h"
 
-// dx_nchw[n,c,2a+ph,2b+pw] = act( sum_{taps,k} dy[n,a+da,b+db,k] * w[k][c][r][s] )
-// One thread = one 2x2 output quad (all 3 channels): weights are wave-uniform -> scalar loads.
 // Taps per output parity (conv k4 s2 p1): p=0 -> (r=1, d=0), (r=3, d=-1);  p=1 -> (r=2, d=0), (r=0, d=+1).
-__global__ __launch_bounds__(256) void c3_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, int N, int H, int W, int K,
-                                                       int lgHo, int lgWo, int act) {
+__device__ __forceinline__ int tap_of(int parity, int d) {
+    // returns the filter index r used by output parity `parity` for neighbour offset d, or -1
+    if (parity == 0) return d == 0 ? 1 : (d == -1 ? 3 : -1);
+    return d == 0 ? 2 : (d == 1 ? 0 : -1);
+}
+
+// ---- generic VALU fallback (any K % 4 == 0) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void c3_dgrad_valu_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int N, int H, int W, int K,
+                                                            int lgHo, int lgWo, int act) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long nquad = (long)N * Ho * Wo;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -60,9 +73,87 @@ __global__ __launch_bounds__(256) void c3_dgrad_kernel(const float* __restrict__
                 v0 = 1.f / (1.f + expf(-v0));
                 v1 = 1.f / (1.f + expf(-v1));
             }
-            float2 o = make_float2(v0, v1);
-            *(float2*)(dx + ((long)(n * 3 + c) * H + 2 * a + ph) * W + 2 * b) = o;
+            *(float2*)(dx + ((long)(n * 3 + c) * H + 2 * a + ph) * W + 2 * b) = make_float2(v0, v1);
         }
+}
+
+// ---- MFMA 16x16x4 version, K == 64 ----------------------------------------------------------------------
+#define CD_K 64
+#define CD_TR 4                 // quad rows per tile = waves per workgroup
+#define CD_TC 16                // quad columns per tile = MFMA M
+#define CD_PR (CD_TR + 2)       // staged dy pixel rows
+#define CD_PC (CD_TC + 2)       // staged dy pixel columns
+#define CD_LDP 66               // floats per staged pixel (64 + 2: conflict-free b32 A reads, 8-byte aligned rows)
+#define CD_NK (9 * CD_K)        // GEMM K = 576
+
+__global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               float* __restrict__ dx, int N, int H, int W, int act,
+                                                               int tiles_r, int tiles_c, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float WqS[CD_NK * 16];                 // [576][16]
+    __shared__ __attribute__((aligned(16))) float dyS[CD_PR * CD_PC * CD_LDP];     // [6*18][66]
+    __shared__ float outS[CD_TR][16 * 17];                                          // per wave [col][quad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ho = H >> 1, Wo = W >> 1;
+
+    // weight image: Wq[(nb, k)][col = c*4 + ph*2 + pw]
+    for (int e = tid; e < CD_NK * 16; e += 256) {
+        const int col = e & 15, row = e >> 4;
+        const int k = row & (CD_K - 1), nb = row >> 6;
+        const int da = nb / 3 - 1, db = nb % 3 - 1;
+        float v = 0.f;
+        if (col < 12) {
+            const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
+            const int r = tap_of(ph, da), s = tap_of(pw, db);
+            if (r >= 0 && s >= 0) v = w[(k * 3 + c) * 16 + r * 4 + s];
+        }
+        WqS[e] = v;
+    }
+
+    const int bq = lane & 15, kk = lane >> 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
+        const int a0 = tr * CD_TR, b0 = tc * CD_TC;
+        __syncthreads();  // previous tile's readers of dyS/outS are done (also orders the WqS build)
+        for (int idx = tid; idx < CD_PR * CD_PC * (CD_K / 4); idx += 256) {
+            const int q4 = idx & (CD_K / 4 - 1), pix = idx >> 4;
+            const int pr = pix / CD_PC, pc = pix - pr * CD_PC;
+            const int a = a0 - 1 + pr, b = b0 - 1 + pc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo)
+                v = *(const f32x4*)(dy + ((long)(n * Ho + a) * Wo + b) * CD_K + q4 * 4);
+            float* d = dyS + pix * CD_LDP + q4 * 4;
+            *(float2*)d = make_float2(v[0], v[1]);
+            *(float2*)(d + 2) = make_float2(v[2], v[3]);
+        }
+        __syncthreads();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < 9; ++nb) {
+            const int da = nb / 3 - 1, db = nb % 3 - 1;
+            const float* ap = dyS + ((wave + 1 + da) * CD_PC + bq + 1 + db) * CD_LDP + kk;
+            const float* bp = WqS + (nb * CD_K + kk) * 16 + bq;
+#pragma unroll
+            for (int ks = 0; ks < CD_K / 4; ks += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], bp[ks * 64], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4 + 4], bp[ks * 64 + 64], acc1, 0, 0, 0);
+            }
+        }
+        // C/D layout 16x16: col = lane & 15, row (quad) = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outS[wave][bq * 17 + kk * 4 + r] = acc0[r] + acc1[r];
+        __syncthreads();
+        const int a = a0 + wave;
+        const int ph = lane >> 5, x = lane & 31;          // x = 2*quad + pw within the 32-wide output row
+        const int qd = x >> 1, pw = x & 1;
+        if (a < Ho && b0 + qd < Wo) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = outS[wave][(c * 4 + ph * 2 + pw) * 17 + qd];
+                if (act == DG_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                dx[((long)(n * 3 + c) * H + 2 * a + ph) * W + 2 * b0 + x] = v;
+            }
+        }
+    }
 }
 
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
@@ -71,105 +162,159 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
     DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_dgrad: bad N/K (%d,%d)", N, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_dgrad: H,W must be powers of two");
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_SIGMOID, "dg_conv4x4s2_c3_dgrad: bad act %d", act);
-    const long nquad = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(c3_dgrad_kernel, dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy_nhwc, w, dx_nchw, N, H, W, K, dg_ilog2(H / 2), dg_ilog2(W / 2), act);
-    DG_CHECK_LAUNCH("c3_dgrad");
+    DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_dgrad: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H / 2, Wo = W / 2;
+    if (K == CD_K) {
+        const int tiles_r = (Ho + CD_TR - 1) / CD_TR, tiles_c = (Wo + CD_TC - 1) / CD_TC;
+        const long ntiles = (long)N * tiles_r * tiles_c;
+        DG_CHECK_ARG(ntiles < (1L << 31), "dg_conv4x4s2_c3_dgrad: too many tiles");
+        const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+        hipLaunchKernelGGL(c3_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                           tiles_r, tiles_c, (int)ntiles);
+        DG_CHECK_LAUNCH("c3_dgrad_mfma");
+        return DG_OK;
+    }
+    const long nquad = (long)N * Ho * Wo;
+    hipLaunchKernelGGL(c3_dgrad_valu_kernel, dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, st, dy_nhwc, w,
+                       dx_nchw, N, H, W, K, dg_ilog2(Ho), dg_ilog2(Wo), act);
+    DG_CHECK_LAUNCH("c3_dgrad_valu");
     return DG_OK;
 }
 
+// ---- weight gradient -------------------------------------------------------------------------------------
 // dw[k][c][r][s] (+)= sum_{pixels} dy[pix][k] * x[n,c,2oy-1+r,2ox-1+s]
-// Block: 256 threads = 64 k-lanes x 4 parts (12 of the 48 (c,r,s) entries each).  Pixels are staged
-// 64 at a time as an im2col patch in LDS (broadcast reads); per-block partial sums go to the workspace
-// and a second kernel reduces them in a fixed order (deterministic, no atomics).
-#define C3W_PIX 64
-__global__ __launch_bounds__(256) void c3_wgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+#define CW_PT 32     // pixels per LDS tile
+#define CW_LD 68     // 64 + 4 floats per staged row
+__global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ part, int N, int H, int W, int K,
-                                                               int lgHo, int lgWo, long npix, int kgroups) {
-    __shared__ __attribute__((aligned(16))) float patch[C3W_PIX][48];
+                                                               int lgHo, int lgWo, long npix, int pix_per_block) {
+    __shared__ __attribute__((aligned(16))) float dyS[CW_PT * CW_LD];   // [pixel][k]   (A operand, k-major)
+    __shared__ __attribute__((aligned(16))) float pS[CW_PT * CW_LD];    // [pixel][j]   (B operand; j >= 48 stays 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
-    const int tid = threadIdx.x;
-    const int kl = tid & 63, prt = tid >> 6;
-    const int kg = blockIdx.y;  // 64-wide group of output channels
-    const int k = kg * 64 + kl;
-    float acc[12];
+    const int kg = blockIdx.y;
+    for (int e = tid; e < CW_PT * CW_LD; e += 256) pS[e] = 0.f;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-    for (long p0 = (long)blockIdx.x * C3W_PIX; p0 < npix; p0 += (long)gridDim.x * C3W_PIX) {
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const long p_begin = (long)blockIdx.x * pix_per_block;
+    const long p_end = min(npix, p_begin + pix_per_block);
+    const int drow = tid >> 4, dcq = tid & 15;          // dy tile: 32 rows x 16 float4, 2 per thread
+    const int gpl = tid & 31, gjb = tid >> 5;           // patch gather: pixel, j = gjb + 8*i
+    for (long p0 = p_begin; p0 < p_end; p0 += CW_PT) {
         __syncthreads();
-        // stage the im2col patch: 64 pixels x 48 values, 12 per thread
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int e = tid + i * 256;       // 0..3071
-            const int pl = e & 63, qq = e >> 6;  // pixel in stage, (c,r,s) index 0..47
-            const long pp = p0 + pl;
-            float v = 0.f;
-            if (pp < npix) {
-                const int ox = (int)(pp & (Wo - 1)), oy = (int)((pp >> lgWo) & (Ho - 1)), n = (int)(pp >> (lgWo + lgHo));
-                const int c = qq >> 4, r = (qq >> 2) & 3, s = qq & 3;
+        for (int i = 0; i < 2; ++i) {
+            const int row = drow + 16 * i;
+            const long pp = p0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pp < p_end) v = *(const f32x4*)(dy + pp * K + kg * 64 + dcq * 4);
+            *(f32x4*)(dyS + row * CW_LD + dcq * 4) = v;
+        }
+        {
+            const long pp = p0 + gpl;
+            const bool pok = pp < p_end;
+            const int ox = (int)(pp & (Wo - 1)), oy = (int)((pp >> lgWo) & (Ho - 1)), n = (int)(pp >> (lgWo + lgHo));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int j = gjb + 8 * i;
+                const int c = j >> 4, r = (j >> 2) & 3, s = j & 3;
                 const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + s;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((long)(n * 3 + c) * H + iy) * W + ix];
+                float v = 0.f;
+                if (pok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = x[((long)(n * 3 + c) * H + iy) * W + ix];
+                pS[gpl * CW_LD + j] = v;
             }
-            patch[pl][qq] = v;
         }
         __syncthreads();
-        const int npl = (int)min((long)C3W_PIX, npix - p0);
-        if (k < K) {
-            for (int pl = 0; pl < npl; ++pl) {
-                const float g = dy[(p0 + pl) * K + k];
-                const f32x4 a0 = *(const f32x4*)&patch[pl][prt * 12 + 0];
-                const f32x4 a1 = *(const f32x4*)&patch[pl][prt * 12 + 4];
-                const f32x4 a2 = *(const f32x4*)&patch[pl][prt * 12 + 8];
+        // intra-workgroup split-K: wave w owns pixels [8w, 8w+8) of the tile
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j] += g * a0[j];
-                    acc[4 + j] += g * a1[j];
-                    acc[8 + j] += g * a2[j];
-                }
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int kkp = wave * 8 + s2 * 2 + lh;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = dyS[kkp * CW_LD + i * 32 + l31];
+                b[i] = pS[kkp * CW_LD + i * 32 + l31];
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
         }
     }
-    if (k < K) {
-        float* dst = part + ((long)blockIdx.x * K + k) * 48 + prt * 12;
+    // per-wave partial slab: part[(block*4 + wave)][K][48]
+    float* slab = part + ((long)(blockIdx.x * 4 + wave) * K + kg * 64) * 48;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) dst[i] = acc[i];
-    }
-}
-__global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                              int nparts, int total, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += part[(long)b * total + e];
-    if (accumulate) s += dw[e];
-    dw[e] = s;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int j = jn * 32 + l31;
+                if (j < 48) slab[(long)k * 48 + j] = acc[i][jn][r];
+            }
+        }
 }
 
-static int c3_wgrad_blocks(long npix) {
-    long nb = (npix + C3W_PIX - 1) / C3W_PIX;
-    if (nb > 1024) nb = 1024;
-    return (int)nb;
+// fixed-order reduction over slabs: block = 16 outputs x 16 slab lanes
+__global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                              int nslabs, int total, int accumulate) {
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float s = 0.f;
+    if (e < total)
+        for (int b = sl; b < nslabs; b += 16) s += part[(long)b * total + e];
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) s += red[j][el];
+        if (accumulate) s += dw[e];
+        dw[e] = s;
+    }
+}
+
+static void c3_wgrad_plan(long npix, int* nb, int* ppb) {
+    long per = (npix + 255) / 256;                       // aim for ~256 workgroups per 64-channel group
+    per = (per + CW_PT - 1) / CW_PT * CW_PT;
+    if (per < CW_PT) per = CW_PT;
+    *ppb = (int)per;
+    *nb = (int)((npix + per - 1) / per);
 }
 extern "C" size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K) {
     const long npix = (long)N * (H / 2) * (W / 2);
-    return (size_t)c3_wgrad_blocks(npix) * K * 48 * sizeof(float);
+    int nb, ppb;
+    c3_wgrad_plan(npix, &nb, &ppb);
+    return (size_t)nb * 4 * K * 48 * sizeof(float);
 }
 extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                                      int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_nhwc && x_nchw && dw, "dg_conv4x4s2_c3_wgrad: null pointer");
-    DG_CHECK_ARG(N >= 1 && K >= 1, "dg_conv4x4s2_c3_wgrad: bad N/K (%d,%d)", N, K);
+    DG_CHECK_ARG(N >= 1 && K >= 64 && K % 64 == 0, "dg_conv4x4s2_c3_wgrad: K=%d must be a multiple of 64", K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_wgrad: H,W must be powers of two");
+    DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_wgrad: tensor too large");
     const long npix = (long)N * (H / 2) * (W / 2);
-    const int nb = c3_wgrad_blocks(npix);
-    const size_t need = (size_t)nb * K * 48 * sizeof(float);
+    int nb, ppb;
+    c3_wgrad_plan(npix, &nb, &ppb);
+    const size_t need = (size_t)nb * 4 * K * 48 * sizeof(float);
     if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "dg_conv4x4s2_c3_wgrad: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const int kgroups = (K + 63) / 64;
-    hipLaunchKernelGGL(c3_wgrad_partial_kernel, dim3(nb, kgroups), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws,
-                       N, H, W, K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, kgroups);
-    DG_CHECK_LAUNCH("c3_wgrad_partial");
+    hipLaunchKernelGGL(c3_wgrad_mfma_kernel, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
+                       dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppb);
+    DG_CHECK_LAUNCH("c3_wgrad_mfma");
     const int total = K * 48;
-    hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);
+    hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb * 4, total, accumulate);
     DG_CHECK_LAUNCH("c3_wgrad_reduce");
     return DG_OK;
 }

@@ -75,23 +75,40 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     dp[i] = gout[0] * (v - label) / fmaxf((1.f - v) * v, 1e-12f) / (float)n;
 }
 
-// diff[j] = mean_n real[n][j] - mean_n fake[n][j];  partial sum of diff^2
-__global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake, int N,
-                                                     long J, float* __restrict__ diff, double* __restrict__ part) {
+// Feature matching, stage 1: batch-chunk partial sums.  grid = (J/4/256 blocks, nchunks); each thread
+// owns one float4 column and walks its chunk of the batch (coalesced 4 KB rows per block).
+// part layout: [2][nchunks][J]  (0: real, 1: fake)
+__global__ __launch_bounds__(256) void fm_partial_kernel(const float* __restrict__ real, const float* __restrict__ fake, int N,
+                                                         long J, int nchunks, float* __restrict__ part) {
+    const long j4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j4 * 4 >= J) return;
+    const int per = (N + nchunks - 1) / nchunks;
+    const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
+    f32x4 sr = {0.f, 0.f, 0.f, 0.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        sr += *(const f32x4*)(real + (long)n * J + j4 * 4);
+        sf += *(const f32x4*)(fake + (long)n * J + j4 * 4);
+    }
+    *(f32x4*)(part + (long)blockIdx.y * J + j4 * 4) = sr;
+    *(f32x4*)(part + ((long)nchunks + blockIdx.y) * J + j4 * 4) = sf;
+}
+// stage 2: diff[j] = mean_n real - mean_n fake (fixed chunk order), block partials of diff^2
+__global__ __launch_bounds__(256) void fm_diff_kernel(const float* __restrict__ part, int N, long J, int nchunks,
+                                                      float* __restrict__ diff, double* __restrict__ dpart) {
     float s = 0.f;
     const long j4n = J >> 2;
     const float inv = 1.f / (float)N;
     for (long j4 = (long)blockIdx.x * 256 + threadIdx.x; j4 < j4n; j4 += (long)gridDim.x * 256) {
         f32x4 sr = {0.f, 0.f, 0.f, 0.f}, sf = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < N; ++n) {
-            sr += *(const f32x4*)(real + (long)n * J + j4 * 4);
-            sf += *(const f32x4*)(fake + (long)n * J + j4 * 4);
+        for (int c = 0; c < nchunks; ++c) {
+            sr += *(const f32x4*)(part + (long)c * J + j4 * 4);
+            sf += *(const f32x4*)(part + ((long)nchunks + c) * J + j4 * 4);
         }
         const f32x4 d = sr * inv - sf * inv;
         *(f32x4*)(diff + j4 * 4) = d;
         s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
     }
-    block_partial_store(s, part);
+    block_partial_store(s, dpart);
 }
 __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ diff, int N, long J, const float* __restrict__ gout,
                                                      float* __restrict__ dreal, float* __restrict__ dfake) {
@@ -144,15 +161,31 @@ extern "C" int dg_bce_bwd(const float* p, int n, float label, const float* gout,
     DG_CHECK_LAUNCH("bce_bwd");
     return DG_OK;
 }
+static int fm_chunks(int N, size_t J) {
+    const long blocks = (long)((J / 4 + 255) / 256);
+    long c = 2048 / blocks;            // aim for ~2048 blocks in stage 1
+    if (c > N / 4) c = N / 4;          // at least 4 images per chunk
+    if (c > 64) c = 64;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+extern "C" size_t dg_fm_workspace_bytes(int N, size_t J) {
+    return dg_loss_workspace_bytes() + (size_t)2 * fm_chunks(N, J) * J * sizeof(float);
+}
 extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss, void* ws,
                          size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(real && fake && diff && loss && N > 0 && J > 0 && J % 4 == 0, "dg_fm_fwd: bad argument");
-    if (!ws || ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
-    const int g = loss_grid((long)(J / 4));
+    if (!ws || ws_bytes < dg_fm_workspace_bytes(N, J)) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
+    const int nch = fm_chunks(N, J);
+    double* dpart = (double*)ws;
+    float* part = (float*)((char*)ws + dg_loss_workspace_bytes());
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fm_fwd_kernel, dim3(g), dim3(256), 0, st, real, fake, N, (long)J, diff, (double*)ws);
-    DG_CHECK_LAUNCH("fm_fwd");
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)J, loss);
+    hipLaunchKernelGGL(fm_partial_kernel, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, real, fake, N, (long)J, nch, part);
+    DG_CHECK_LAUNCH("fm_partial");
+    const int g = loss_grid((long)(J / 4));
+    hipLaunchKernelGGL(fm_diff_kernel, dim3(g), dim3(256), 0, st, (const float*)part, N, (long)J, nch, diff, dpart);
+    DG_CHECK_LAUNCH("fm_diff");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)dpart, g, 1.0 / (double)J, loss);
     DG_CHECK_LAUNCH("fm_final");
     return DG_OK;
 }

@@ -133,17 +133,21 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
     return 1.f;
 }
 
-// part layout: [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
+// BatchNorm backward reductions and the final expression run in fp64, like PyTorch's CPU kernels
+// (accscalar_t = double): dy is a small difference of large terms whenever the incoming gradient is
+// nearly constant within a channel (saturated discriminator), and fp32 there costs percents.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// part layout (fp64): [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                                             float* __restrict__ part, int M, int C, int rchunks,
+                                                             double* __restrict__ part, int M, int C, int rchunks,
                                                              const float* __restrict__ saved, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope) {
-    __shared__ f32x4 red[2][BN_TY][BN_TX];
+    __shared__ f64x4 red[2][BN_TY][BN_TX];
     const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
     const int c = (blockIdx.x * BN_TX + tx) * 4;
     const int rows_per = (M + rchunks - 1) / rchunks;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    f64x4 s = {0., 0., 0., 0.}, q = {0., 0., 0., 0.};
     if (c < C) {
         const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
         const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float u = bn_norm(v[j], mean[j], g[j] * istd[j], b[j]);
-                const float gg = d[j] * act_grad(u, act, slope);
+                const double gg = (double)(d[j] * act_grad(u, act, slope));
                 s[j] += gg;
-                q[j] += gg * ((v[j] - mean[j]) * istd[j]);
+                q[j] += gg * (((double)v[j] - (double)mean[j]) * (double)istd[j]);
             }
         }
     }
@@ -168,20 +172,35 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
             s += red[0][j][tx];
             q += red[1][j][tx];
         }
-        *(f32x4*)(part + (long)blockIdx.y * C + c) = s;
-        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
+        *(f64x4*)(part + (long)blockIdx.y * C + c) = s;
+        *(f64x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
     }
 }
 
-// coef: [2][C] = dbeta/M, dgamma/M  (kept in the workspace after the partials)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int M, int C, int rchunks,
-                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+// coef (fp64): [2][C] = dbeta/M, dgamma/M  (kept in the workspace after the partials)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int M, int C, int rchunks,
+                                                              double* __restrict__ coef, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-    double s, q;
-    const int c = bn_reduce_partials(part, C, rchunks, &s, &q);
-    if (c < 0) return;
-    coef[c] = (float)(s / M);
-    coef[C + c] = (float)(q / M);
+    __shared__ double red[2][32][BN_FIN_CH];
+    const int cl = threadIdx.x % BN_FIN_CH, pl = threadIdx.x / BN_FIN_CH;
+    const int c = blockIdx.x * BN_FIN_CH + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int r = pl; r < rchunks; r += 32) {
+            s += part[(long)r * C + c];
+            q += part[((long)rchunks + r) * C + c];
+        }
+    }
+    red[0][pl][cl] = s;
+    red[1][pl][cl] = q;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    for (int j = 1; j < 32; ++j) {
+        s += red[0][j][cl];
+        q += red[1][j][cl];
+    }
+    coef[c] = s / M;
+    coef[C + c] = q / M;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
 }
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                            float* __restrict__ dy, long total4, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ coef,
+                                                           const float* __restrict__ beta, const double* __restrict__ coef,
                                                            int act, float slope) {
     const int c4n = C >> 2;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
@@ -198,15 +217,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 d = *(const f32x4*)(dz + idx * 4);
         const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
         const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        const f32x4 c1 = *(const f32x4*)(coef + c), c2 = *(const f32x4*)(coef + C + c);
+        const f64x4 c1 = *(const f64x4*)(coef + c), c2 = *(const f64x4*)(coef + C + c);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gs = g[j] * istd[j];
             const float u = bn_norm(v[j], mean[j], gs, b[j]);
-            const float gg = d[j] * act_grad(u, act, slope);
-            const float xhat = (v[j] - mean[j]) * istd[j];
-            o[j] = gs * (gg - c1[j] - xhat * c2[j]);
+            const double gg = (double)(d[j] * act_grad(u, act, slope));
+            const double xhat = ((double)v[j] - (double)mean[j]) * (double)istd[j];
+            o[j] = (float)((double)g[j] * (double)istd[j] * (gg - c1[j] - xhat * c2[j]));
         }
         *(f32x4*)(dy + idx * 4) = o;
     }
@@ -260,7 +279,7 @@ static int stream_grid(long total4) {
 extern "C" size_t dg_bn_workspace_bytes(int M, int C) {
     int cc, rc;
     bn_grid(M, C, &cc, &rc);
-    return ((size_t)2 * rc * C + 2 * (size_t)C) * sizeof(float);
+    return ((size_t)2 * rc * C + 2 * (size_t)C) * sizeof(double);   // fp64 partials in the backward
 }
 
 extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
@@ -305,16 +324,16 @@ extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, 
     int cc, rc;
     bn_grid(M, C, &cc, &rc);
     hipStream_t st = (hipStream_t)stream;
-    float* part = (float*)ws;
-    float* coef = part + (size_t)2 * rc * C;
+    double* part = (double*)ws;
+    double* coef = part + (size_t)2 * rc * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, saved, gamma, beta, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_partial");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const float*)part, M, C, rc, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const double*)part, M, C, rc, coef,
                        dgamma, dbeta, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long total4 = (long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
-                       beta, (const float*)coef, act, slope);
+                       beta, (const double*)coef, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
 }

@@ -336,7 +336,7 @@ def fm_fwd(real, fake):
     j = real.numel() // n
     diff = torch.empty(j, device=real.device, dtype=torch.float32)
     loss = torch.empty((), device=real.device, dtype=torch.float32)
-    ws, wsb = _loss_ws(real.device)
+    ws, wsb = _ws(_lib.load().dg_fm_workspace_bytes(n, j), real.device)
     _lib.check(_lib.load().dg_fm_fwd(_ptr(real), _ptr(fake), n, j, _ptr(diff), _ptr(loss), _ptr(ws), wsb, _stream()),
                "dg_fm_fwd")
     return loss, diff, real, fake

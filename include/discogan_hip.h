@@ -147,7 +147,8 @@ int dg_mse_bwd(const float* x, const float* t, size_t n, const float* gout, floa
 int dg_bce_fwd(const float* p, int n, float label, float* loss, void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_bce_bwd(const float* p, int n, float label, const float* gout, float* dp, dg_stream_t s);
 /* one layer of get_fm_loss (image_translation.py:136-144): mean_j (mean_n real - mean_n fake)^2,
- * real/fake [N][J]; diff[J] kept for backward */
+ * real/fake [N][J]; diff[J] kept for backward; ws >= dg_fm_workspace_bytes(N, J) */
+size_t dg_fm_workspace_bytes(int N, size_t J);
 int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss,
               void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);

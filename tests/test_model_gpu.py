@@ -221,6 +221,7 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
     """Every iteration starts from the ORACLE's current weights/buffers, so the comparison stays
     well-conditioned through the saturated-discriminator regime (iterations 1, 2): losses, D outputs,
     per-tensor gradients, BN buffers, and the Adam update op-wise on the oracle's gradients."""
+    import copy
     st = O.build_state(image_size=S, seed=1234)
     tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
     A, B = O.synthetic_batch(N, S, seed=0)
@@ -228,6 +229,29 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
     for it in range(4):
         for k in st.nets:
             tr.nets[k].load_state_dict(st.nets[k].state_dict())
+        # fp64 run of the same oracle = ground truth.  Two conditioning yardsticks per tensor:
+        #   noise: the oracle's own fp32-vs-fp64 error (first-layer / BN-bias gradients are only good to
+        #          ~1e-2 in the reference's own fp32 arithmetic at small batch);
+        #   sens : LeakyReLU/ReLU have a discontinuous derivative at 0.  A BN output within fp32 rounding
+        #          of 0 gets derivative 1.0 in one implementation and 0.2 (or 0) in another; at batch 4
+        #          ONE such element moves every upstream gradient by ~1% (measured).  We probe it by
+        #          shifting every BN bias by +-5e-6 in fp64 and differencing the gradients.
+        def oracle64_grads(shift):
+            s64 = copy.deepcopy(st)
+            for net in s64.nets.values():
+                net.double()
+                if shift != 0.0:
+                    for m in net.modules():
+                        if isinstance(m, torch.nn.BatchNorm2d):
+                            m.bias.data.add_(shift)
+            torch.set_default_dtype(torch.float64)
+            try:
+                O.train_iteration(s64, A.double(), B.double(), it, do_step=False)
+            finally:
+                torch.set_default_dtype(torch.float32)
+            return s64
+        st64 = oracle64_grads(0.0)
+        st64p, st64m = oracle64_grads(5e-6), oracle64_grads(-5e-6)   # ~ fp32 rounding of u = (y-mean)*gs+beta
         ref = O.train_iteration(st, A, B, it, do_step=False)
         out = tr.train_iteration(Ag, Bg, it, do_step=False)
         got, want = tr.losses_to_floats(out), O.losses_to_floats(ref)
@@ -239,9 +263,15 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
         dstep = O.is_dis_step(it, st.args)
         live = ("dis_A", "dis_B") if dstep else ("gen_A", "gen_B")
         for name in live:
-            for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
-                e = rel_err(pm.grad, po.grad)
-                assert e < 2e-3, f"iter {it} grad {name}.{pn}: rel err {e:.2e}"
+            for (pn, po), (_, pm), (_, p64), (_, pp), (_, pq) in zip(
+                    st.nets[name].named_parameters(), tr.nets[name].named_parameters(),
+                    st64.nets[name].named_parameters(), st64p.nets[name].named_parameters(),
+                    st64m.nets[name].named_parameters()):
+                noise = rel_err(po.grad, p64.grad)           # the reference's own fp32 error
+                sens = rel_err(pp.grad, pq.grad)             # activation-derivative discontinuity
+                e = rel_err(pm.grad, p64.grad)
+                assert e < max(1e-3, 8 * noise, 8 * sens), \
+                    f"iter {it} grad {name}.{pn}: rel err {e:.2e} (reference fp32 noise {noise:.2e}, kink sensitivity {sens:.2e})"
         for name in st.nets:
             for (bn_, bo), (_, bm) in zip(st.nets[name].named_buffers(), tr.nets[name].named_buffers()):
                 if bo.dtype == torch.int64:
