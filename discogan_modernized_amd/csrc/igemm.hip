@@ -30,6 +30,7 @@
 // blockIdx; partial fp32 slabs go to the caller's workspace and a second kernel sums them in a fixed
 // order (bitwise reproducible; no float atomics).
 #include "dg_common.h"
+#include <type_traits>
 
 enum { MODE_FWD = 0, MODE_DGRAD_S2 = 1, MODE_DGRAD_PLAIN = 2, MODE_WGRAD = 3, MODE_FWD_C3 = 4 };
 
@@ -50,6 +51,11 @@ struct IgemmArgs {
 };
 
 #define NEG_BIG (-(1 << 28))
+
+// Masked (padding / out-of-range) operand vectors are fetched from this zero block instead of being
+// zeroed after the load: a select on the loaded value would force an s_waitcnt right behind every
+// global load and serialise HBM latency into the MFMA stream.
+__device__ float dg_zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 template <int MODE, int WM, int WN, int KT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
@@ -160,116 +166,88 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         chunk = it_begin - tap * kchunks;
     }
 
-    f32x4 ra[NVA], rb[NVB];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[2][NVA], rb[2][NVB];   // two register sets: tiles t+1 (waiting to be written to LDS) and t+2 (in flight)
 
-    auto load_tiles = [&](int it) {
+    // Branch-free tile loads: an invalid (padding / out-of-range) vector loads from the tensor base and
+    // is zeroed by a select, so the whole K-loop body is ONE basic block and the address arithmetic,
+    // global loads, LDS reads and LDS writes can be interleaved between MFMAs (each 64-cycle
+    // v_mfma_f32_32x32x2_f32 leaves ~48 issue cycles for other instruction types).
+    const float* const zp = dg_zero16;
+    auto ld4 = [&](const float* base, long off, bool ok) -> f32x4 {
+        const float* ptr = ok ? base + off : zp;
+        return *(const f32x4*)ptr;
+    };
+    auto load_A = [&](int set, int i, int it) {
         if (MODE == MODE_FWD) {
             const int r = tap >> 2, s = tap & 3, c0 = chunk * KT;
-#pragma unroll
-            for (int i = 0; i < NVA; ++i) {
-                const int iy = a_y[i] + r, ix = a_x[i] + s;
-                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const long off = (long)(a_pix[i] + r * W + s) * Cc + c0 + acq * 4;
-                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
-            }
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int k = n0 + brow0 + i * B_RSTEP;
-                const long off = (long)k * 16 * Cc + (long)it * KT + bcq * 4;
-                rb[i] = (k < K) ? *(const f32x4*)(Bg + off) : zero4;
-            }
+            const int iy = a_y[i] + r, ix = a_x[i] + s;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            ra[set][i] = ld4(Ag, (long)(a_pix[i] + r * W + s) * Cc + c0 + acq * 4, ok);
         } else if (MODE == MODE_FWD_C3) {
             static_assert(MODE != MODE_FWD_C3 || KT == 16, "FWD_C3 iterates one input channel (16 taps) per K-tile");
+            const bool rowok = (unsigned)a_y[i] < (unsigned)H;
+            const long base = (long)a_pix[i] + (long)it * H * W;
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) {
-                const bool rowok = (unsigned)a_y[i] < (unsigned)H;
-                const float* src = Ag + ((long)a_pix[i] + (long)it * H * W);
-                f32x4 v = zero4;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int ix = a_x[i] + s;
-                    if (rowok && (unsigned)ix < (unsigned)W) v[s] = src[s];
-                }
-                ra[i] = v;
+            for (int s = 0; s < 4; ++s) {
+                const bool ok = rowok && (unsigned)(a_x[i] + s) < (unsigned)W;
+                const float* ptr = ok ? Ag + base + s : zp;
+                v[s] = *ptr;
             }
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int k = n0 + brow0 + i * B_RSTEP;
-                rb[i] = (k < K) ? *(const f32x4*)(Bg + (long)k * 48 + it * 16 + bcq * 4) : zero4;
-            }
+            ra[set][i] = v;
         } else if (MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1, k0 = chunk * KT;
             const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
-            const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
             const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
-            const int s = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
-#pragma unroll
-            for (int i = 0; i < NVA; ++i) {
-                const int iy = a_y[i] + dyo, ix = a_x[i] + dxo;
-                const bool ok = (unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo;
-                const long off = (long)(a_pix[i] + dyo * Wo + dxo) * K + k0 + acq * 4;
-                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
-            }
-            const int col = n0 + bcq * 4;
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int k = k0 + brow0 + i * B_RSTEP;
-                const long off = (long)(k * 16 + r * 4 + s) * Cc + col;
-                rb[i] = (col < Cc) ? *(const f32x4*)(Bg + off) : zero4;
-            }
+            const int iy = a_y[i] + dyo, ix = a_x[i] + dxo;
+            const bool ok = (unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo;
+            ra[set][i] = ld4(Ag, (long)(a_pix[i] + dyo * Wo + dxo) * K + k0 + acq * 4, ok);
         } else if (MODE == MODE_DGRAD_PLAIN) {
-            const int k0 = it * KT;
-            const int kcol = k0 + acq * 4;
-#pragma unroll
-            for (int i = 0; i < NVA; ++i) {
-                const bool ok = a_y[i] >= 0 && kcol < K;
-                const long off = (long)a_pix[i] * K + kcol;
-                ra[i] = ok ? *(const f32x4*)(Ag + off) : zero4;
-            }
-            const int col = n0 + bcq * 4;
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int k = k0 + brow0 + i * B_RSTEP;
-                const long off = (long)k * p.Ng + col;
-                rb[i] = (k < K && col < p.Ng) ? *(const f32x4*)(Bg + off) : zero4;
-            }
-        } else {  // WGRAD: rows of both tiles are reduction pixels
-            const int mm0 = it * KT;
+            const int kcol = it * KT + acq * 4;
+            ra[set][i] = ld4(Ag, (long)a_pix[i] * K + kcol, a_y[i] >= 0 && kcol < K);
+        } else {  // WGRAD: rows are reduction pixels
+            const int mrow = it * KT + arow0 + i * A_RSTEP;
             const int kcol = m0 + acq * 4;
-#pragma unroll
-            for (int i = 0; i < NVA; ++i) {
-                const int mrow = mm0 + arow0 + i * A_RSTEP;
-                const long off = (long)mrow * K + kcol;
-                ra[i] = (mrow < p.R && kcol < K) ? *(const f32x4*)(Ag + off) : zero4;
-            }
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) {
-                const int mrow = mm0 + brow0 + i * B_RSTEP;
-                const int ox = mrow & (Wo - 1), oy = (mrow >> lgWo) & (Ho - 1), n = mrow >> lgHW;
-                const int iy = oy * p.stride - p.pad + wg_r, ix = ox * p.stride - p.pad + wg_s;
-                const bool ok = wg_colok && mrow < p.R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const long off = (long)((n * H + iy) * W + ix) * Cc + wg_c;
-                rb[i] = ok ? *(const f32x4*)(Bg + off) : zero4;
-            }
+            ra[set][i] = ld4(Ag, (long)mrow * K + kcol, mrow < p.R && kcol < K);
         }
     };
-    auto advance = [&]() {
+    auto load_B = [&](int set, int i, int it) {
+        if (MODE == MODE_FWD) {
+            const int k = n0 + brow0 + i * B_RSTEP;
+            rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)it * KT + bcq * 4, k < K);
+        } else if (MODE == MODE_FWD_C3) {
+            const int k = n0 + brow0 + i * B_RSTEP;
+            rb[set][i] = ld4(Bg, (long)k * 48 + it * 16 + bcq * 4, k < K);
+        } else if (MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1, k0 = chunk * KT;
+            const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+            const int s = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+            const int col = n0 + bcq * 4;
+            const int k = k0 + brow0 + i * B_RSTEP;
+            rb[set][i] = ld4(Bg, (long)(k * 16 + r * 4 + s) * Cc + col, col < Cc);
+        } else if (MODE == MODE_DGRAD_PLAIN) {
+            const int col = n0 + bcq * 4;
+            const int k = it * KT + brow0 + i * B_RSTEP;
+            rb[set][i] = ld4(Bg, (long)k * p.Ng + col, k < K && col < p.Ng);
+        } else {
+            const int mrow = it * KT + brow0 + i * B_RSTEP;
+            const int ox = mrow & (Wo - 1), oy = (mrow >> lgWo) & (Ho - 1), n = mrow >> lgHW;
+            const int iy = oy * p.stride - p.pad + wg_r, ix = ox * p.stride - p.pad + wg_s;
+            const bool ok = wg_colok && mrow < p.R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            rb[set][i] = ld4(Bg, (long)((n * H + iy) * W + ix) * Cc + wg_c, ok);
+        }
+    };
+    // (tap, chunk) advance without control flow; `go` = 0 freezes the state on the last iteration
+    auto advance = [&](int go) {
         if (MODE == MODE_FWD || MODE == MODE_DGRAD_S2) {
-            if (++chunk == kchunks) {
-                chunk = 0;
-                ++tap;
-            }
+            chunk += go;
+            const int wrap = (chunk == kchunks) ? 1 : 0;
+            chunk = wrap ? 0 : chunk;
+            tap += wrap;
         }
     };
-    auto store_tiles = [&](float* stage) {
-        float* As = stage;
-        float* Bs = stage + A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) *(f32x4*)(As + (arow0 + i * A_RSTEP) * LDA + acq * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) *(f32x4*)(Bs + (brow0 + i * B_RSTEP) * LDB + bcq * 4) = rb[i];
-    };
+    auto store_A = [&](float* stage, int set, int i) { *(f32x4*)(stage + (arow0 + i * A_RSTEP) * LDA + acq * 4) = ra[set][i]; };
+    auto store_B = [&](float* stage, int set, int i) { *(f32x4*)(stage + A_FLOATS + (brow0 + i * B_RSTEP) * LDB + bcq * 4) = rb[set][i]; };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -279,54 +257,92 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LDS fragment fetch for one 8-wide k group: a[i][0..3], b[i][0..3] = the lane's operands of 4 MFMAs
+    auto fetch = [&](const float* As, const float* Bs, int kb, float (&a)[2][4], float (&b)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            if (!A_KM) {
+                const f32x4 v = *(const f32x4*)(As + row * LDA + kb * 8 + 4 * lh);
+                a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[i][j] = As[(kb * 8 + 4 * lh + j) * LDA + row];
+            }
+            const int col = wn * 64 + i * 32 + l31;
+            if (!B_KM) {
+                const f32x4 v = *(const f32x4*)(Bs + col * LDB + kb * 8 + 4 * lh);
+                b[i][0] = v[0]; b[i][1] = v[1]; b[i][2] = v[2]; b[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb * 8 + 4 * lh + j) * LDB + col];
+            }
+        }
+    };
+
+    constexpr int NG = KT / 8;            // k groups per tile (16 MFMAs each)
+    constexpr int SC = NG * 4;            // sub-chunks of 4 MFMAs
+    constexpr int NLD = NVA + NVB;        // global-load / LDS-store work items per tile
+    static_assert(NLD <= SC, "more load items than sub-chunks");
+    constexpr int ST0 = SC - NLD;         // first sub-chunk that carries an LDS store
+
+    // Pipeline: tile t lives in LDS buffer (t & 1); tile t+1 sits in register set ((t+1) & 1) and is written
+    // to the other LDS buffer in the second half of iteration t; tile t+2 is loaded into register set
+    // (t & 1) in the first half of iteration t.  Global-load latency tolerance = 1.5 iterations.
+    // Tiles past the end are re-loaded from the last position and never used (no branches in the body).
+    const int it_last = it_end - 1;
     if (it_begin < it_end) {
-        load_tiles(it_begin);
-        advance();
-        store_tiles(smem);
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) load_A(0, i, it_begin);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_B(0, i, it_begin);
+        advance(it_begin + 1 < it_end ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) load_A(1, i, min(it_begin + 1, it_last));
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_B(1, i, min(it_begin + 1, it_last));
+        advance(it_begin + 2 < it_end ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) store_A(smem, 0, i);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) store_B(smem, 0, i);
     }
     __syncthreads();
 
-    for (int it = it_begin; it < it_end; ++it) {
-        const int cur = (it - it_begin) & 1;
-        const float* As = smem + cur * STAGE;
+    // one K-tile; P = parity of (it - it_begin) = LDS buffer of the current tile = register set to refill
+    auto body = [&](auto P, int it) {
+        constexpr int p_ = decltype(P)::value;
+        const float* As = smem + p_ * STAGE;
         const float* Bs = As + A_FLOATS;
-        const bool more = (it + 1 < it_end);
-        if (more) {
-            load_tiles(it + 1);
-            advance();
-        }
+        float* nxt = smem + (p_ ^ 1) * STAGE;
+        const int itn = min(it + 2, it_last);
+        float fa[2][2][4], fb[2][2][4];   // double-buffered LDS fragments
+        fetch(As, Bs, 0, fa[0], fb[0]);
 #pragma unroll
-        for (int kb = 0; kb < KT / 8; ++kb) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + l31;
-                if (!A_KM) {
-                    const f32x4 v = *(const f32x4*)(As + row * LDA + kb * 8 + 4 * lh);
-                    a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[i][j] = As[(kb * 8 + 4 * lh + j) * LDA + row];
-                }
-                const int col = wn * 64 + i * 32 + l31;
-                if (!B_KM) {
-                    const f32x4 v = *(const f32x4*)(Bs + col * LDB + kb * 8 + 4 * lh);
-                    b[i][0] = v[0]; b[i][1] = v[1]; b[i][2] = v[2]; b[i][3] = v[3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb * 8 + 4 * lh + j) * LDB + col];
-                }
+        for (int sc = 0; sc < SC; ++sc) {
+            const int g = sc >> 2, j = sc & 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if (sc >= ST0) {          // tile it+1: registers (set p^1) -> LDS; read before the refill below is issued
+                const int q = sc - ST0;
+                if (q < NVA) store_A(nxt, p_ ^ 1, q);
+                else store_B(nxt, p_ ^ 1, q - NVA);
             }
+            if (sc < NVA) load_A(p_, sc, itn);
+            else if (sc < NLD) load_B(p_, sc - NVA, itn);
+            if (j == 1 && g + 1 < NG) fetch(As, Bs, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < 2; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+                for (int jn = 0; jn < 2; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][j], fb[g & 1][jn][j], acc[i][jn], 0, 0, 0);
         }
-        if (more) store_tiles(smem + (cur ^ 1) * STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        advance(it + 3 < it_end ? 1 : 0);
         __syncthreads();
+    };
+    for (int it = it_begin; it < it_end; it += 2) {
+        body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < it_end) body(std::integral_constant<int, 1>{}, it + 1);
     }
 
     // ---- epilogue: acc[i][jn][r] -> row (r&3)+8*(r>>2)+4*lh, col l31 of the 32x32 sub-tile --------
