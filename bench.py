@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_512", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
     return ap.parse_args()
 
 
@@ -82,15 +83,16 @@ def roofline_pass(trainer, A, B, start_iter):
     from discogan_modernized_amd import ops
     ui = trainer.args.update_interval
     start_iter = (start_iter + ui - 1) // ui * ui            # align to a D-step
-    was_graph = trainer.use_graph
+    was_graph, was_two = trainer.use_graph, trainer.two_streams
     trainer.use_graph = False
+    trainer.two_streams = False          # isolated kernel durations: one stream, one kernel at a time
     ops.PROFILE = []
     for k in range(ui):
         trainer.train_iteration(A, B, start_iter + k)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     rec = [r for r in rec if r[0] != "head1"]   # K==1 head uses plain reduction kernels, not the MFMA family
-    trainer.use_graph = was_graph
+    trainer.use_graph, trainer.two_streams = was_graph, was_two
     flops = sum(r[1] for r in rec)
     ms = sum(r[2].elapsed_time(r[3]) for r in rec)
     by = {}
@@ -136,7 +138,7 @@ def main():
     dev = torch.device("cuda", local)
 
     trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
-                              use_graph=not a.no_graph)
+                              use_graph=not a.no_graph, two_streams=not a.single_stream)
     A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
     log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
     dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
@@ -161,7 +163,7 @@ def main():
     torch.cuda.empty_cache()
     if not a.no_512:
         tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
-                                use_graph=not a.no_graph)
+                                use_graph=not a.no_graph, two_streams=not a.single_stream)
         A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
         log("512px models built")
         dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)
@@ -186,7 +188,7 @@ def main():
                     config=dict(workload=f"edges2shoes discogan image_size={a.image_size} batch_size={a.batch_size} per GPU "
                                          f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped",
                                 global_batch=a.batch_size * world, parallelism=f"dp{world}",
-                                hipgraph=not a.no_graph),
+                                hipgraph=not a.no_graph, hip_streams=1 if a.single_stream else 2),
                     roofline=roof, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -40,7 +40,8 @@ SIGNATURES = {
     "dg_convT4x4_1to4_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "dg_convT4x4_1to4_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "dg_conv4x4s2_c3_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dg_c3_dgrad_workspace_bytes": (_z, [_i]),
+    "dg_conv4x4s2_c3_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_c3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dg_conv4x4s2_c3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_bn_workspace_bytes": (_z, [_i, _i]),

@@ -6,10 +6,11 @@
 //   c3_dgrad (K == 64): out[n,c,2a+ph,2b+pw] for a 2x2 output quad is a [9 neighbours x 64 k] . [576 x 12]
 //       product: M = quads, N = 12 (c,ph,pw) padded to 16, K = 576, on v_mfma_f32_16x16x4_f32.  The
 //       [576][16] weight image is structurally 4/9 dense (each output parity uses 2x2 of the 3x3
-//       neighbours) and is built once per workgroup in LDS from w[K][3][4][4].
-//   c3_wgrad: dw[64][48] = dy^T [64 x pixels] . im2col(x) [pixels x 48] on v_mfma_f32_32x32x2_f32; the four
-//       waves of a workgroup split each 32-pixel tile (intra-workgroup split-K), per-wave partial slabs
-//       are summed by a fixed-order reduction kernel (deterministic, no atomics).
+//       neighbours); it is built once per call into the workspace and copied to LDS by each workgroup;
+//       the next tile's dy rows are prefetched into registers under the current tile's MFMAs.
+//   c3_wgrad: dw[64][48] = dy^T [64 x pixels] . im2col(x) [pixels x 48] on v_mfma_f32_32x32x2_f32; every wave
+//       streams its own pixel range with operands loaded straight into MFMA registers (no LDS, no
+//       barriers); per-wave partial slabs are summed by a fixed-order reduction kernel (deterministic).
 #include "dg_common.h"
 
 // Taps per output parity (conv k4 s2 p1): p=0 -> (r=1, d=0), (r=3, d=-1);  p=1 -> (r=2, d=0), (r=0, d=+1).
@@ -86,7 +87,24 @@ __global__ __launch_bounds__(256) void c3_dgrad_valu_kernel(const float* __restr
 #define CD_LDP 66               // floats per staged pixel (64 + 2: conflict-free b32 A reads, 8-byte aligned rows)
 #define CD_NK (9 * CD_K)        // GEMM K = 576
 
-__global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+// weight image Wq[(nb, k)][col = c*4 + ph*2 + pw], built once per call into the workspace
+__global__ __launch_bounds__(256) void c3_wq_build_kernel(const float* __restrict__ w, float* __restrict__ wq) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= CD_NK * 16) return;
+    const int col = e & 15, row = e >> 4;
+    const int k = row & (CD_K - 1), nb = row >> 6;
+    const int da = nb / 3 - 1, db = nb % 3 - 1;
+    float v = 0.f;
+    if (col < 12) {
+        const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
+        const int r = tap_of(ph, da), s = tap_of(pw, db);
+        if (r >= 0 && s >= 0) v = w[(k * 3 + c) * 16 + r * 4 + s];
+    }
+    wq[e] = v;
+}
+
+#define CD_NV ((CD_PR * CD_PC * (CD_K / 4) + 255) / 256)   // float4 per thread per staged tile (7)
+__global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ wq,
                                                                float* __restrict__ dx, int N, int H, int W, int act,
                                                                int tiles_r, int tiles_c, int ntiles) {
     __shared__ __attribute__((aligned(16))) float WqS[CD_NK * 16];                 // [576][16]
@@ -94,38 +112,40 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
     __shared__ float outS[CD_TR][16 * 17];                                          // per wave [col][quad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ho = H >> 1, Wo = W >> 1;
+    for (int e = tid; e < CD_NK * 4; e += 256) *(f32x4*)(WqS + e * 4) = *(const f32x4*)(wq + e * 4);
 
-    // weight image: Wq[(nb, k)][col = c*4 + ph*2 + pw]
-    for (int e = tid; e < CD_NK * 16; e += 256) {
-        const int col = e & 15, row = e >> 4;
-        const int k = row & (CD_K - 1), nb = row >> 6;
-        const int da = nb / 3 - 1, db = nb % 3 - 1;
-        float v = 0.f;
-        if (col < 12) {
-            const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
-            const int r = tap_of(ph, da), s = tap_of(pw, db);
-            if (r >= 0 && s >= 0) v = w[(k * 3 + c) * 16 + r * 4 + s];
-        }
-        WqS[e] = v;
-    }
-
-    const int bq = lane & 15, kk = lane >> 4;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    f32x4 pre[CD_NV];
+    auto prefetch = [&](int t) {
         const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
         const int a0 = tr * CD_TR, b0 = tc * CD_TC;
-        __syncthreads();  // previous tile's readers of dyS/outS are done (also orders the WqS build)
-        for (int idx = tid; idx < CD_PR * CD_PC * (CD_K / 4); idx += 256) {
+#pragma unroll
+        for (int i = 0; i < CD_NV; ++i) {
+            const int idx = tid + i * 256;
             const int q4 = idx & (CD_K / 4 - 1), pix = idx >> 4;
             const int pr = pix / CD_PC, pc = pix - pr * CD_PC;
             const int a = a0 - 1 + pr, b = b0 - 1 + pc;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo)
-                v = *(const f32x4*)(dy + ((long)(n * Ho + a) * Wo + b) * CD_K + q4 * 4);
-            float* d = dyS + pix * CD_LDP + q4 * 4;
-            *(float2*)d = make_float2(v[0], v[1]);
-            *(float2*)(d + 2) = make_float2(v[2], v[3]);
+            const bool ok = idx < CD_PR * CD_PC * (CD_K / 4) && t < ntiles &&
+                            (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
+            pre[i] = ok ? *(const f32x4*)(dy + ((long)(n * Ho + a) * Wo + b) * CD_K + q4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int bq = lane & 15, kk = lane >> 4;
+    prefetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
+        const int a0 = tr * CD_TR, b0 = tc * CD_TC;
+        __syncthreads();  // previous tile's readers of dyS/outS are done (also orders the WqS copy)
+#pragma unroll
+        for (int i = 0; i < CD_NV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < CD_PR * CD_PC * (CD_K / 4)) {
+                float* d = dyS + (idx >> 4) * CD_LDP + (idx & (CD_K / 4 - 1)) * 4;
+                *(float2*)d = make_float2(pre[i][0], pre[i][1]);
+                *(float2*)(d + 2) = make_float2(pre[i][2], pre[i][3]);
+            }
         }
         __syncthreads();
+        prefetch(t + gridDim.x);   // next tile's HBM reads fly under this tile's MFMAs
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < 9; ++nb) {
@@ -156,8 +176,9 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
     }
 }
 
+extern "C" size_t dg_c3_dgrad_workspace_bytes(int K) { return K == CD_K ? (size_t)CD_NK * 16 * sizeof(float) : 0; }
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
-                                     int act, dg_stream_t stream) {
+                                     int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_nhwc && w && dx_nchw, "dg_conv4x4s2_c3_dgrad: null pointer");
     DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_dgrad: bad N/K (%d,%d)", N, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_dgrad: H,W must be powers of two");
@@ -169,8 +190,12 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
         const int tiles_r = (Ho + CD_TR - 1) / CD_TR, tiles_c = (Wo + CD_TC - 1) / CD_TC;
         const long ntiles = (long)N * tiles_r * tiles_c;
         DG_CHECK_ARG(ntiles < (1L << 31), "dg_conv4x4s2_c3_dgrad: too many tiles");
-        const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
-        hipLaunchKernelGGL(c3_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+        if (ws == nullptr || ws_bytes < dg_c3_dgrad_workspace_bytes(K))
+            return dg_fail(DG_ERR_WORKSPACE, "dg_conv4x4s2_c3_dgrad: workspace %zu < %zu", ws_bytes, dg_c3_dgrad_workspace_bytes(K));
+        hipLaunchKernelGGL(c3_wq_build_kernel, dim3((CD_NK * 16 + 255) / 256), dim3(256), 0, st, w, (float*)ws);
+        DG_CHECK_LAUNCH("c3_wq_build");
+        const int grid = (int)(ntiles < 512 ? ntiles : 512);
+        hipLaunchKernelGGL(c3_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, st, dy_nhwc, (const float*)ws, dx_nchw, N, H, W, act,
                            tiles_r, tiles_c, (int)ntiles);
         DG_CHECK_LAUNCH("c3_dgrad_mfma");
         return DG_OK;
@@ -184,18 +209,20 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
 
 // ---- weight gradient -------------------------------------------------------------------------------------
 // dw[k][c][r][s] (+)= sum_{pixels} dy[pix][k] * x[n,c,2oy-1+r,2ox-1+s]
-#define CW_PT 32     // pixels per LDS tile
-#define CW_LD 68     // 64 + 4 floats per staged row
+// Each wave streams its own pixels: the MFMA A operand dy^T[k][pixel] and the B operand
+// im2col(x)[pixel][j] are loaded straight into registers (A: 32 lanes read 32 consecutive k of one pixel
+// = 128 B; B: each lane owns a fixed (c,r,s) and gathers from the NCHW image), 8 k-steps (16 pixels) per
+// batch, two batches in flight.  No LDS, no barriers; masked lanes read a zero block.
+#define CW_B 8       // k-steps (of 2 pixels) per batch
+__device__ float dg_zero_edge[64];   // zero-initialised; masked lanes read [0] and [32] from here
 __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ part, int N, int H, int W, int K,
-                                                               int lgHo, int lgWo, long npix, int pix_per_block) {
-    __shared__ __attribute__((aligned(16))) float dyS[CW_PT * CW_LD];   // [pixel][k]   (A operand, k-major)
-    __shared__ __attribute__((aligned(16))) float pS[CW_PT * CW_LD];    // [pixel][j]   (B operand; j >= 48 stays 0)
+                                                               int lgHo, int lgWo, long npix, int pix_per_wave) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
     const int kg = blockIdx.y;
-    for (int e = tid; e < CW_PT * CW_LD; e += 256) pS[e] = 0.f;
+    const float* const zp = dg_zero_edge;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -203,56 +230,63 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const long p_begin = (long)blockIdx.x * pix_per_block;
-    const long p_end = min(npix, p_begin + pix_per_block);
-    const int drow = tid >> 4, dcq = tid & 15;          // dy tile: 32 rows x 16 float4, 2 per thread
-    const int gpl = tid & 31, gjb = tid >> 5;           // patch gather: pixel, j = gjb + 8*i
-    for (long p0 = p_begin; p0 < p_end; p0 += CW_PT) {
-        __syncthreads();
+    // this lane's two im2col columns j = l31, 32 + l31 (valid < 48): fixed (c, r, s)
+    int jr[2], js[2];
+    long joff[2];
+    bool jok[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = drow + 16 * i;
-            const long pp = p0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pp < p_end) v = *(const f32x4*)(dy + pp * K + kg * 64 + dcq * 4);
-            *(f32x4*)(dyS + row * CW_LD + dcq * 4) = v;
-        }
-        {
-            const long pp = p0 + gpl;
+    for (int jn = 0; jn < 2; ++jn) {
+        const int j = jn * 32 + l31;
+        jok[jn] = j < 48;
+        const int c = (j >> 4) % 3;
+        jr[jn] = (j >> 2) & 3;
+        js[jn] = j & 3;
+        joff[jn] = ((long)c * H + jr[jn]) * W + js[jn];
+    }
+    const long wave_id = (long)blockIdx.x * 4 + wave;
+    const long p_begin = wave_id * pix_per_wave;
+    const long p_end = min(npix, p_begin + pix_per_wave);
+    const float* dyk = dy + kg * 64 + l31;
+
+    float fa[2][CW_B][2], fb[2][CW_B][2];
+    auto load_batch = [&](int set, long p0) {
+#pragma unroll
+        for (int st = 0; st < CW_B; ++st) {
+            const long pp = p0 + 2 * st + lh;
             const bool pok = pp < p_end;
             const int ox = (int)(pp & (Wo - 1)), oy = (int)((pp >> lgWo) & (Ho - 1)), n = (int)(pp >> (lgWo + lgHo));
+            const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+            const long xb = ((long)n * 3 * H + iy0) * W + ix0;
+            const float* ap = pok ? dyk + pp * K : zp;
+            fa[set][st][0] = ap[0];
+            fa[set][st][1] = ap[32];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int j = gjb + 8 * i;
-                const int c = j >> 4, r = (j >> 2) & 3, s = j & 3;
-                const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + s;
-                float v = 0.f;
-                if (pok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    v = x[((long)(n * 3 + c) * H + iy) * W + ix];
-                pS[gpl * CW_LD + j] = v;
+            for (int jn = 0; jn < 2; ++jn) {
+                const bool ok = pok && jok[jn] && (unsigned)(iy0 + jr[jn]) < (unsigned)H && (unsigned)(ix0 + js[jn]) < (unsigned)W;
+                const float* bp = ok ? x + xb + joff[jn] : zp;
+                fb[set][st][jn] = *bp;
             }
         }
-        __syncthreads();
-        // intra-workgroup split-K: wave w owns pixels [8w, 8w+8) of the tile
+    };
+    auto mma_batch = [&](int set) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const int kkp = wave * 8 + s2 * 2 + lh;
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = dyS[kkp * CW_LD + i * 32 + l31];
-                b[i] = pS[kkp * CW_LD + i * 32 + l31];
-            }
+        for (int st = 0; st < CW_B; ++st)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
-        }
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][st][i], fb[set][st][jn], acc[i][jn], 0, 0, 0);
+    };
+    load_batch(0, p_begin);
+    for (long p0 = p_begin; p0 < p_end; p0 += 4 * CW_B) {
+        load_batch(1, p0 + 2 * CW_B);
+        mma_batch(0);
+        load_batch(0, p0 + 4 * CW_B);
+        mma_batch(1);
     }
-    // per-wave partial slab: part[(block*4 + wave)][K][48]
-    float* slab = part + ((long)(blockIdx.x * 4 + wave) * K + kg * 64) * 48;
+    // the 4 waves' accumulators are summed through LDS in a fixed order -> one slab per workgroup:
+    // part[block][K][48]
+    __shared__ float slabS[4][64 * 48];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -261,9 +295,12 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
                 const int j = jn * 32 + l31;
-                if (j < 48) slab[(long)k * 48 + j] = acc[i][jn][r];
+                if (j < 48) slabS[wave][k * 48 + j] = acc[i][jn][r];
             }
         }
+    __syncthreads();
+    float* slab = part + ((long)blockIdx.x * K + kg * 64) * 48;
+    for (int e = tid; e < 64 * 48; e += 256) slab[e] = ((slabS[0][e] + slabS[1][e]) + slabS[2][e]) + slabS[3][e];
 }
 
 // fixed-order reduction over slabs: block = 16 outputs x 16 slab lanes
@@ -285,18 +322,21 @@ __global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __res
     }
 }
 
-static void c3_wgrad_plan(long npix, int* nb, int* ppb) {
-    long per = (npix + 255) / 256;                       // aim for ~256 workgroups per 64-channel group
-    per = (per + CW_PT - 1) / CW_PT * CW_PT;
-    if (per < CW_PT) per = CW_PT;
-    *ppb = (int)per;
-    *nb = (int)((npix + per - 1) / per);
+// nb workgroups of 4 waves; every wave owns `ppw` consecutive pixels (multiple of one double batch)
+static void c3_wgrad_plan(long npix, int* nb, int* ppw) {
+    const int unit = 4 * CW_B;                           // pixels per loop trip
+    long per = (npix + 2047) / 2048;                     // aim for ~512 workgroups = 2048 waves
+    per = (per + unit - 1) / unit * unit;
+    if (per < unit) per = unit;
+    *ppw = (int)per;
+    const long nwaves = (npix + per - 1) / per;
+    *nb = (int)((nwaves + 3) / 4);
 }
 extern "C" size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K) {
     const long npix = (long)N * (H / 2) * (W / 2);
-    int nb, ppb;
-    c3_wgrad_plan(npix, &nb, &ppb);
-    return (size_t)nb * 4 * K * 48 * sizeof(float);
+    int nb, ppw;
+    c3_wgrad_plan(npix, &nb, &ppw);
+    return (size_t)nb * K * 48 * sizeof(float);
 }
 extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                                      int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
@@ -305,16 +345,16 @@ extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, 
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_wgrad: H,W must be powers of two");
     DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_wgrad: tensor too large");
     const long npix = (long)N * (H / 2) * (W / 2);
-    int nb, ppb;
-    c3_wgrad_plan(npix, &nb, &ppb);
-    const size_t need = (size_t)nb * 4 * K * 48 * sizeof(float);
+    int nb, ppw;
+    c3_wgrad_plan(npix, &nb, &ppw);
+    const size_t need = (size_t)nb * K * 48 * sizeof(float);
     if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "dg_conv4x4s2_c3_wgrad: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(c3_wgrad_mfma_kernel, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                       dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppb);
+                       dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw);
     DG_CHECK_LAUNCH("c3_wgrad_mfma");
     const int total = K * 48;
-    hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb * 4, total, accumulate);
+    hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);
     DG_CHECK_LAUNCH("c3_wgrad_reduce");
     return DG_OK;
 }

@@ -14,6 +14,16 @@ from torch.autograd import Function
 from . import ops
 
 
+def _flat_grad_of(param):
+    """The flat-buffer gradient view of a parameter (optim.Adam installs it) when it is the live .grad:
+    backward kernels then accumulate into it directly and autograd gets None for that input, instead of
+    materialising a gradient tensor and running an ATen add per parameter per pass."""
+    fg = getattr(param, "_dg_flat_grad", None)
+    if fg is not None and param.grad is fg:
+        return fg
+    return None
+
+
 class ConvFn(Function):
     """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
 
@@ -22,6 +32,7 @@ class ConvFn(Function):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
+        ctx.wref = w
         return ops.conv_fwd(x, w, stride, pad)
 
     @staticmethod
@@ -30,7 +41,13 @@ class ConvFn(Function):
         stride, pad = ctx.sp
         dy = ops.as_nhwc(dy)
         dx = ops.conv_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
-        dw = ops.conv_wgrad(dy, x, stride, pad) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            fg = _flat_grad_of(ctx.wref)
+            if fg is not None:
+                ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True)
+            else:
+                dw = ops.conv_wgrad(dy, x, stride, pad)
         return dx, dw, None, None
 
 
@@ -43,6 +60,7 @@ class ConvTransposeFn(Function):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
+        ctx.wref = w
         hin, win = x.shape[2], x.shape[3]
         hout, wout = (hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4
         ctx.out_hw = (hout, wout)
@@ -55,7 +73,13 @@ class ConvTransposeFn(Function):
         dy = ops.as_nhwc(dy)
         dx = ops.conv_fwd(dy, w, stride, pad) if ctx.needs_input_grad[0] else None
         # dw[cin][r][s][cout] = sum x[..cin] * dy[..cout]: conv wgrad with roles (dy := x, x := dy)
-        dw = ops.conv_wgrad(x, dy, stride, pad) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            fg = _flat_grad_of(ctx.wref)
+            if fg is not None:
+                ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True)
+            else:
+                dw = ops.conv_wgrad(x, dy, stride, pad)
         return dx, dw, None, None
 
 
@@ -68,6 +92,7 @@ class ConvC3Fn(Function):
         y = ops.c3_fwd(x, w, act, slope)
         ctx.save_for_backward(x, w, y)
         ctx.act = (act, slope)
+        ctx.wref = w
         return y
 
     @staticmethod
@@ -76,7 +101,13 @@ class ConvC3Fn(Function):
         act, slope = ctx.act
         g = ops.act_bwd(dy, y, act, slope) if act != ops.ACT_NONE else ops.as_nhwc(dy)
         dx = ops.c3_dgrad(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
-        dw = ops.c3_wgrad(g, x) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            fg = _flat_grad_of(ctx.wref)
+            if fg is not None and fg.is_contiguous():
+                ops.c3_wgrad(g, x, out=fg, accumulate=True)
+            else:
+                dw = ops.c3_wgrad(g, x)
         return dx, dw, None, None
 
 
@@ -89,6 +120,7 @@ class ConvTransposeC3Fn(Function):
         out = ops.c3_dgrad(x, w, act)
         ctx.save_for_backward(x, w, out)
         ctx.act = act
+        ctx.wref = w
         return out
 
     @staticmethod
@@ -96,7 +128,13 @@ class ConvTransposeC3Fn(Function):
         x, w, out = ctx.saved_tensors
         g = ops.act_bwd(dout, out, ctx.act) if ctx.act != ops.ACT_NONE else dout.contiguous()
         dx = ops.c3_fwd(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
-        dw = ops.c3_wgrad(x, g) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            fg = _flat_grad_of(ctx.wref)
+            if fg is not None and fg.is_contiguous():
+                ops.c3_wgrad(x, g, out=fg, accumulate=True)
+            else:
+                dw = ops.c3_wgrad(x, g)
         return dx, dw, None
 
 
@@ -114,6 +152,7 @@ class BatchNormActFn(Function):
         z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope)
         ctx.save_for_backward(y, saved, gamma, beta)
         ctx.cfg = (act, slope, training)
+        ctx.prefs = (gamma, beta)
         return z
 
     @staticmethod
@@ -123,6 +162,10 @@ class BatchNormActFn(Function):
         if not training:
             raise RuntimeError("BatchNormActFn: backward in eval mode is not supported")
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        fg, fb = _flat_grad_of(ctx.prefs[0]), _flat_grad_of(ctx.prefs[1])
+        if need_p and fg is not None and fb is not None:
+            dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb))
+            return (dy,) + (None,) * 10
         dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 None, None, None, None, None, None, None, None)

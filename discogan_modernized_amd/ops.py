@@ -193,23 +193,25 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     w = w.contiguous()
     n, k, ho, wo = dy.shape
     dx = torch.empty((n, 3, 2 * ho, 2 * wo), device=dy.device, dtype=torch.float32)
-    _lib.check(_lib.load().dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _stream()),
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_c3_dgrad_workspace_bytes(k), dy.device)
+    _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb, _stream()),
                "dg_conv4x4s2_c3_dgrad")
     return dx
 
 
-def c3_wgrad(dy, x_nchw):
+def c3_wgrad(dy, x_nchw, out=None, accumulate=False):
     """dw [K,3,4,4] contiguous from dy NHWC-memory [N,K,Ho,Wo] and x NCHW [N,3,H,W]."""
     _check_dev(dy, x_nchw)
     dy = as_nhwc(dy)
     x = x_nchw.contiguous()
     n, k, ho, wo = dy.shape
     h, wd = x.shape[2], x.shape[3]
-    dw = torch.empty((k, 3, 4, 4), device=dy.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((k, 3, 4, 4), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_wgrad_workspace_bytes(n, h, wd, k), dy.device)
-    _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, 0, _ptr(ws), wsb, _stream()),
-               "dg_conv4x4s2_c3_wgrad")
+    _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, int(accumulate), _ptr(ws), wsb,
+                                       _stream()), "dg_conv4x4s2_c3_wgrad")
     return dw
 
 
@@ -236,18 +238,24 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     return z
 
 
-def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True):
+def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None):
+    """out_grads=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into those buffers in place."""
     dz = as_nhwc(dz)
     y = as_nhwc(y)
     n, c, h, w = y.shape
     m = n * h * w
     dy = empty_nhwc(n, c, h, w, y.device)
-    dgamma = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
-    dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
+    acc = 0
+    if out_grads is not None:
+        dgamma, dbeta = out_grads
+        acc = 1
+    else:
+        dgamma = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
+        dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
     _lib.check(L.dg_bn_act_bwd(_ptr(dz), _ptr(y), _ptr(dy), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act, slope,
-                               _ptr(dgamma), _ptr(dbeta), 0, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
+                               _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
     return dy, dgamma, dbeta
 
 

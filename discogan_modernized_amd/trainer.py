@@ -17,6 +17,7 @@ Differences that do not change any result:
 """
 from __future__ import annotations
 
+import contextlib
 from itertools import chain
 from types import SimpleNamespace
 
@@ -42,7 +43,7 @@ def default_args(**over):
 
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
-                 use_graph=False, skip_dead_work=True):
+                 use_graph=False, skip_dead_work=True, two_streams=True):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -72,7 +73,12 @@ class DiscoGANTrainer:
                                     lr=a.learning_rate, betas=(a.beta1, a.beta2), weight_decay=a.weight_decay)
         self._graphs = {}
         self._static = None
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.world_size > 1 else None
+        # The A-side chain (G_A, D_A) runs on a second HIP stream next to the B-side chain (G_B, D_B):
+        # the two are independent except for two hand-overs (AB -> G_A, BA -> G_B), so prologues and
+        # tails of one chain's kernels overlap the other chain's kernels.  Every network stays on ONE
+        # stream, which keeps its two calls per iteration (and its BN running-stat updates) ordered.
+        self.two_streams = two_streams
+        self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
 
     # ---------------------------------------------------------------------------------------------
     def is_dis_step(self, iters):
@@ -93,22 +99,41 @@ class DiscoGANTrainer:
         a = self.args
         dstep = self.is_dis_step(iters)
         skip = self.skip_dead_work
-        gen_ctx = torch.no_grad() if (skip and dstep) else torch.enable_grad()
-        with gen_ctx:
-            AB = self.generator_B(A)
-            BA = self.generator_A(B)
-            ABA = self.generator_A(AB)
+        gen_ctx = torch.no_grad if (skip and dstep) else torch.enable_grad
+        main = torch.cuda.current_stream(self.device)
+        side = self.side_stream if self.two_streams else main
+        on_side = (lambda: torch.cuda.stream(side)) if self.two_streams else contextlib.nullcontext
+        if self.two_streams:
+            side.wait_stream(main)
+        # stage 1: the two first-stage translations are independent
+        with gen_ctx():
+            with on_side():
+                BA = self.generator_A(B)                     # side: G_A
+            AB = self.generator_B(A)                         # main: G_B
+        if self.two_streams:
+            ev_ab, ev_ba = torch.cuda.Event(), torch.cuda.Event()
+            ev_ab.record(main)
+            ev_ba.record(side)
+            side.wait_event(ev_ab)                           # G_A(AB) needs AB
+            main.wait_event(ev_ba)                           # G_B(BA) needs BA
+        # stage 2 + discriminators: A-side chain on `side`, B-side chain on `main`
+        with on_side():
+            with gen_ctx():
+                ABA = self.generator_A(AB)
+                recon_loss_A = self.recon_criterion(ABA, A)
+            A_dis_real, A_feats_real = self.discriminator_A(A)
+            A_dis_fake, A_feats_fake = self.discriminator_A(BA)
+            dis_loss_A, gen_loss_A = L.get_gan_loss(A_dis_real, A_dis_fake, self.gan_criterion, self.device)
+            fm_loss_A = L.get_fm_loss(A_feats_real, A_feats_fake, self.feat_criterion, self.device)
+        with gen_ctx():
             BAB = self.generator_B(BA)
-            recon_loss_A = self.recon_criterion(ABA, A)
             recon_loss_B = self.recon_criterion(BAB, B)
-        A_dis_real, A_feats_real = self.discriminator_A(A)
-        A_dis_fake, A_feats_fake = self.discriminator_A(BA)
-        dis_loss_A, gen_loss_A = L.get_gan_loss(A_dis_real, A_dis_fake, self.gan_criterion, self.device)
-        fm_loss_A = L.get_fm_loss(A_feats_real, A_feats_fake, self.feat_criterion, self.device)
         B_dis_real, B_feats_real = self.discriminator_B(B)
         B_dis_fake, B_feats_fake = self.discriminator_B(AB)
         dis_loss_B, gen_loss_B = L.get_gan_loss(B_dis_real, B_dis_fake, self.gan_criterion, self.device)
         fm_loss_B = L.get_fm_loss(B_feats_real, B_feats_fake, self.feat_criterion, self.device)
+        if self.two_streams:
+            main.wait_stream(side)
         rate = self.rate(iters)
         gen_loss_A_total = (fm_loss_B * 0.9 + gen_loss_B * 0.1) * (1 - rate) + recon_loss_A * rate
         gen_loss_B_total = (fm_loss_A * 0.9 + gen_loss_A * 0.1) * (1 - rate) + recon_loss_B * rate
@@ -137,6 +162,10 @@ class DiscoGANTrainer:
         self.optim_dis.zero_grad()
         out = self.forward_losses(A, B, iters)
         (out.dis_loss if dstep else out.gen_loss).backward()
+        if self.two_streams:
+            # the backward kernels of the A-side chain ran on the side stream and wrote the flat gradient
+            # buffer directly (no AccumulateGrad leaf for autograd to sync): join before Adam / all-reduce
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         return out
 
     def _graph_key(self, iters):

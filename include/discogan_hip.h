@@ -108,8 +108,9 @@ int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw, int N, in
  */
 int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
                         int act, float slope, dg_stream_t s);
+size_t dg_c3_dgrad_workspace_bytes(int K);
 int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
-                          int act, dg_stream_t s);
+                          int act, void* ws, size_t ws_bytes, dg_stream_t s);
 size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K);
 int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
