@@ -87,6 +87,12 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # tuning knobs from the environment, e.g. DG_OPT_KT=16 DG_OPT_SPLITK=1 (benchmarking aid)
+    for key, val in os.environ.items():
+        if key.startswith("DG_OPT_"):
+            rc = lib.dg_set_option(key[7:].lower().encode(), int(val))
+            if rc != 0:
+                raise DiscoganHipError(f"bad option {key}: " + lib.dg_last_error().decode())
     return lib
 
 

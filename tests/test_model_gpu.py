@@ -305,6 +305,19 @@ def test_graph_replay_equals_eager():
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_two_streams_equal_single_stream():
+    """Overlapping the A-side and B-side chains on two HIP streams must not change any value."""
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for two in (False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234, two_streams=two)
+        vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(6)]
+        torch.cuda.synchronize()
+        res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_skipping_dead_work_changes_nothing():
     A, B = synthetic_batch(4, 16, 0, DEV)
     res = []
