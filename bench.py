@@ -83,6 +83,7 @@ def timed_run(trainer, A, B, steps, warmup, world, start_iter=0):
     for _ in range(steps):
         trainer.train_iteration(A, B, it)
         it += 1
+    trainer.finish()
     barrier_sync(world)
     dt = time.perf_counter() - t0
     if world > 1:

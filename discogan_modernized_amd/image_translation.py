@@ -88,6 +88,7 @@ def run_dirs(args, rank_suffix=""):
 
 
 def save_models(trainer, model_path, tag):
+    trainer.finish()                      # join the communication stream before reading parameters
     names = dict(gen_A=trainer.generator_A, gen_B=trainer.generator_B,
                  dis_A=trainer.discriminator_A, dis_B=trainer.discriminator_B)
     for k, net in names.items():

@@ -318,6 +318,22 @@ def test_two_streams_equal_single_stream():
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_comm_stream_overlap_path_is_bitwise_neutral():
+    """The DP overlap path (D-step all-reduce + Adam on a communication stream, overlapped with the next
+    iteration's generator passes) exercised at world size 1: identical results to the plain path."""
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for overlap in (False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234, overlap_comm=overlap)
+        assert tr.overlap_comm == overlap
+        vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(9)]
+        tr.finish()
+        torch.cuda.synchronize()
+        res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_skipping_dead_work_changes_nothing():
     A, B = synthetic_batch(4, 16, 0, DEV)
     res = []
