@@ -48,6 +48,10 @@ struct IgemmArgs {
     int accumulate;
     int act;      // FWD_C3 only: fused activation on the output
     float slope;
+    // fused BatchNorm statistics (FWD / DGRAD_S2): per-tile partial rows [P][3*Ng + 4] =
+    // {count, -, -, -, shift[Ng], sum(y - shift)[Ng], sum((y - shift)^2)[Ng]}; nullptr = off
+    float* stat;
+    int stat_rs;
 };
 
 #define NEG_BIG (-(1 << 28))
@@ -345,6 +349,42 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         if (it + 1 < it_end) body(std::integral_constant<int, 1>{}, it + 1);
     }
 
+    // ---- fused BatchNorm statistics: one partial row per (tile, wave row), shifted by the wave tile's
+    //      first row so that sum/sumsq never cancel catastrophically; merged by bn_partials_finalize.
+    if ((MODE == MODE_FWD || MODE == MODE_DGRAD_S2) && p.stat != nullptr && p.part == nullptr) {
+        const int row0 = m0 + wm * 64;
+        const int nrows = min(64, p.M - row0);
+        const int prow = ((MODE == MODE_DGRAD_S2 ? parity : 0) * p.tilesM + tm) * WM + wm;
+        float* srow = p.stat + (long)prow * p.stat_rs;
+        if (wn == 0 && tn == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
+        if (nrows > 0) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const float sh = __shfl(acc[0][jn][0], l31, 64);
+                float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (lr < nrows) {
+                            const float d = acc[i][jn][r] - sh;
+                            ssum += d;
+                            ssq += d * d;
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                const int n = n0 + wn * 64 + jn * 32 + l31;
+                if (lh == 0 && n < p.Ng) {
+                    srow[4 + n] = sh;
+                    srow[4 + p.Ng + n] = ssum;
+                    srow[4 + 2 * p.Ng + n] = ssq;
+                }
+            }
+        }
+    }
+
     // ---- epilogue: acc[i][jn][r] -> row (r&3)+8*(r>>2)+4*lh, col l31 of the 32x32 sub-tile --------
     const bool to_part = p.part != nullptr;
 #pragma unroll
@@ -400,6 +440,61 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
         }
         if (p.accumulate) s += *(const f32x4*)dst;
         *(f32x4*)dst = s;
+    }
+}
+
+// Split-K reduction that also emits the BatchNorm partial rows: block = 32 float4 columns x 8 row lanes,
+// grid = (column chunks of 128, row chunks); one partial row per row chunk.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArgs p, int rchunks) {
+    __shared__ f32x4 red[2][8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + tx) * 4;
+    const long R = (long)(MODE == MODE_DGRAD_S2 ? 4 : 1) * p.M;
+    const long slab = R * p.Ng;
+    const long rows_per = (R + rchunks - 1) / rchunks;
+    const long r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    const bool cok = c < p.Ng;
+    if (cok && r0 < r1) {
+        const float* src = p.part + r0 * p.Ng + c;
+        sh = *(const f32x4*)src;
+        for (int k = 1; k < p.splits; ++k) sh += *(const f32x4*)(src + k * slab);
+        for (long row = r0 + ty; row < r1; row += 8) {
+            const float* sp = p.part + row * p.Ng + c;
+            f32x4 v = *(const f32x4*)sp;
+            for (int k = 1; k < p.splits; ++k) v += *(const f32x4*)(sp + k * slab);
+            float* dst;
+            if (MODE == MODE_DGRAD_S2) {
+                const int parity = (int)(row / p.M);
+                const int m = (int)(row - (long)parity * p.M);
+                const int b = m & (p.Wo - 1), a = (m >> p.lgWo) & (p.Ho - 1), n = m >> (p.lgWo + p.lgHo);
+                dst = p.C + (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c;
+            } else {
+                dst = p.C + row * p.Ng + c;
+            }
+            *(f32x4*)dst = v;
+            const f32x4 d = v - sh;
+            s += d;
+            q += d * d;
+        }
+    }
+    red[0][ty][tx] = s;
+    red[1][ty][tx] = q;
+    __syncthreads();
+    if (ty == 0) {
+        float* srow = p.stat + (long)blockIdx.y * p.stat_rs;
+        if (blockIdx.x == 0 && tx == 0) srow[0] = (float)max(0L, r1 - r0);
+        if (cok && r0 < r1) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                s += red[0][j][tx];
+                q += red[1][j][tx];
+            }
+            *(f32x4*)(srow + 4 + c) = sh;
+            *(f32x4*)(srow + 4 + p.Ng + c) = s;
+            *(f32x4*)(srow + 4 + 2 * p.Ng + c) = q;
+        }
     }
 }
 
@@ -464,7 +559,18 @@ struct Plan {
     int mode, wm, wn, kt;
     IgemmArgs a;
     size_t ws_bytes;
+    int stat_rows;   // partial rows the fused BatchNorm statistics would produce (0: not supported)
 };
+
+static int reduce_stats_rchunks(long R, int Ng) {
+    const int cch = (Ng + 127) / 128;
+    long rc = 1024 / cch;
+    if (rc > 256) rc = 256;
+    const long maxrc = (R + 7) / 8;
+    if (rc > maxrc) rc = maxrc;
+    if (rc < 1) rc = 1;
+    return (int)rc;
+}
 
 static int choose_splits(int base_wgs, int nIt) {
     int forced = dg_get_option(DG_OPT_SPLITK);
@@ -518,6 +624,9 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
     pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
+    pl->stat_rows = 0;
+    if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)
+        pl->stat_rows = a.splits > 1 ? reduce_stats_rchunks((long)zmul * a.M, a.Ng) : zmul * a.tilesM * pl->wm;
 }
 
 template <int MODE, int WM, int WN, int KT>
@@ -548,7 +657,13 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         default: return dg_fail(DG_ERR_INVALID, "%s: no kernel for mode %d wm %d kt %d", who, pl.mode, pl.wm, pl.kt);
     }
     DG_CHECK_LAUNCH(who);
-    if (a.splits > 1) {
+    if (a.splits > 1 && a.stat != nullptr) {
+        const int rc = pl.stat_rows;
+        dim3 grid((a.Ng + 127) / 128, rc);
+        if (pl.mode == MODE_DGRAD_S2) hipLaunchKernelGGL(splitk_reduce_stats_kernel<MODE_DGRAD_S2>, grid, dim3(256), 0, st, a, rc);
+        else hipLaunchKernelGGL(splitk_reduce_stats_kernel<MODE_FWD>, grid, dim3(256), 0, st, a, rc);
+        DG_CHECK_LAUNCH("splitk_reduce_stats");
+    } else if (a.splits > 1) {
         const long total4 = (long)zmul * a.M * a.Ng / 4;
         int grid = (int)((total4 + 255) / 256);
         if (grid > 4096) grid = 4096;
@@ -631,6 +746,40 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
     make_plan(2, g, &pl);
     pl.a.A = dy; pl.a.B = x; pl.a.C = dw; pl.a.accumulate = accumulate;
     return run_plan("dg_conv_wgrad", pl, ws, ws_bytes, st);
+}
+
+// ---- conv + fused BatchNorm partial statistics -------------------------------------------------------
+extern "C" int dg_conv_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (check_geom("dg_conv_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK) return 0;
+    if (K == 1 || stride != 2 || (op != 0 && op != 1)) return 0;
+    Plan pl;
+    make_plan(op, g, &pl);
+    return pl.stat_rows;
+}
+static int conv_with_stats(int op, const float* a_in, const float* w, float* out, int N, int H, int W, int C, int K,
+                           float* stat, size_t stat_floats, void* ws, size_t ws_bytes, hipStream_t st) {
+    const char* who = op == 0 ? "dg_conv_fwd_bnstats" : "dg_conv_dgrad_bnstats";
+    ConvGeom g;
+    int rc = check_geom(who, N, H, W, C, K, 2, 1, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(a_in && w && out && stat, "%s: null pointer", who);
+    DG_CHECK_ARG(K % 32 == 0 && C % 32 == 0, "%s: C and K must be multiples of 32", who);
+    Plan pl;
+    make_plan(op, g, &pl);
+    const int ncols = op == 0 ? K : C;
+    DG_CHECK_ARG(pl.stat_rows > 0 && stat_floats >= (size_t)pl.stat_rows * (3 * ncols + 4), "%s: statistics buffer too small", who);
+    pl.a.A = a_in; pl.a.B = w; pl.a.C = out;
+    pl.a.stat = stat; pl.a.stat_rs = 3 * ncols + 4;
+    return run_plan(who, pl, ws, ws_bytes, st);
+}
+extern "C" int dg_conv_fwd_bnstats(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                                   float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_with_stats(0, x, w, y, N, H, W, C, K, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_dgrad_bnstats(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                                     float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_with_stats(1, dy, w, dx, N, H, W, C, K, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---- named wrappers --------------------------------------------------------------

@@ -108,6 +108,54 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     }
 }
 
+// Finalize from the conv kernels' partial rows [P][3C+4] = {count,-,-,-, shift[C], sum[C], sumsq[C]}.
+// Every partial is re-referenced to ONE global shift G (the first row's shift, itself a sample of the
+// channel):  sum(y-G) = s_p + n_p*d,  sum((y-G)^2) = q_p + 2*d*s_p + n_p*d^2  with d = shift_p - G, all in
+// fp64 FMAs (no divisions in the loop); block = 4 channels x 64 lanes, lanes combined in a fixed order.
+__global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* __restrict__ stat, int P, int rs, int M, int C,
+                                                                  float eps, float momentum, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                  float* __restrict__ saved) {
+    __shared__ double red[2][64][4];
+    const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    double S = 0.0, Q = 0.0;
+    double G = 0.0;
+    if (c < C) {
+        G = (double)stat[4 + c];                    // row 0 always has count > 0
+        for (int p = pl; p < P; p += 64) {
+            const float* row = stat + (long)p * rs;
+            const double np = (double)row[0];
+            const double s = (double)row[4 + C + c], q = (double)row[4 + 2 * C + c];
+            const double d = (double)row[4 + c] - G;
+            if (np > 0.0) {
+                S += s + np * d;
+                Q += q + d * (2.0 * s + np * d);
+            }
+        }
+    }
+    red[0][pl][cl] = S;
+    red[1][pl][cl] = Q;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    for (int j = 1; j < 64; ++j) {
+        S += red[0][j][cl];
+        Q += red[1][j][cl];
+    }
+    if (c == 0 && nbt) nbt[0] += 1;
+    const double dm = S / M;
+    const double mean = G + dm;
+    double var = Q / M - dm * dm;
+    if (var < 0.0) var = 0.0;
+    saved[c] = (float)mean;
+    saved[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, long total4,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -298,6 +346,18 @@ extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float 
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
                        momentum, running_mean, running_var, nbt, saved);
     DG_CHECK_LAUNCH("bn_stats_finalize");
+    return DG_OK;
+}
+
+extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C, float eps, float momentum,
+                                         float* running_mean, float* running_var, int64_t* nbt, float* saved,
+                                         dg_stream_t stream) {
+    DG_CHECK_ARG(stat && saved && P >= 1, "dg_bn_stats_from_partials: bad argument");
+    DG_CHECK_ARG(M >= 2, "dg_bn_stats_from_partials: Expected more than 1 value per channel when training (M=%d)", M);
+    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_stats_from_partials: C=%d must be a multiple of 4", C);
+    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stat, P, 3 * C + 4,
+                       M, C, eps, momentum, running_mean, running_var, nbt, saved);
+    DG_CHECK_LAUNCH("bn_partials_finalize");
     return DG_OK;
 }
 

@@ -28,15 +28,21 @@ class ConvFn(Function):
     """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, want_stats=False):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
         ctx.wref = w
-        return ops.conv_fwd(x, w, stride, pad)
+        if not want_stats:
+            return ops.conv_fwd(x, w, stride, pad)
+        y, stat = ops.conv_fwd(x, w, stride, pad, want_stats=True)
+        if stat is None:
+            stat = torch.empty(0, device=y.device)
+        ctx.mark_non_differentiable(stat)
+        return y, stat
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dstat=None):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
         dy = ops.as_nhwc(dy)
@@ -48,7 +54,7 @@ class ConvFn(Function):
                 ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True)
             else:
                 dw = ops.conv_wgrad(dy, x, stride, pad)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class ConvTransposeFn(Function):
@@ -56,7 +62,7 @@ class ConvTransposeFn(Function):
     same weight tensor."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, want_stats=False):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
@@ -64,10 +70,16 @@ class ConvTransposeFn(Function):
         hin, win = x.shape[2], x.shape[3]
         hout, wout = (hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4
         ctx.out_hw = (hout, wout)
-        return ops.conv_dgrad(x, w, (hout, wout), stride, pad)
+        if not want_stats:
+            return ops.conv_dgrad(x, w, (hout, wout), stride, pad)
+        y, stat = ops.conv_dgrad(x, w, (hout, wout), stride, pad, want_stats=True)
+        if stat is None:
+            stat = torch.empty(0, device=y.device)
+        ctx.mark_non_differentiable(stat)
+        return y, stat
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dstat=None):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
         dy = ops.as_nhwc(dy)
@@ -80,7 +92,7 @@ class ConvTransposeFn(Function):
                 ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True)
             else:
                 dw = ops.conv_wgrad(x, dy, stride, pad)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class ConvC3Fn(Function):
@@ -143,9 +155,13 @@ class BatchNormActFn(Function):
     the kernel exactly like PyTorch (momentum 0.1, unbiased running_var, num_batches_tracked += 1)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope,
+                partials=None):
         y = ops.as_nhwc(y)
-        if training:
+        if training and partials is not None and partials.numel() > 0:
+            # statistics came out of the producing conv kernel's epilogue: no extra pass over y
+            saved = ops.bn_stats_from_partials(partials, y, running_mean, running_var, nbt, eps, momentum)
+        elif training:
             saved = ops.bn_train_stats(y, running_mean, running_var, nbt, eps, momentum)
         else:
             saved = torch.stack([running_mean, torch.rsqrt(running_var + eps)])
@@ -165,10 +181,10 @@ class BatchNormActFn(Function):
         fg, fb = _flat_grad_of(ctx.prefs[0]), _flat_grad_of(ctx.prefs[1])
         if need_p and fg is not None and fb is not None:
             dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb))
-            return (dy,) + (None,) * 10
+            return (dy,) + (None,) * 11
         dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class ActFn(Function):

@@ -22,6 +22,13 @@ from . import functional as F
 from . import ops
 
 
+# BatchNorm statistics can come out of the producing conv kernel's epilogue (dg_conv_*_bnstats) instead of a
+# separate read pass.  Measured on MI355X (round 1): with the two-stream schedule the separate HBM-bound
+# statistics pass overlaps the other chain's MFMA kernels for free, while the fused form lengthens the
+# MFMA kernels' tails: 15.21 vs 14.95 ms/step at 64 px / batch 256, 182.5 vs 182.9 at 512 px.  Off by default.
+FUSE_BN_STATS = False
+
+
 def stage_channels(image_size: int):
     n = int(round(math.log2(image_size))) - 2
     if n < 1 or 2 ** (n + 2) != image_size:
@@ -68,10 +75,17 @@ class Conv2d(nn.Module):
             w = ops.krsc_param(w)  # memory [K][4][4][C], logical shape unchanged
         self.weight = nn.Parameter(w)
 
-    def forward(self, x, fused_act=ops.ACT_NONE, slope=0.2):
+    def forward(self, x, fused_act=ops.ACT_NONE, slope=0.2, want_stats=False):
+        """want_stats (interior stride-2 layers): returns (y, BatchNorm partial statistics of y)."""
         if self.in_channels == 3:
             return F.ConvC3Fn.apply(x, self.weight, fused_act, slope)
+        if want_stats:
+            return F.ConvFn.apply(x, self.weight, self.stride, self.padding, True)
         return F.ConvFn.apply(x, self.weight, self.stride, self.padding)
+
+    @property
+    def emits_bn_stats(self):
+        return self.in_channels != 3 and self.stride == 2
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size=(4, 4), stride={self.stride}, padding={self.padding}, bias=False"
@@ -91,10 +105,16 @@ class ConvTranspose2d(nn.Module):
             w = ops.krsc_param(w)  # memory [Cin][4][4][Cout]
         self.weight = nn.Parameter(w)
 
-    def forward(self, x, fused_act=ops.ACT_NONE):
+    def forward(self, x, fused_act=ops.ACT_NONE, want_stats=False):
         if self.out_channels == 3:
             return F.ConvTransposeC3Fn.apply(x, self.weight, fused_act)
+        if want_stats:
+            return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding, True)
         return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding)
+
+    @property
+    def emits_bn_stats(self):
+        return self.out_channels != 3 and self.stride == 2
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size=(4, 4), stride={self.stride}, padding={self.padding}, bias=False"
@@ -112,11 +132,12 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2):
+    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2, partials=None):
         if self.training and y.shape[0] * y.shape[2] * y.shape[3] <= 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
         return F.BatchNormActFn.apply(y, self.weight, self.bias, self.running_mean, self.running_var,
-                                      self.num_batches_tracked, self.training, self.eps, self.momentum, fused_act, slope)
+                                      self.num_batches_tracked, self.training, self.eps, self.momentum, fused_act, slope,
+                                      partials)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine=True, track_running_stats=True"
@@ -164,7 +185,10 @@ def _run_fused(layers, x):
         act_mod = layers[j] if j < n and isinstance(layers[j], _Act) else None
         act = act_mod.act if act_mod is not None else ops.ACT_NONE
         slope = act_mod.negative_slope if act_mod is not None else 0.0
-        if bn is not None:
+        if bn is not None and bn.training and FUSE_BN_STATS and conv.emits_bn_stats:
+            y, st = conv(x, want_stats=True)                # BN statistics from the conv kernel's epilogue
+            x = bn(y, act, slope, st)
+        elif bn is not None:
             x = bn(conv(x), act, slope)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
             x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
@@ -199,8 +223,12 @@ class Discriminator(_FlatGradMixin, nn.Module):
         feats = []
         h = self.conv1(input_tensor, ops.ACT_LEAKY, self.relu1.negative_slope)
         for i in range(2, self.n_stages + 1):
-            relu = getattr(self, f"relu{i}")
-            h = getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h), ops.ACT_LEAKY, relu.negative_slope)
+            relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
+            if bn.training and FUSE_BN_STATS:
+                y, st = conv(h, want_stats=True)            # BN statistics from the conv kernel's epilogue
+                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
+            else:
+                h = bn(conv(h), ops.ACT_LEAKY, relu.negative_slope)
             feats.append(h)
         out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))
         return out, feats

@@ -121,8 +121,9 @@ def _out_hw(h, w, stride, pad):
     return (h + 2 * pad - 4) // stride + 1, (w + 2 * pad - 4) // stride + 1
 
 
-def conv_fwd(x, w, stride, pad):
-    """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC."""
+def conv_fwd(x, w, stride, pad, want_stats=False):
+    """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC.
+    want_stats: also return the BatchNorm partial-statistics rows of y (None if the layer has no fused path)."""
     _check_dev(x, w)
     x = as_nhwc(x)
     w = _krsc(w)
@@ -132,14 +133,22 @@ def conv_fwd(x, w, stride, pad):
     y = empty_nhwc(n, k, ho, wo, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
+    rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
-        _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                   "dg_conv_fwd")
-    return y
+        if rows > 0:
+            stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
+            _lib.check(L.dg_conv_fwd_bnstats(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, _ptr(stat), stat.numel(),
+                                             _ptr(ws), wsb, _stream()), "dg_conv_fwd_bnstats")
+        else:
+            stat = None
+            _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                       "dg_conv_fwd")
+    return (y, stat) if want_stats else y
 
 
-def conv_dgrad(dy, w, x_hw, stride, pad):
-    """Input-gradient of that Conv2d == ConvTranspose2d forward. dy [N,K,Ho,Wo]; returns [N,C,H,W]."""
+def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
+    """Input-gradient of that Conv2d == ConvTranspose2d forward. dy [N,K,Ho,Wo]; returns [N,C,H,W]
+    (and, with want_stats, the BatchNorm partial-statistics rows of the result or None)."""
     _check_dev(dy, w)
     dy = as_nhwc(dy)
     w = _krsc(w)
@@ -149,10 +158,17 @@ def conv_dgrad(dy, w, x_hw, stride, pad):
     dx = empty_nhwc(n, c, h, wd, dy.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
+    rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-        _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                   "dg_conv_dgrad")
-    return dx
+        if rows > 0:
+            stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)
+            _lib.check(L.dg_conv_dgrad_bnstats(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, _ptr(stat), stat.numel(),
+                                               _ptr(ws), wsb, _stream()), "dg_conv_dgrad_bnstats")
+        else:
+            stat = None
+            _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb,
+                                       _stream()), "dg_conv_dgrad")
+    return (dx, stat) if want_stats else dx
 
 
 def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
@@ -226,6 +242,16 @@ def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
     _lib.check(L.dg_bn_train_stats(_ptr(y), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
                                    _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
+    return saved
+
+
+def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentum):
+    """Same result as bn_train_stats(y, ...) from the partial rows a conv kernel emitted for y."""
+    n, c, h, w = y.shape
+    saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_bn_stats_from_partials(_ptr(stat), stat.shape[0], n * h * w, c, eps, momentum,
+                                                     _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
+                                                     _stream()), "dg_bn_stats_from_partials")
     return saved
 
 

@@ -69,6 +69,16 @@ int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int 
 int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 
+/* Stride-2 conv forward / dgrad (= ConvTranspose2d forward) that ALSO emit BatchNorm partial statistics
+ * of the output from the kernel epilogue (or from the split-K reduction), saving the separate read
+ * pass of dg_bn_train_stats.  stat: [rows][3*cols + 4] floats with rows = dg_conv_bnstats_rows(op,...)
+ * and cols = K (op 0, fwd) or C (op 1, dgrad); consume with dg_bn_stats_from_partials. */
+int dg_conv_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad);
+int dg_conv_fwd_bnstats(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
+                        float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad_bnstats(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
+                          float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
+
 /* named wrappers; H,W always name the LARGER spatial side of the layer */
 int dg_conv4x4s2_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
                      void* ws, size_t ws_bytes, dg_stream_t s);
@@ -125,6 +135,10 @@ size_t dg_bn_workspace_bytes(int M, int C);
 int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* saved, void* ws, size_t ws_bytes, dg_stream_t s);
+/* same outputs as dg_bn_train_stats, from partial rows written by dg_conv_*_bnstats (M = N*H*W rows total) */
+int dg_bn_stats_from_partials(const float* stat, int P, int M, int C, float eps, float momentum,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float* saved, dg_stream_t s);
 int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
                   const float* beta, int act, float slope, dg_stream_t s);
 /* dy = BN'(act'(dz)); dgamma/dbeta (+)= ; dy may alias dz */

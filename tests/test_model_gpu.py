@@ -318,6 +318,20 @@ def test_two_streams_equal_single_stream():
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_fused_bn_statistics_path_matches_default(monkeypatch):
+    """model.FUSE_BN_STATS routes BN statistics through the conv epilogue; same losses / weights to rounding."""
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for fuse in (False, True):
+        monkeypatch.setattr(M, "FUSE_BN_STATS", fuse)
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234)
+        vals = [tr.losses_to_floats(tr.train_iteration(A, B, it, do_step=False)) for it in range(2)]
+        res.append(vals)
+    for a, b in zip(res[0], res[1]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-7, (k, a[k], b[k])
+
+
 def test_comm_stream_overlap_path_is_bitwise_neutral():
     """The DP overlap path (D-step all-reduce + Adam on a communication stream, overlapped with the next
     iteration's generator passes) exercised at world size 1: identical results to the plain path."""

@@ -196,6 +196,32 @@ def test_batchnorm_act(N, C, H, act):
     close(dbeta, bn.bias.grad, rtol=5e-4, what="bn dbeta")
 
 
+@pytest.mark.parametrize("N,C,K,H", [(2, 64, 128, 8), (3, 64, 128, 16), (4, 256, 512, 8), (8, 64, 128, 32), (2, 128, 64, 16)])
+def test_conv_fused_bn_statistics(N, C, K, H):
+    """BN statistics emitted by the conv epilogue / split-K reduction == the stand-alone statistics pass."""
+    x = rnd(N, C, H, H, seed=1) + 0.4
+    w = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    xg, wg = nhwc(x), krsc(w)
+    for name, fn in (("fwd", lambda: ops.conv_fwd(xg, wg, 2, 1, want_stats=True)),):
+        y, st = fn()
+        assert st is not None and st.shape[1] == 3 * y.shape[1] + 4
+        rm1, rv1 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        rm2, rv2 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        n1, n2 = torch.zeros((), dtype=torch.long, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+        a = ops.bn_stats_from_partials(st, y, rm1, rv1, n1, 1e-5, 0.1)
+        b = ops.bn_train_stats(y, rm2, rv2, n2, 1e-5, 0.1)
+        close(a, b, rtol=2e-6, atol=1e-7, what=f"{name} fused stats")
+        close(rv1, rv2, rtol=2e-6, atol=1e-7, what=f"{name} running_var")
+        assert int(n1) == 1
+    # ConvTranspose direction (dgrad kernel, 4 parity classes): dy [N,K,H/2,H/2] -> [N,C,H,H]
+    dy = nhwc(rnd(N, K, H // 2, H // 2, seed=3) + 0.2)
+    out, st = ops.conv_dgrad(dy, wg, (H, H), 2, 1, want_stats=True)
+    rm1, rv1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    a = ops.bn_stats_from_partials(st, out, rm1, rv1, None, 1e-5, 0.1)
+    b = ops.bn_train_stats(out, None, None, None, 1e-5, 0.1)
+    close(a, b, rtol=2e-6, atol=1e-7, what="dgrad fused stats")
+
+
 def test_bn_needs_two_values():
     y = nhwc(rnd(1, 100, 1, 1))
     with pytest.raises(_lib.DiscoganHipError, match="more than 1 value"):
