@@ -126,10 +126,16 @@ def cpu_baseline(image_size, batch, update_interval=3):
     A, B = O.synthetic_batch(batch, image_size, seed=1000)
     O.train_iteration(st, A, B, 1)                      # warm-up (G-step; allocs, oneDNN primitives)
     t0 = time.perf_counter()
-    for it in range(update_interval, 2 * update_interval):
-        O.train_iteration(st, A, B, it)
-    dt = time.perf_counter() - t0
-    return batch * update_interval / dt, dt
+    it, n = update_interval, 0
+    while True:                                         # whole D,G,G cycles until ~10 s of CPU work
+        for _ in range(update_interval):
+            O.train_iteration(st, A, B, it)
+            it += 1
+            n += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or n >= 60:
+            break
+    return batch * n / dt, dt, n
 
 
 def main():
@@ -193,10 +199,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         torch.set_num_threads(min(16, os.cpu_count() or 1))   # the 1-GPU box's CPU share is 16 cores
         log("cpu baseline (oracle) ...")
-        v, cdt = cpu_baseline(a.image_size, 64)
+        v, cdt, cn = cpu_baseline(a.image_size, 64)
         cpu = dict(value=round(v, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
                    sample=f"oracle/discogan_ref.py, image_size={a.image_size} batch 64 (BASELINE configs[0]), "
-                          f"one D,G,G cycle after 1 warm-up iteration, {cdt:.1f} s")
+                          f"{cn} iterations (whole D,G,G cycles) after 1 warm-up iteration, {cdt:.1f} s")
     if rank == 0:
         line = dict(metric="images/sec per DiscoGAN train step", value=round(value, 2), unit="images/s",
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
