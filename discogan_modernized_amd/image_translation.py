@@ -60,6 +60,9 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no_graph", action="store_true", help="dispatch every kernel from Python (no hipGraph replay)")
     p.add_argument("--weight_decay", type=float, default=0.00001)
+    p.add_argument("--save_train_state", action="store_true",
+                   help="also write train_state_{iters}.pth (weights + Adam moments + iteration) at every model save")
+    p.add_argument("--resume", type=str, default=None, help="train_state_*.pth to continue from (exact resume)")
     return p
 
 
@@ -87,8 +90,10 @@ def run_dirs(args, rank_suffix=""):
     return Path(args.results_dir) / sub, Path(args.models_dir) / sub
 
 
-def save_models(trainer, model_path, tag):
+def save_models(trainer, model_path, tag, iters=None, with_state=False):
     trainer.finish()                      # join the communication stream before reading parameters
+    if with_state and iters is not None:
+        torch.save(trainer.train_state(iters), model_path / f"train_state_{tag}.pth")
     names = dict(gen_A=trainer.generator_A, gen_B=trainer.generator_B,
                  dis_A=trainer.discriminator_A, dis_B=trainer.discriminator_B)
     for k, net in names.items():
@@ -119,6 +124,11 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
             f.write(f"Task: {args.task_name}, Model: {args.model_arch}\n")
             f.write(f"Batch size: {args.batch_size}, Learning rate: {args.learning_rate}\n\n")
     iters = 0
+    if getattr(args, "resume", None):
+        iters = trainer.load_train_state(torch.load(args.resume, map_location="cpu"))
+        if is_main:
+            print(f"resumed from {args.resume} at iteration {iters}")
+    start_iters = iters
     t0 = time.time()
     gperm = torch.Generator(device="cpu").manual_seed(args.seed + 17 * rank)
     for epoch in range(args.epochs):
@@ -132,18 +142,18 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
             if is_main and iters % args.log_interval == 0:
                 msg = trainer.format_log(iters, total_iterations, out)
                 dt = time.time() - t0
-                print(msg + f"  [{(iters + 1) * args.batch_size * world_size / max(dt, 1e-9):.1f} img/s]", flush=True)
+                print(msg + f"  [{(iters - start_iters + 1) * args.batch_size * world_size / max(dt, 1e-9):.1f} img/s]", flush=True)
                 with open(log_file, "a") as f:
                     f.write(msg + "\n")
             if is_main and iters % args.model_save_interval == 0:
-                save_models(trainer, model_path, str(iters))
+                save_models(trainer, model_path, str(iters), iters, getattr(args, "save_train_state", False))
             iters += 1
             if args.max_iters and iters >= args.max_iters:
                 break
         if args.max_iters and iters >= args.max_iters:
             break
     if is_main:
-        save_models(trainer, model_path, "final")
+        save_models(trainer, model_path, "final", iters, getattr(args, "save_train_state", False))
         print(f"Training completed. Final models saved to {model_path}")
         print(f"Results and logs saved to {result_path}")
     return trainer

@@ -65,14 +65,32 @@ class Adam:
                 p._dg_flat_grad.copy_(p.grad)
                 p.grad = p._dg_flat_grad
 
+    def ranges_of(self, modules):
+        """Flat [begin, end) ranges covering the parameters of the given modules (merged when adjacent)."""
+        ids = {id(p) for m in modules for p in m.parameters()}
+        out = []
+        for p, off in zip(self.params, self.offsets):
+            if id(p) in ids:
+                end = off + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                if out and out[-1][1] == off:
+                    out[-1][1] = end
+                else:
+                    out.append([off, end])
+        return [tuple(r) for r in out]
+
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, active=None):
+        """``active``: flat ranges that received gradients this iteration (from ``ranges_of``).  Like
+        torch.optim.Adam, parameters whose ``.grad`` would be None (a network outside the loss of the
+        ``recongan`` / ``gan`` architectures, image_translation.py:377-382) are left untouched: no weight
+        decay, no moment update.  None = the whole group."""
         g = self.param_groups[0]
         self._sync_foreign_grads()
         ops.adam_advance(self.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
-        ops.adam_step_flat(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.state,
-                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                           float(grad_scale))
+        for b, e in (active if active is not None else [(0, self.numel)]):
+            ops.adam_step_flat(self.flat_p[b:e], self.flat_g[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], self.state,
+                               float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                               float(grad_scale))
 
     def state_dict(self):
         return dict(step=self.state[0:1].clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

@@ -93,6 +93,19 @@ class DiscoGANTrainer:
             self.use_graph = False
 
     # ---------------------------------------------------------------------------------------------
+    def active_ranges(self, dstep):
+        """Networks that receive gradients in this kind of step (image_translation.py:374-382):
+        discogan: both of the stepped side; recongan: D_B | G_A+G_B (G_B through recon_A's cycle);
+        gan: D_B | G_B only.  Returned as flat ranges of the stepped optimiser (None = all)."""
+        arch = self.args.model_arch
+        if arch == "discogan":
+            return None
+        if dstep:
+            return self.optim_dis.ranges_of([self.discriminator_B])
+        if arch == "gan":
+            return self.optim_gen.ranges_of([self.generator_B])
+        return None                                       # recongan: ABA = G_A(G_B(A)) reaches both generators
+
     def is_dis_step(self, iters):
         return iters % self.args.update_interval == 0          # image_translation.py:385
 
@@ -229,13 +242,13 @@ class DiscoGANTrainer:
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 scale, _ = dp.all_reduce_flat(opt.flat_g, self.pg) if self.world_size > 1 else (1.0, None)
-                opt.step(grad_scale=scale)
+                opt.step(grad_scale=scale, active=self.active_ranges(dstep))
                 self._ev_dis_ready = torch.cuda.Event()
                 self._ev_dis_ready.record(self.comm_stream)
             return out
         scale, _ = dp.all_reduce_flat(opt.flat_g, self.pg) if self.world_size > 1 else (1.0, None)
         if do_step:
-            opt.step(grad_scale=scale)
+            opt.step(grad_scale=scale, active=self.active_ranges(dstep))
         return out
 
     def finish(self):
@@ -258,6 +271,23 @@ class DiscoGANTrainer:
 
     def state_dicts(self):
         return {k: v.state_dict() for k, v in self.nets.items()}
+
+    def train_state(self, iters):
+        """Everything needed to resume exactly: weights + BN buffers, both Adam states, the iteration count
+        (the reference resumes weights only and restarts Adam and the GAN curriculum)."""
+        self.finish()
+        torch.cuda.synchronize(self.device)
+        return dict(iters=int(iters), nets={k: {n: t.detach().contiguous().cpu() for n, t in v.state_dict().items()}
+                                            for k, v in self.nets.items()},
+                    optim_gen=self.optim_gen.state_dict(), optim_dis=self.optim_dis.state_dict())
+
+    def load_train_state(self, st):
+        for k, v in self.nets.items():
+            v.load_state_dict(st["nets"][k])
+        self.optim_gen.load_state_dict(st["optim_gen"])
+        self.optim_dis.load_state_dict(st["optim_dis"])
+        self._graphs = {}
+        return int(st["iters"])
 
 
 def synthetic_batch(n, image_size, seed, device):

@@ -332,6 +332,81 @@ def test_fused_bn_statistics_path_matches_default(monkeypatch):
             assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-7, (k, a[k], b[k])
 
 
+@pytest.mark.parametrize("arch", ["recongan", "gan"])
+def test_other_architectures_teacher_forced(arch):
+    """--model_arch recongan / gan (image_translation.py:377-382): different loss wiring; networks outside the
+    loss get no gradient and, like torch.optim.Adam with grad=None, must not be touched by the step."""
+    S, N = 16, 4
+    st = O.build_state(image_size=S, seed=1234, args=O.default_args(model_arch=arch))
+    tr = DiscoGANTrainer(default_args(model_arch=arch), device=DEV, image_size=S, seed=1234)
+    A, B = O.synthetic_batch(N, S, seed=0)
+    Ag, Bg = A.to(DEV), B.to(DEV)
+    for it in range(3):
+        for k in st.nets:
+            tr.nets[k].load_state_dict(st.nets[k].state_dict())
+        before = {k: [p.detach().clone() for p in tr.nets[k].parameters()] for k in tr.nets}
+        ref = O.train_iteration(st, A, B, it, do_step=False)
+        out = tr.train_iteration(Ag, Bg, it, do_step=False)
+        got, want = tr.losses_to_floats(out), O.losses_to_floats(ref)
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-6, f"{arch} iter {it} {k}: {got[k]} vs {v}"
+        dstep = O.is_dis_step(it, st.args)
+        live = ("dis_A", "dis_B") if dstep else ("gen_A", "gen_B")
+        touched = set()
+        for name in live:
+            for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
+                if po.grad is None:
+                    assert float(pm.grad.abs().max()) == 0.0, f"{arch} iter {it}: {name}.{pn} should have no gradient"
+                else:
+                    touched.add(name)
+                    assert rel_err(pm.grad, po.grad) < 5e-3, f"{arch} iter {it} grad {name}.{pn}"
+                    pm.grad.copy_(po.grad.to(DEV))
+        (st.optim_dis if dstep else st.optim_gen).step()
+        (tr.optim_dis if dstep else tr.optim_gen).step(active=tr.active_ranges(dstep))
+        for name in tr.nets:
+            for i, ((pn, po), pm) in enumerate(zip(st.nets[name].named_parameters(), tr.nets[name].parameters())):
+                if name in touched:
+                    assert float((pm.detach().cpu() - po.detach()).abs().max()) <= 1e-6, f"{arch} iter {it} Adam {name}.{pn}"
+                else:
+                    assert torch.equal(pm.detach(), before[name][i]), f"{arch} iter {it}: {name}.{pn} must be untouched"
+
+
+def test_exact_resume_from_train_state(tmp_path):
+    """weights + BN buffers + Adam moments + iteration counter round-trip: the resumed run continues bitwise."""
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234)
+    for it in range(4):
+        tr.train_iteration(A, B, it)
+    path = tmp_path / "train_state.pth"
+    torch.save(tr.train_state(4), path)
+    cont = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4, 8)]
+    tr2 = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=99)       # different init on purpose
+    start = tr2.load_train_state(torch.load(path, map_location="cpu"))
+    assert start == 4
+    cont2 = [tr2.losses_to_floats(tr2.train_iteration(A, B, it)) for it in range(4, 8)]
+    assert cont == cont2
+    assert torch.equal(tr.optim_gen.flat_p, tr2.optim_gen.flat_p) and torch.equal(tr.optim_dis.exp_avg_sq, tr2.optim_dis.exp_avg_sq)
+
+
+def test_eval_mode_inference_matches_oracle():
+    """inference.py's use of the generators: eval() -> BatchNorm normalises with the running statistics."""
+    torch.manual_seed(3)
+    og = O.Generator(True, image_size=16)
+    mg = M.Generator(True, image_size=16).to(DEV)
+    x = torch.rand(5, 3, 16, 16)
+    og.train()
+    for _ in range(3):
+        og(torch.rand(6, 3, 16, 16))                 # move the running statistics away from (0, 1)
+    mg.load_state_dict(og.state_dict())
+    og.eval()
+    mg.eval()
+    with torch.no_grad():
+        max_close(mg(x.to(DEV)), og(x), 1e-4, 1e-5, "eval-mode generator")
+        mid = mg.decoder(mg.encoder(x[:1].to(DEV)))  # batch of one is fine in eval mode
+    assert mid.shape == (1, 3, 16, 16)
+    assert int(mg.encoder[3].num_batches_tracked) == int(og.encoder[3].num_batches_tracked) == 3
+
+
 def test_comm_stream_overlap_path_is_bitwise_neutral():
     """The DP overlap path (D-step all-reduce + Adam on a communication stream, overlapped with the next
     iteration's generator passes) exercised at world size 1: identical results to the plain path."""
