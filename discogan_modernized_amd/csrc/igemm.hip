@@ -749,6 +749,13 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
 }
 
 // ---- conv + fused BatchNorm partial statistics -------------------------------------------------------
+extern "C" int dg_conv_plan_splits(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (check_geom("dg_conv_plan_splits", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
+    Plan pl;
+    make_plan(op, g, &pl);
+    return pl.a.splits;
+}
 extern "C" int dg_conv_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK) return 0;

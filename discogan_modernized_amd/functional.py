@@ -35,7 +35,7 @@ class ConvFn(Function):
         ctx.wref = w
         if not want_stats:
             return ops.conv_fwd(x, w, stride, pad)
-        y, stat = ops.conv_fwd(x, w, stride, pad, want_stats=True)
+        y, stat = ops.conv_fwd(x, w, stride, pad, want_stats=want_stats)
         if stat is None:
             stat = torch.empty(0, device=y.device)
         ctx.mark_non_differentiable(stat)
@@ -72,7 +72,7 @@ class ConvTransposeFn(Function):
         ctx.out_hw = (hout, wout)
         if not want_stats:
             return ops.conv_dgrad(x, w, (hout, wout), stride, pad)
-        y, stat = ops.conv_dgrad(x, w, (hout, wout), stride, pad, want_stats=True)
+        y, stat = ops.conv_dgrad(x, w, (hout, wout), stride, pad, want_stats=want_stats)
         if stat is None:
             stat = torch.empty(0, device=y.device)
         ctx.mark_non_differentiable(stat)

@@ -25,7 +25,11 @@ from . import ops
 # BatchNorm statistics can come out of the producing conv kernel's epilogue (dg_conv_*_bnstats) instead of a
 # separate read pass.  Measured on MI355X (round 1): with the two-stream schedule the separate HBM-bound
 # statistics pass overlaps the other chain's MFMA kernels for free, while the fused form lengthens the
-# MFMA kernels' tails: 15.21 vs 14.95 ms/step at 64 px / batch 256, 182.5 vs 182.9 at 512 px.  Off by default.
+# MFMA kernels' tails: 15.21 vs 14.95 ms/step at 64 px / batch 256, 182.5 vs 182.9 at 512 px.
+#   False   : always the separate statistics pass (default; fastest under the two-stream schedule)
+#   "split" : fused only for layers whose conv plan uses split-K -- the statistics then come out of the
+#             split-K reduction kernel (measured 15.14 ms/step: still slower than the separate pass)
+#   True    : fused everywhere
 FUSE_BN_STATS = False
 
 
@@ -80,7 +84,7 @@ class Conv2d(nn.Module):
         if self.in_channels == 3:
             return F.ConvC3Fn.apply(x, self.weight, fused_act, slope)
         if want_stats:
-            return F.ConvFn.apply(x, self.weight, self.stride, self.padding, True)
+            return F.ConvFn.apply(x, self.weight, self.stride, self.padding, want_stats)
         return F.ConvFn.apply(x, self.weight, self.stride, self.padding)
 
     @property
@@ -109,7 +113,7 @@ class ConvTranspose2d(nn.Module):
         if self.out_channels == 3:
             return F.ConvTransposeC3Fn.apply(x, self.weight, fused_act)
         if want_stats:
-            return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding, True)
+            return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding, want_stats)
         return F.ConvTransposeFn.apply(x, self.weight, self.stride, self.padding)
 
     @property
@@ -186,7 +190,7 @@ def _run_fused(layers, x):
         act = act_mod.act if act_mod is not None else ops.ACT_NONE
         slope = act_mod.negative_slope if act_mod is not None else 0.0
         if bn is not None and bn.training and FUSE_BN_STATS and conv.emits_bn_stats:
-            y, st = conv(x, want_stats=True)                # BN statistics from the conv kernel's epilogue
+            y, st = conv(x, want_stats=FUSE_BN_STATS)       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
             x = bn(conv(x), act, slope)
@@ -225,7 +229,7 @@ class Discriminator(_FlatGradMixin, nn.Module):
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
             if bn.training and FUSE_BN_STATS:
-                y, st = conv(h, want_stats=True)            # BN statistics from the conv kernel's epilogue
+                y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
                 h = bn(conv(h), ops.ACT_LEAKY, relu.negative_slope)

@@ -134,6 +134,8 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
+    if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
+        rows = 0                      # statistics only where the split-K reduction kernel can emit them
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
         if rows > 0:
             stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
@@ -159,6 +161,8 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
     rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
+    if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
+        rows = 0
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
         if rows > 0:
             stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)

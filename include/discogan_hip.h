@@ -74,6 +74,8 @@ int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int 
  * pass of dg_bn_train_stats.  stat: [rows][3*cols + 4] floats with rows = dg_conv_bnstats_rows(op,...)
  * and cols = K (op 0, fwd) or C (op 1, dgrad); consume with dg_bn_stats_from_partials. */
 int dg_conv_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad);
+/* number of K splits the plan for this shape uses (1 = no split-K reduction kernel); 0 on bad geometry */
+int dg_conv_plan_splits(int op, int N, int H, int W, int C, int K, int stride, int pad);
 int dg_conv_fwd_bnstats(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
                         float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_dgrad_bnstats(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
