@@ -88,7 +88,7 @@ def timed_run(trainer, A, B, steps, warmup, world, start_iter=0):
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # max over ranks
         dt = float(t.item())
     return dt, it
 
@@ -149,11 +149,15 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
+    if os.environ.get("DG_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)          # rehearsal: ranks share the visible GPU(s)
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" == RCCL over xGMI; DG_DIST_BACKEND=gloo lets the launch be rehearsed with several ranks on ONE GPU
+        backend = os.environ.get("DG_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
     from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
     dev = torch.device("cuda", local)
