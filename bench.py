@@ -167,6 +167,7 @@ def main():
     A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
     log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
     dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
+    used_graph, used_overlap = bool(trainer.use_graph), bool(trainer.overlap_comm)
     log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
     images = a.batch_size * world * a.steps
     value = images / dt
@@ -214,7 +215,8 @@ def main():
                     config=dict(workload=f"edges2shoes discogan image_size={a.image_size} batch_size={a.batch_size} per GPU "
                                          f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped",
                                 global_batch=a.batch_size * world, parallelism=f"dp{world}",
-                                hipgraph=not a.no_graph, hip_streams=1 if a.single_stream else 2),
+                                hipgraph=used_graph, hip_streams=1 if a.single_stream else 2,
+                                allreduce_overlap=used_overlap),
                     roofline=roof, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line), flush=True)
     if world > 1:
