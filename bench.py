@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no_512", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
+    ap.add_argument("--async_wgrad", action="store_true",
+                    help="weight-gradient kernels on a third stream (measured: neutral to slightly slower)")
     return ap.parse_args()
 
 
@@ -98,16 +100,17 @@ def roofline_pass(trainer, A, B, start_iter):
     from discogan_modernized_amd import ops
     ui = trainer.args.update_interval
     start_iter = (start_iter + ui - 1) // ui * ui            # align to a D-step
-    was_graph, was_two = trainer.use_graph, trainer.two_streams
+    was_graph, was_two, was_aw = trainer.use_graph, trainer.two_streams, trainer.wgrad_stream
     trainer.use_graph = False
     trainer.two_streams = False          # isolated kernel durations: one stream, one kernel at a time
+    trainer.wgrad_stream = None
     ops.PROFILE = []
     for k in range(ui):
         trainer.train_iteration(A, B, start_iter + k)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     rec = [r for r in rec if r[0] != "head1"]   # K==1 head uses plain reduction kernels, not the MFMA family
-    trainer.use_graph, trainer.two_streams = was_graph, was_two
+    trainer.use_graph, trainer.two_streams, trainer.wgrad_stream = was_graph, was_two, was_aw
     flops = sum(r[1] for r in rec)
     ms = sum(r[2].elapsed_time(r[3]) for r in rec)
     by = {}
@@ -163,7 +166,8 @@ def main():
     dev = torch.device("cuda", local)
 
     trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
-                              use_graph=not a.no_graph, two_streams=not a.single_stream)
+                              use_graph=not a.no_graph, two_streams=not a.single_stream,
+                              async_wgrad=a.async_wgrad and not a.single_stream)
     A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
     log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
     dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
@@ -190,7 +194,8 @@ def main():
     torch.cuda.empty_cache()
     if not a.no_512:
         tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
-                                use_graph=not a.no_graph, two_streams=not a.single_stream)
+                                use_graph=not a.no_graph, two_streams=not a.single_stream,
+                                async_wgrad=a.async_wgrad and not a.single_stream)
         A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
         log("512px models built")
         dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)

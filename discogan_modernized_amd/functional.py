@@ -24,6 +24,29 @@ def _flat_grad_of(param):
     return None
 
 
+# Auxiliary HIP stream for weight-gradient kernels (set by the trainer).  dgrad feeds the next BN-backward
+# on the chain's own stream; wgrad only feeds Adam at the end of the iteration, so it is launched on this
+# stream behind an event and fills the matrix pipes while the chain runs its HBM-bound BN-backward kernels.
+WGRAD_STREAM = None
+
+
+def _launch_wgrad(fn, *tensors):
+    """Run fn() (a wgrad that accumulates into the flat gradient buffer) on WGRAD_STREAM, after the work
+    already queued on the current stream; keeps the tensors it reads alive for that stream."""
+    aux = WGRAD_STREAM
+    if aux is None:
+        fn()
+        return
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    aux.wait_event(ev)
+    with torch.cuda.stream(aux):
+        fn()
+    for t in tensors:
+        t.record_stream(aux)
+
+
 class ConvFn(Function):
     """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
 
@@ -51,7 +74,7 @@ class ConvFn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
-                ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True)
+                _launch_wgrad(lambda: ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True), dy, x)
             else:
                 dw = ops.conv_wgrad(dy, x, stride, pad)
         return dx, dw, None, None, None
@@ -89,7 +112,7 @@ class ConvTransposeFn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
-                ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True)
+                _launch_wgrad(lambda: ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True), dy, x)
             else:
                 dw = ops.conv_wgrad(x, dy, stride, pad)
         return dx, dw, None, None, None
@@ -117,7 +140,7 @@ class ConvC3Fn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
-                ops.c3_wgrad(g, x, out=fg, accumulate=True)
+                _launch_wgrad(lambda: ops.c3_wgrad(g, x, out=fg, accumulate=True), g, x)
             else:
                 dw = ops.c3_wgrad(g, x)
         return dx, dw, None, None
@@ -144,7 +167,7 @@ class ConvTransposeC3Fn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
-                ops.c3_wgrad(x, g, out=fg, accumulate=True)
+                _launch_wgrad(lambda: ops.c3_wgrad(x, g, out=fg, accumulate=True), g, x)
             else:
                 dw = ops.c3_wgrad(x, g)
         return dx, dw, None

@@ -43,7 +43,7 @@ def default_args(**over):
 
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
-                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None):
+                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -79,6 +79,10 @@ class DiscoGANTrainer:
         # stream, which keeps its two calls per iteration (and its BN running-stat updates) ordered.
         self.two_streams = two_streams
         self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
+        # optional: weight-gradient kernels on a third stream (functional.WGRAD_STREAM), off the backward
+        # critical path.  Bitwise neutral; measured 15.04 vs 14.80 ms/step (eager, 64 px) -> off by default.
+        self.async_wgrad = bool(async_wgrad)
+        self.wgrad_stream = torch.cuda.Stream(device=self.device) if async_wgrad else None
         # Data-parallel exchange overlap: after a D-step the all-reduce of the D gradients and the D Adam
         # step run on a communication stream while the NEXT iteration's generator passes run; the
         # discriminator passes wait on the event.  (A G-step's update is needed by the very next kernel,
@@ -198,7 +202,14 @@ class DiscoGANTrainer:
             self.optim_gen.zero_grad()                   # image_translation.py:336-339
             self.optim_dis.zero_grad()
         out = self.forward_losses(A, B, iters)
-        (out.dis_loss if dstep else out.gen_loss).backward()
+        from . import functional as _F
+        _F.WGRAD_STREAM = self.wgrad_stream
+        try:
+            (out.dis_loss if dstep else out.gen_loss).backward()
+        finally:
+            _F.WGRAD_STREAM = None
+        if self.async_wgrad:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:
             # the backward kernels of the A-side chain ran on the side stream and wrote the flat gradient
             # buffer directly (no AccumulateGrad leaf for autograd to sync): join before Adam / all-reduce
