@@ -30,7 +30,7 @@ from . import ops
 #   "split" : fused only for layers whose conv plan uses split-K -- the statistics then come out of the
 #             split-K reduction kernel (measured 15.14 ms/step: still slower than the separate pass)
 #   True    : fused everywhere
-FUSE_BN_STATS = False
+FUSE_BN_STATS = {"0": False, "1": True, "split": "split"}[__import__("os").environ.get("DG_FUSE_BN", "0")]
 
 
 def stage_channels(image_size: int):
