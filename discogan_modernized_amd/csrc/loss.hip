@@ -124,6 +124,61 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- loss mix (image_translation.py:162-166, 367-382) -----------------------------------------------------
+// lossvec slots:  0 recon_A  1 recon_B | 2 bce(D_A real,1) 3 bce(D_A fake,0) 4 bce(D_A fake,1) | 5,6,7 same for D_B
+//                 8 .. 8+nfm-1  feature-matching layers of D_A | 8+nfm .. 8+2nfm-1  of D_B
+// out slots:      0 gen_loss_A 1 gen_loss_B 2 fm_loss_A 3 fm_loss_B 4 dis_loss_A 5 dis_loss_B 6 gen_loss 7 dis_loss
+// arch: 0 discogan, 1 recongan, 2 gan.  One thread; fp32 operations in the reference's order.
+#define LM_FM0 8
+__device__ __forceinline__ void loss_mix_coeffs(int arch, float rate, float* cA_fmgan, float* cB_fmgan, float* cA_rec,
+                                                float* cB_rec, float* dA, float* dB) {
+    // gen_loss = sA*[(fm_B*0.9 + gen_B*0.1)*(1-rate) + recon_A*rate] + sB*[(fm_A*0.9 + gen_A*0.1)*(1-rate) + recon_B*rate]
+    const float omr = 1.f - rate;
+    if (arch == 0) { *cA_fmgan = omr; *cB_fmgan = omr; *cA_rec = rate; *cB_rec = rate; *dA = 1.f; *dB = 1.f; }
+    else if (arch == 1) { *cA_fmgan = omr; *cB_fmgan = 0.f; *cA_rec = rate; *cB_rec = 0.f; *dA = 0.f; *dB = 1.f; }
+    else { *cA_fmgan = 1.f; *cB_fmgan = 0.f; *cA_rec = 0.f; *cB_rec = 0.f; *dA = 0.f; *dB = 1.f; }
+}
+__global__ void loss_mix_fwd_kernel(const float* __restrict__ lv, float* __restrict__ out, int nfm, float rate, int arch) {
+    float fmA = 0.f, fmB = 0.f;
+    for (int l = 0; l < nfm; ++l) { fmA += lv[LM_FM0 + l]; fmB += lv[LM_FM0 + nfm + l]; }
+    const float disA = (lv[2] + lv[3]) * 0.5f, disB = (lv[5] + lv[6]) * 0.5f;
+    const float genA = lv[4], genB = lv[7];
+    const float omr = 1.f - rate;
+    const float totA = (fmB * 0.9f + genB * 0.1f) * omr + lv[0] * rate;   // gen_loss_A_total (cross-wired, :370)
+    const float totB = (fmA * 0.9f + genA * 0.1f) * omr + lv[1] * rate;
+    float gen, dis;
+    if (arch == 0) { gen = totA + totB; dis = disA + disB; }
+    else if (arch == 1) { gen = totA; dis = disB; }
+    else { gen = genB * 0.1f + fmB * 0.9f; dis = disB; }
+    out[0] = genA; out[1] = genB; out[2] = fmA; out[3] = fmB; out[4] = disA; out[5] = disB; out[6] = gen; out[7] = dis;
+}
+// gradient seeds for every lossvec slot given d(gen_loss) or d(dis_loss) (which: 6 or 7)
+__global__ void loss_mix_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gv, int nfm, float rate, int arch, int which) {
+    const float g = gout[0];
+    for (int i = 0; i < LM_FM0 + 2 * nfm; ++i) gv[i] = 0.f;
+    if (which == 7) {
+        const float dA = arch == 0 ? 1.f : 0.f;
+        gv[2] = gv[3] = g * dA * 0.5f;
+        gv[5] = gv[6] = g * 0.5f;
+        return;
+    }
+    const float omr = 1.f - rate;
+    if (arch == 2) {
+        gv[7] = g * 0.1f;
+        for (int l = 0; l < nfm; ++l) gv[LM_FM0 + nfm + l] = g * 0.9f;
+        return;
+    }
+    // totA path (always): fm_B, gen_B, recon_A
+    gv[0] = g * rate;
+    gv[7] = g * omr * 0.1f;
+    for (int l = 0; l < nfm; ++l) gv[LM_FM0 + nfm + l] = g * omr * 0.9f;
+    if (arch == 0) {   // totB path: fm_A, gen_A, recon_B
+        gv[1] = g * rate;
+        gv[4] = g * omr * 0.1f;
+        for (int l = 0; l < nfm; ++l) gv[LM_FM0 + l] = g * omr * 0.9f;
+    }
+}
+
 static int loss_grid(long work) {
     long g = (work + 255) / 256;
     if (g > LOSS_MAX_BLOCKS) g = LOSS_MAX_BLOCKS;
@@ -196,5 +251,18 @@ extern "C" int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, 
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(fm_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, dreal, dfake);
     DG_CHECK_LAUNCH("fm_bwd");
+    return DG_OK;
+}
+
+extern "C" int dg_loss_mix_fwd(const float* lossvec, float* out8, int nfm, float rate, int arch, dg_stream_t stream) {
+    DG_CHECK_ARG(lossvec && out8 && nfm >= 0 && nfm <= 12 && arch >= 0 && arch <= 2, "dg_loss_mix_fwd: bad argument");
+    hipLaunchKernelGGL(loss_mix_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, lossvec, out8, nfm, rate, arch);
+    DG_CHECK_LAUNCH("loss_mix_fwd");
+    return DG_OK;
+}
+extern "C" int dg_loss_mix_bwd(const float* gout, float* gvec, int nfm, float rate, int arch, int which, dg_stream_t stream) {
+    DG_CHECK_ARG(gout && gvec && nfm >= 0 && nfm <= 12 && arch >= 0 && arch <= 2 && (which == 6 || which == 7), "dg_loss_mix_bwd: bad argument");
+    hipLaunchKernelGGL(loss_mix_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gout, gvec, nfm, rate, arch, which);
+    DG_CHECK_LAUNCH("loss_mix_bwd");
     return DG_OK;
 }

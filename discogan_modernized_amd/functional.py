@@ -229,8 +229,8 @@ class ActFn(Function):
 
 class MSELossFn(Function):
     @staticmethod
-    def forward(ctx, x, t):
-        loss, xd, td = ops.mse_fwd(x, t)
+    def forward(ctx, x, t, out=None):
+        loss, xd, td = ops.mse_fwd(x, t, out)
         ctx.save_for_backward(xd, td)
         ctx.in_strides = x.stride()
         return loss
@@ -243,16 +243,16 @@ class MSELossFn(Function):
         dt = None
         if ctx.needs_input_grad[1]:
             dt = ops.mse_bwd(td, xd, gout)
-        return dx, dt
+        return dx, dt, None
 
 
 class BCELossFn(Function):
     """nn.BCELoss against a constant label tensor (image_translation.py:157-166)."""
 
     @staticmethod
-    def forward(ctx, p, label):
+    def forward(ctx, p, label, out=None):
         shape = p.shape
-        loss, pc = ops.bce_fwd(p.reshape(-1), label)
+        loss, pc = ops.bce_fwd(p.reshape(-1), label, out)
         ctx.save_for_backward(pc)
         ctx.cfg = (label, shape)
         return loss
@@ -261,15 +261,15 @@ class BCELossFn(Function):
     def backward(ctx, gout):
         (pc,) = ctx.saved_tensors
         label, shape = ctx.cfg
-        return ops.bce_bwd(pc, label, gout.contiguous()).reshape(shape), None
+        return ops.bce_bwd(pc, label, gout.contiguous()).reshape(shape), None, None
 
 
 class FeatureMatchFn(Function):
     """One layer of get_fm_loss: mean((real.mean(0) - fake.mean(0))**2)."""
 
     @staticmethod
-    def forward(ctx, real, fake):
-        loss, diff, rd, fd = ops.fm_fwd(real, fake)
+    def forward(ctx, real, fake, out=None):
+        loss, diff, rd, fd = ops.fm_fwd(real, fake, out)
         ctx.save_for_backward(diff, rd, fd)
         return loss
 
@@ -277,4 +277,28 @@ class FeatureMatchFn(Function):
     def backward(ctx, gout):
         diff, rd, fd = ctx.saved_tensors
         dreal, dfake = ops.fm_bwd(diff, rd, fd, gout.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dreal, dfake
+        return dreal, dfake, None
+
+
+class LossMixFn(Function):
+    """The whole curriculum mix (get_gan_loss's 0.5*(real+fake), get_fm_loss's layer sum, and
+    image_translation.py:367-382) in one launch over the loss vector, and all gradient seeds in one launch.
+    ``slots`` are the views of ``lossvec`` that the differentiated loss (`which`: 6 gen_loss, 7 dis_loss)
+    depends on, ``idx`` their slot numbers: autograd routes each seed to the loss op that wrote the slot and
+    never visits the others.  Returns the 8 outputs of dg_loss_mix_fwd as 0-dim tensors."""
+
+    @staticmethod
+    def forward(ctx, lossvec, nfm, rate, arch, which, idx, *slots):
+        out = ops.loss_mix_fwd(lossvec, nfm, rate, arch)
+        ctx.cfg = (lossvec.numel(), nfm, rate, arch, which, idx)
+        ctx.set_materialize_grads(False)
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        nslots, nfm, rate, arch, which, idx = ctx.cfg
+        gout = gouts[which]
+        if gout is None:
+            return (None,) * (6 + len(idx))
+        gv = ops.loss_mix_bwd(gout.contiguous(), nslots, nfm, rate, arch, which)
+        return (None, None, None, None, None, None) + tuple(gv[i] for i in idx)

@@ -337,10 +337,10 @@ def same_layout_pair(a, b):
     return a, b
 
 
-def mse_fwd(x, t):
+def mse_fwd(x, t, out=None):
     _check_dev(x, t)
     x, t = same_layout_pair(x, t)
-    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    loss = out if out is not None else torch.empty((), device=x.device, dtype=torch.float32)
     ws, wsb = _loss_ws(x.device)
     _lib.check(_lib.load().dg_mse_fwd(_ptr(x), _ptr(t), x.numel(), _ptr(loss), _ptr(ws), wsb, _stream()), "dg_mse_fwd")
     return loss, x, t
@@ -352,10 +352,10 @@ def mse_bwd(x, t, gout):
     return dx
 
 
-def bce_fwd(p, label):
+def bce_fwd(p, label, out=None):
     _check_dev(p)
     p = p.contiguous()
-    loss = torch.empty((), device=p.device, dtype=torch.float32)
+    loss = out if out is not None else torch.empty((), device=p.device, dtype=torch.float32)
     _lib.check(_lib.load().dg_bce_fwd(_ptr(p), p.numel(), float(label), _ptr(loss), None, 0, _stream()), "dg_bce_fwd")
     return loss, p
 
@@ -366,14 +366,14 @@ def bce_bwd(p, label, gout):
     return dp
 
 
-def fm_fwd(real, fake):
+def fm_fwd(real, fake, out=None):
     """One layer of get_fm_loss; real/fake logical [N,C,H,W] with identical dense layouts."""
     _check_dev(real, fake)
     real, fake = same_layout_pair(real, fake)
     n = real.shape[0]
     j = real.numel() // n
     diff = torch.empty(j, device=real.device, dtype=torch.float32)
-    loss = torch.empty((), device=real.device, dtype=torch.float32)
+    loss = out if out is not None else torch.empty((), device=real.device, dtype=torch.float32)
     ws, wsb = _ws(_lib.load().dg_fm_workspace_bytes(n, j), real.device)
     _lib.check(_lib.load().dg_fm_fwd(_ptr(real), _ptr(fake), n, j, _ptr(diff), _ptr(loss), _ptr(ws), wsb, _stream()),
                "dg_fm_fwd")
@@ -387,6 +387,18 @@ def fm_bwd(diff, like_real, like_fake, gout, need_real, need_fake):
     dfake = _dense_like(like_fake) if need_fake else None
     _lib.check(_lib.load().dg_fm_bwd(_ptr(diff), n, j, _ptr(gout), _ptr(dreal), _ptr(dfake), _stream()), "dg_fm_bwd")
     return dreal, dfake
+
+
+def loss_mix_fwd(lossvec, nfm, rate, arch):
+    out = torch.empty(8, device=lossvec.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_loss_mix_fwd(_ptr(lossvec), _ptr(out), nfm, float(rate), arch, _stream()), "dg_loss_mix_fwd")
+    return out
+
+
+def loss_mix_bwd(gout, nslots, nfm, rate, arch, which):
+    gv = torch.empty(nslots, device=gout.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_loss_mix_bwd(_ptr(gout), _ptr(gv), nfm, float(rate), arch, which, _stream()), "dg_loss_mix_bwd")
+    return gv
 
 
 # ---- Adam -----------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ from types import SimpleNamespace
 import torch
 
 from . import dp
+from . import functional as F_
 from . import losses as L
 from . import optim
 from .model import Discriminator, Generator
@@ -79,6 +80,7 @@ class DiscoGANTrainer:
         # stream, which keeps its two calls per iteration (and its BN running-stat updates) ordered.
         self.two_streams = two_streams
         self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
+        self._one = torch.ones((), device=self.device, dtype=torch.float32)
         # optional: weight-gradient kernels on a third stream (functional.WGRAD_STREAM), off the backward
         # critical path.  Bitwise neutral; measured 15.04 vs 14.80 ms/step (eager, 64 px) -> off by default.
         self.async_wgrad = bool(async_wgrad)
@@ -150,44 +152,62 @@ class DiscoGANTrainer:
             if self.two_streams:
                 side.wait_event(self._ev_dis_ready)
             self._ev_dis_ready = None
-        # stage 2 + discriminators: A-side chain on `side`, B-side chain on `main`
+        # stage 2 + discriminators: A-side chain on `side`, B-side chain on `main`.  Every loss term is written
+        # into its slot of one device vector (layout: dg_loss_mix_fwd); the mix and its gradient seeds are
+        # one launch each instead of ~45 scalar kernels.
+        nfm = None
         with on_side():
             with gen_ctx():
                 ABA = self.generator_A(AB)
-                recon_loss_A = self.recon_criterion(ABA, A)
             A_dis_real, A_feats_real = self.discriminator_A(A)
+        if nfm is None:
+            nfm = len(A_feats_real)
+        lv = torch.empty(8 + 2 * nfm, device=self.device, dtype=torch.float32)
+        if self.two_streams:
+            lv.record_stream(side)
+        sl = [lv[i] for i in range(8 + 2 * nfm)]
+        terms = {}
+
+        def bce(p, label, k):
+            terms[k] = F_.BCELossFn.apply(p.reshape(p.size(0), -1), label, sl[k])
+
+        with on_side():
+            with gen_ctx():
+                terms[0] = F_.MSELossFn.apply(ABA, A, sl[0])
             A_dis_fake, A_feats_fake = self.discriminator_A(BA)
-            dis_loss_A, gen_loss_A = L.get_gan_loss(A_dis_real, A_dis_fake, self.gan_criterion, self.device)
-            fm_loss_A = L.get_fm_loss(A_feats_real, A_feats_fake, self.feat_criterion, self.device)
+            bce(A_dis_real, 1.0, 2); bce(A_dis_fake, 0.0, 3); bce(A_dis_fake, 1.0, 4)
+            for l, (r, f) in enumerate(zip(A_feats_real, A_feats_fake)):
+                terms[8 + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + l])
         with gen_ctx():
             BAB = self.generator_B(BA)
-            recon_loss_B = self.recon_criterion(BAB, B)
+            terms[1] = F_.MSELossFn.apply(BAB, B, sl[1])
         B_dis_real, B_feats_real = self.discriminator_B(B)
         B_dis_fake, B_feats_fake = self.discriminator_B(AB)
-        dis_loss_B, gen_loss_B = L.get_gan_loss(B_dis_real, B_dis_fake, self.gan_criterion, self.device)
-        fm_loss_B = L.get_fm_loss(B_feats_real, B_feats_fake, self.feat_criterion, self.device)
+        bce(B_dis_real, 1.0, 5); bce(B_dis_fake, 0.0, 6); bce(B_dis_fake, 1.0, 7)
+        for l, (r, f) in enumerate(zip(B_feats_real, B_feats_fake)):
+            terms[8 + nfm + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + nfm + l])
         if self.two_streams:
             main.wait_stream(side)
         rate = self.rate(iters)
-        gen_loss_A_total = (fm_loss_B * 0.9 + gen_loss_B * 0.1) * (1 - rate) + recon_loss_A * rate
-        gen_loss_B_total = (fm_loss_A * 0.9 + gen_loss_A * 0.1) * (1 - rate) + recon_loss_B * rate
-        if a.model_arch == "discogan":
-            gen_loss = gen_loss_A_total + gen_loss_B_total
-            dis_loss = dis_loss_A + dis_loss_B
-        elif a.model_arch == "recongan":
-            gen_loss = gen_loss_A_total
-            dis_loss = dis_loss_B
-        elif a.model_arch == "gan":
-            gen_loss = gen_loss_B * 0.1 + fm_loss_B * 0.9
-            dis_loss = dis_loss_B
-        else:
+        arch = {"discogan": 0, "recongan": 1, "gan": 2}.get(a.model_arch)
+        if arch is None:
             raise ValueError(f"unknown model_arch {a.model_arch}")
+        fmA, fmB = list(range(8, 8 + nfm)), list(range(8 + nfm, 8 + 2 * nfm))
+        if dstep:
+            which, idx = 7, ([2, 3, 5, 6] if arch == 0 else [5, 6])
+        else:
+            which = 6
+            idx = ([0, 1, 4, 7] + fmA + fmB) if arch == 0 else (([0, 7] if arch == 1 else [7]) + fmB)
+        idx = tuple(idx)
+        (gen_loss_A, gen_loss_B, fm_loss_A, fm_loss_B, dis_loss_A, dis_loss_B, gen_loss, dis_loss) = \
+            F_.LossMixFn.apply(lv, nfm, rate, arch, which, idx, *[terms[i] for i in idx])
+        recon_loss_A, recon_loss_B = terms[0], terms[1]
         return SimpleNamespace(
             gen_loss=gen_loss, dis_loss=dis_loss, gen_loss_A=gen_loss_A, gen_loss_B=gen_loss_B,
             fm_loss_A=fm_loss_A, fm_loss_B=fm_loss_B, recon_loss_A=recon_loss_A, recon_loss_B=recon_loss_B,
             dis_loss_A=dis_loss_A, dis_loss_B=dis_loss_B, AB=AB, BA=BA, ABA=ABA, BAB=BAB,
             A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
-            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake)
+            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
 
     def _fwd_bwd(self, A, B, iters):
         dstep = self.is_dis_step(iters)
@@ -205,7 +225,7 @@ class DiscoGANTrainer:
         from . import functional as _F
         _F.WGRAD_STREAM = self.wgrad_stream
         try:
-            (out.dis_loss if dstep else out.gen_loss).backward()
+            (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
         if self.async_wgrad:

@@ -170,6 +170,14 @@ int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff
               void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);
 
+/* Curriculum loss mix (image_translation.py:162-166,367-382) over a vector of loss scalars, and the
+ * gradient seeds of every term, each in ONE launch.  lossvec: [0,1] recon A,B; [2..4] BCE(D_A real,1),
+ * BCE(D_A fake,0), BCE(D_A fake,1); [5..7] same for D_B; [8..8+nfm) FM layers of D_A; [8+nfm..8+2nfm) of D_B.
+ * out8: gen_loss_A, gen_loss_B, fm_loss_A, fm_loss_B, dis_loss_A, dis_loss_B, gen_loss, dis_loss.
+ * arch 0 discogan, 1 recongan, 2 gan.  which: 6 = backward of gen_loss, 7 = backward of dis_loss. */
+int dg_loss_mix_fwd(const float* lossvec, float* out8, int nfm, float rate, int arch, dg_stream_t s);
+int dg_loss_mix_bwd(const float* gout, float* gvec, int nfm, float rate, int arch, int which, dg_stream_t s);
+
 /* ---- Adam over flat buffers (optim.Adam, image_translation.py:275-287) ------------------------
  * state (device, 4 x float64): [0] step count, [1] lr/(1-b1^t), [2] sqrt(1-b2^t), [3] spare.
  * dg_adam_advance increments the step and refreshes the scalars ON DEVICE (graph-capturable).

@@ -291,6 +291,38 @@ def test_feature_matching(N, C, H):
     close(dfake, fr.grad, rtol=1e-4, atol=1e-10, what="fm dfake")
 
 
+@pytest.mark.parametrize("arch", [0, 1, 2])
+@pytest.mark.parametrize("rate", [0.01, 0.5])
+def test_loss_mix(arch, rate):
+    """dg_loss_mix_fwd/bwd against the reference's scalar arithmetic (image_translation.py:162-166, 367-382),
+    bit-exact forward (same fp32 operations in the same order), exact seeds."""
+    nfm = 3
+    lv = torch.rand(8 + 2 * nfm, dtype=torch.float32) + 0.1
+    t = lv.clone().requires_grad_(True)
+    fmA = 0
+    fmB = 0
+    for l in range(nfm):
+        fmA = fmA + t[8 + l]
+        fmB = fmB + t[8 + nfm + l]
+    disA, disB = (t[2] + t[3]) * 0.5, (t[5] + t[6]) * 0.5
+    genA, genB = t[4], t[7]
+    totA = (fmB * 0.9 + genB * 0.1) * (1 - rate) + t[0] * rate
+    totB = (fmA * 0.9 + genA * 0.1) * (1 - rate) + t[1] * rate
+    if arch == 0:
+        gen, dis = totA + totB, disA + disB
+    elif arch == 1:
+        gen, dis = totA, disB
+    else:
+        gen, dis = genB * 0.1 + fmB * 0.9, disB
+    out = ops.loss_mix_fwd(lv.to(DEV), nfm, rate, arch).cpu()
+    ref = torch.stack([genA, genB, fmA, fmB, disA, disB, gen, dis]).detach()
+    assert torch.allclose(out, ref, rtol=2e-7, atol=0), (out, ref)
+    for which, loss in ((6, gen), (7, dis)):
+        (g,) = torch.autograd.grad(loss * 1.5, t, retain_graph=True)
+        gv = ops.loss_mix_bwd(torch.tensor([1.5], device=DEV), lv.numel(), nfm, rate, arch, which).cpu()
+        assert torch.allclose(gv, g, rtol=2e-7, atol=0), (which, gv, g)
+
+
 def test_adam_flat_matches_torch():
     """Op-wise Adam parity with oracle gradients over several steps."""
     from discogan_modernized_amd import optim
