@@ -63,6 +63,9 @@ SIGNATURES = {
     "dg_fm_workspace_bytes": (_z, [_i, _z]),
     "dg_fm_fwd": (_i, [_p, _p, _i, _z, _p, _p, _p, _z, _p]),
     "dg_fm_bwd": (_i, [_p, _i, _z, _p, _p, _p, _p]),
+    "dg_stream_create_cu_mask": (_i, [_p, _i, _p]),
+    "dg_stream_destroy": (_i, [_p]),
+    "dg_device_cu_count": (_i, []),
     "dg_loss_mix_fwd": (_i, [_p, _p, _i, _f, _i, _p]),
     "dg_loss_mix_bwd": (_i, [_p, _p, _i, _f, _i, _i, _p]),
     "dg_adam_advance": (_i, [_p, _d, _d, _d, _p]),

@@ -28,6 +28,28 @@ extern "C" int dg_set_option(const char* name, int value) {
     return DG_OK;
 }
 
+// HIP streams restricted to a subset of the compute units (one bit per CU, 32 per word).  The trainer gives
+// each of its two independent network chains half of the chip (trainer.py: cu_partition).
+extern "C" int dg_stream_create_cu_mask(const uint32_t* mask, int nwords, dg_stream_t* out) {
+    if (!mask || nwords < 1 || !out) return dg_fail(DG_ERR_INVALID, "dg_stream_create_cu_mask: bad argument");
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+    if (e != hipSuccess) return dg_fail(DG_ERR_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    *out = (dg_stream_t)s;
+    return DG_OK;
+}
+extern "C" int dg_stream_destroy(dg_stream_t s) {
+    hipError_t e = hipStreamDestroy((hipStream_t)s);
+    if (e != hipSuccess) return dg_fail(DG_ERR_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+    return DG_OK;
+}
+extern "C" int dg_device_cu_count(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}
+
 // 32x32 tile transpose through LDS between the [C] and [H*W] axes of one image
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int Cn) {
     // x: [B][R][Cn] -> y: [B][Cn][R]

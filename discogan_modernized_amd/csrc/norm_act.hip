@@ -10,27 +10,37 @@
 //             dbeta = sum g, dgamma = sum g*xhat, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
 #include "dg_common.h"
 
-#define BN_TX 32  // float4 lanes along channels -> 128 channels per block
-#define BN_TY 8   // row lanes
+#define BN_U 4     // independent row loads in flight per thread (HBM latency x bandwidth needs ~64 KB per CU)
 
 __device__ __forceinline__ float bn_norm(float y, float mean, float gs, float beta) { return fmaf(y - mean, gs, beta); }
 
-static void bn_grid(int M, int C, int* cchunks, int* rchunks) {
-    *cchunks = (C + 4 * BN_TX - 1) / (4 * BN_TX);
-    int rc = 1024 / *cchunks;
-    if (rc > 256) rc = 256;  // the finalize kernels walk this many partials per channel
-    int maxrc = (M + BN_TY - 1) / BN_TY;  // at least one row per row-lane
-    if (rc > maxrc) rc = maxrc;
+// Reduction-pass geometry: a 256-thread block is TX float4 lanes along channels x TY = 256/TX row lanes, with
+// TX = the power of two covering C/4 (capped at 64), so every thread is busy for C = 64 as for C = 512.
+// grid = (cchunks, rchunks); each block walks rows r0 + ty + k*TY of its row chunk.
+struct BnGrid { int tx, ty, cchunks, rchunks; };
+static BnGrid bn_grid(int M, int C) {
+    BnGrid g;
+    int q = C / 4, tx = 1;
+    while (tx < q && tx < 64) tx <<= 1;
+    g.tx = tx;
+    g.ty = 256 / tx;
+    g.cchunks = (q + tx - 1) / tx;
+    int rc = M / (g.ty * BN_U);            // at least one unrolled trip per row lane
+    int cap = 2048 / g.cchunks;
+    if (cap > 512) cap = 512;              // the finalize kernels walk this many partials per channel
+    if (rc > cap) rc = cap;
     if (rc < 1) rc = 1;
-    *rchunks = rc;
+    g.rchunks = rc;
+    return g;
 }
 
 // part layout: [2][rchunks][C]  (0: sum of (y - shift), 1: sum of (y - shift)^2; shift = y[row 0])
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
-                                                               int M, int C, int rchunks) {
-    __shared__ f32x4 red[2][BN_TY][BN_TX];
-    const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
-    const int c = (blockIdx.x * BN_TX + tx) * 4;
+                                                               int M, int C, int rchunks, int TX) {
+    __shared__ f32x4 red[2][256];
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
     const int rows_per = (M + rchunks - 1) / rchunks;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
@@ -38,23 +48,38 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         // shifted sums: d = y - y[row 0]; var = E[d^2] - E[d]^2 has no catastrophic cancellation
         // because the shift is itself a sample of the channel (|mean - shift| ~ std).
         const f32x4 sh = *(const f32x4*)(y + c);
-        for (int r = r0 + ty; r < r1; r += BN_TY) {
-            const f32x4 d = *(const f32x4*)(y + (long)r * C + c) - sh;
+        const float* p = y + c;
+        int r = r0 + ty;
+        for (; r + (BN_U - 1) * TY < r1; r += BN_U * TY) {
+            f32x4 v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) v[u] = *(const f32x4*)(p + (long)(r + u * TY) * C);
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const f32x4 d = v[u] - sh;
+                s += d;
+                q += d * d;
+            }
+        }
+        for (; r < r1; r += TY) {
+            const f32x4 d = *(const f32x4*)(p + (long)r * C) - sh;
             s += d;
             q += d * d;
         }
     }
-    red[0][ty][tx] = s;
-    red[1][ty][tx] = q;
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
     __syncthreads();
-    if (ty == 0 && c < C) {
-#pragma unroll
-        for (int j = 1; j < BN_TY; ++j) {
-            s += red[0][j][tx];
-            q += red[1][j][tx];
+    for (int h = TY >> 1; h > 0; h >>= 1) {     // fixed-order tree over the row lanes
+        if (ty < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h * TX];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h * TX];
         }
-        *(f32x4*)(part + (long)blockIdx.y * C + c) = s;
-        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
+        __syncthreads();
+    }
+    if (ty == 0 && c < C) {
+        *(f32x4*)(part + (long)blockIdx.y * C + c) = red[0][tx];
+        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = red[1][tx];
     }
 }
 
@@ -187,41 +212,57 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // part layout (fp64): [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                                             double* __restrict__ part, int M, int C, int rchunks,
+                                                             double* __restrict__ part, int M, int C, int rchunks, int TX,
                                                              const float* __restrict__ saved, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope) {
-    __shared__ f64x4 red[2][BN_TY][BN_TX];
-    const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
-    const int c = (blockIdx.x * BN_TX + tx) * 4;
+    __shared__ f64x4 red[2][256];
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * 4;
     const int rows_per = (M + rchunks - 1) / rchunks;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     f64x4 s = {0., 0., 0., 0.}, q = {0., 0., 0., 0.};
     if (c < C) {
         const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
         const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        for (int r = r0 + ty; r < r1; r += BN_TY) {
-            const f32x4 v = *(const f32x4*)(y + (long)r * C + c);
-            const f32x4 d = *(const f32x4*)(dz + (long)r * C + c);
+        const f32x4 gs = g * istd;
+        auto acc = [&](const f32x4& v, const f32x4& d) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float u = bn_norm(v[j], mean[j], g[j] * istd[j], b[j]);
+                const float u = bn_norm(v[j], mean[j], gs[j], b[j]);
                 const double gg = (double)(d[j] * act_grad(u, act, slope));
                 s[j] += gg;
                 q[j] += gg * (((double)v[j] - (double)mean[j]) * (double)istd[j]);
             }
-        }
-    }
-    red[0][ty][tx] = s;
-    red[1][ty][tx] = q;
-    __syncthreads();
-    if (ty == 0 && c < C) {
+        };
+        const float* py = y + c;
+        const float* pd = dz + c;
+        int r = r0 + ty;
+        for (; r + (BN_U - 1) * TY < r1; r += BN_U * TY) {
+            f32x4 v[BN_U], d[BN_U];
 #pragma unroll
-        for (int j = 1; j < BN_TY; ++j) {
-            s += red[0][j][tx];
-            q += red[1][j][tx];
+            for (int u = 0; u < BN_U; ++u) {
+                v[u] = *(const f32x4*)(py + (long)(r + u * TY) * C);
+                d[u] = *(const f32x4*)(pd + (long)(r + u * TY) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) acc(v[u], d[u]);
         }
-        *(f64x4*)(part + (long)blockIdx.y * C + c) = s;
-        *(f64x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = q;
+        for (; r < r1; r += TY) acc(*(const f32x4*)(py + (long)r * C), *(const f32x4*)(pd + (long)r * C));
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int h = TY >> 1; h > 0; h >>= 1) {
+        if (ty < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h * TX];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h * TX];
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && c < C) {
+        *(f64x4*)(part + (long)blockIdx.y * C + c) = red[0][tx];
+        *(f64x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = red[1][tx];
     }
 }
 
@@ -325,9 +366,8 @@ static int stream_grid(long total4) {
 }
 
 extern "C" size_t dg_bn_workspace_bytes(int M, int C) {
-    int cc, rc;
-    bn_grid(M, C, &cc, &rc);
-    return ((size_t)2 * rc * C + 2 * (size_t)C) * sizeof(double);   // fp64 partials in the backward
+    const BnGrid g = bn_grid(M, C);
+    return ((size_t)2 * g.rchunks * C + 2 * (size_t)C) * sizeof(double);   // fp64 partials in the backward
 }
 
 extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
@@ -338,10 +378,10 @@ extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float 
     DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_train_stats: C=%d must be a multiple of 4", C);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
         return dg_fail(DG_ERR_WORKSPACE, "dg_bn_train_stats: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
-    int cc, rc;
-    bn_grid(M, C, &cc, &rc);
+    const BnGrid g = bn_grid(M, C);
+    const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc, g.tx);
     DG_CHECK_LAUNCH("bn_stats_partial");
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
                        momentum, running_mean, running_var, nbt, saved);
@@ -381,12 +421,12 @@ extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, 
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
         return dg_fail(DG_ERR_WORKSPACE, "dg_bn_act_bwd: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
-    int cc, rc;
-    bn_grid(M, C, &cc, &rc);
+    const BnGrid g = bn_grid(M, C);
+    const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
     double* coef = part + (size_t)2 * rc * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, saved, gamma, beta, act, slope);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, g.tx, saved, gamma, beta, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_partial");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const double*)part, M, C, rc, coef,
                        dgamma, dbeta, accumulate);

@@ -44,7 +44,8 @@ def default_args(**over):
 
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
-                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False):
+                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
+                 cu_partition=None):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -80,6 +81,13 @@ class DiscoGANTrainer:
         # stream, which keeps its two calls per iteration (and its BN running-stat updates) ordered.
         self.two_streams = two_streams
         self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
+        # cu_partition: give each chain its own half of the compute units (CU-masked HIP streams) instead of
+        # letting two full-chip queues time-slice.  "xcd": XCDs 0-3 | 4-7, "half": CUs 0-127 | 128-255.
+        self.cu_partition = cu_partition if two_streams else None
+        self.part_main = None
+        if self.cu_partition:
+            self.side_stream, self.part_main = self._masked_streams(self.cu_partition)
+            self.use_graph = False                        # hipGraph kernel nodes do not carry a CU mask
         self._one = torch.ones((), device=self.device, dtype=torch.float32)
         # optional: weight-gradient kernels on a third stream (functional.WGRAD_STREAM), off the backward
         # critical path.  Bitwise neutral; measured 15.04 vs 14.80 ms/step (eager, 64 px) -> off by default.
@@ -97,6 +105,27 @@ class DiscoGANTrainer:
         self._ev_dis_ready = None
         if self.overlap_comm:
             self.use_graph = False
+
+    def _masked_streams(self, mode):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        ncu = lib.dg_device_cu_count()
+        nw = (ncu + 31) // 32
+        if mode == "xcd":          # CU index i sits on XCD i % 8
+            lo = [0x0F0F0F0F] * nw
+        elif mode == "half":
+            lo = [0xFFFFFFFF if w < nw // 2 else 0 for w in range(nw)]
+        else:
+            raise ValueError(f"cu_partition must be 'xcd' or 'half', got {mode!r}")
+        hi = [(~w) & 0xFFFFFFFF for w in lo]
+        streams = []
+        for words in (lo, hi):
+            arr = (ctypes.c_uint32 * nw)(*words)
+            h = ctypes.c_void_p()
+            _lib.check(lib.dg_stream_create_cu_mask(arr, nw, ctypes.byref(h)), "dg_stream_create_cu_mask")
+            streams.append(torch.cuda.ExternalStream(h.value, device=self.device))
+        return streams
 
     # ---------------------------------------------------------------------------------------------
     def active_ranges(self, dstep):
@@ -259,6 +288,13 @@ class DiscoGANTrainer:
 
     def train_iteration(self, A, B, iters, do_step=True):
         """One full iteration; returns the namespace of (device) loss scalars."""
+        if self.part_main is not None and torch.cuda.current_stream(self.device) != self.part_main:
+            caller = torch.cuda.current_stream(self.device)
+            self.part_main.wait_stream(caller)
+            with torch.cuda.stream(self.part_main):
+                out = self.train_iteration(A, B, iters, do_step)
+            caller.wait_stream(self.part_main)
+            return out
         dstep = self.is_dis_step(iters)
         opt = self.optim_dis if dstep else self.optim_gen
         if self.use_graph and iters >= self.args.update_interval:   # first cycle runs eagerly (warm-up)

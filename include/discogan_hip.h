@@ -170,6 +170,13 @@ int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff
               void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);
 
+/* Streams restricted to a subset of the compute units (mask: one bit per CU, 32 per word): the host layer
+ * runs its two independent network chains (G_A/D_A and G_B/D_B, image_translation.py:342-365) on disjoint
+ * halves of the chip.  Host plumbing, no reference counterpart. */
+int dg_stream_create_cu_mask(const uint32_t* mask, int nwords, dg_stream_t* out);
+int dg_stream_destroy(dg_stream_t s);
+int dg_device_cu_count(void);
+
 /* Curriculum loss mix (image_translation.py:162-166,367-382) over a vector of loss scalars, and the
  * gradient seeds of every term, each in ONE launch.  lossvec: [0,1] recon A,B; [2..4] BCE(D_A real,1),
  * BCE(D_A fake,0), BCE(D_A fake,1); [5..7] same for D_B; [8..8+nfm) FM layers of D_A; [8+nfm..8+2nfm) of D_B.

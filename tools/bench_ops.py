@@ -84,17 +84,19 @@ def main():
     t3 = timeit(lambda: ops.c3_wgrad(dy, x))
     mb = (x.numel() + dy.numel()) * 4 / 1e6
     print(f"edge c3    3->{K:4d} @{S:3d}       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}   ({mb:.0f} MB -> {mb / t1 / 1e3:.2f}/{mb / t2 / 1e3:.2f}/{mb / t3 / 1e3:.2f} TB/s)")
-    # BN + act streaming
-    C, H = ch[1], S // 4
-    y = ops.empty_nhwc(N, C, H, H, dev).normal_()
-    dz = ops.empty_nhwc(N, C, H, H, dev).normal_()
-    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-    saved = ops.bn_train_stats(y, None, None, None, 1e-5, 0.1)
-    mbt = y.numel() * 4 / 1e6
-    t1 = timeit(lambda: ops.bn_train_stats(y, None, None, None, 1e-5, 0.1))
-    t2 = timeit(lambda: ops.bn_act_fwd(y, saved, g, b, ops.ACT_LEAKY, 0.2))
-    t3 = timeit(lambda: ops.bn_act_bwd(dz, y, saved, g, b, ops.ACT_LEAKY, 0.2))
-    print(f"bn [{N}x{H}x{H}x{C}] {mbt:.0f} MB: stats {t1:.3f} ms ({mbt / t1 / 1e3:.2f} TB/s)  apply {t2:.3f} ms ({2 * mbt / t2 / 1e3:.2f} TB/s)  bwd {t3:.3f} ms ({5 * mbt / t3 / 1e3:.2f} TB/s)")
+    # BN + act streaming, every BN shape of the nets (decoder 64ch @S/2 ... bottleneck)
+    for C, H in [(ch[0], S // 2)] + [(ch[i], S // (4 << (i - 1))) for i in range(1, len(ch))]:
+        if H < 1:
+            continue
+        y = ops.empty_nhwc(N, C, H, H, dev).normal_()
+        dz = ops.empty_nhwc(N, C, H, H, dev).normal_()
+        g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        saved = ops.bn_train_stats(y, None, None, None, 1e-5, 0.1)
+        mbt = y.numel() * 4 / 1e6
+        t1 = timeit(lambda: ops.bn_train_stats(y, None, None, None, 1e-5, 0.1))
+        t2 = timeit(lambda: ops.bn_act_fwd(y, saved, g, b, ops.ACT_LEAKY, 0.2))
+        t3 = timeit(lambda: ops.bn_act_bwd(dz, y, saved, g, b, ops.ACT_LEAKY, 0.2))
+        print(f"bn [{N}x{H}x{H}x{C}] {mbt:.0f} MB: stats {t1:.3f} ms ({mbt / t1 / 1e3:.2f} TB/s)  apply {t2:.3f} ms ({2 * mbt / t2 / 1e3:.2f} TB/s)  bwd {t3:.3f} ms ({5 * mbt / t3 / 1e3:.2f} TB/s)")
     print(f"interior totals: {totf:.1f} GFLOP each dir | fwd {tot['fwd']:.3f} ms ({totf / tot['fwd']:.1f} TF/s) dgrad {tot['dgrad']:.3f} ms ({totf / tot['dgrad']:.1f}) wgrad {tot['wgrad']:.3f} ms ({totf / tot['wgrad']:.1f})")
 
 
