@@ -12,6 +12,9 @@
 //       streams its own pixel range with operands loaded straight into MFMA registers (no LDS, no
 //       barriers); per-wave partial slabs are summed by a fixed-order reduction kernel (deterministic).
 #include "dg_common.h"
+#include <type_traits>
+
+__device__ float dg_zero_edge[64];   // zero-initialised; masked lanes read from here instead of branching
 
 // Taps per output parity (conv k4 s2 p1): p=0 -> (r=1, d=0), (r=3, d=-1);  p=1 -> (r=2, d=0), (r=0, d=+1).
 __device__ __forceinline__ int tap_of(int parity, int d) {
@@ -207,6 +210,129 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
     return DG_OK;
 }
 
+// ---- forward, K == 64: per-wave streaming on v_mfma_f32_32x32x2_f32 ---------------------------------------
+// y[pix][k] = act(sum_{c,r,q} x[n,c,2oy-1+r,2ox-1+q] * w[k][c][r][q]).  A group is 32 consecutive output pixels
+// (one output row at 64 px); a wave owns whole groups.  MFMA A operand (pixel = lane%32, k-half = lane/32) is
+// gathered straight from the NCHW image: GEMM-k step s = (c, r, j) and lane half h read column q = 2j+h, so the
+// 64 lanes of one load cover 64 consecutive input floats (fully coalesced, every byte used).  The B operand
+// (the [48][64] weights) lives in 48 registers per lane for the whole kernel; the next group's 24 image values
+// are prefetched under the current group's 48 MFMAs.  LDS only stages the weights once; no barriers after that.  Stores: 32 lanes write the 32
+// consecutive channels of one pixel (128 B).
+#define CF_K 64
+#define CF_S 24            // GEMM-k steps of 2
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
+                                                             long npix, int ngroups, float slope, int xbytes) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const float* const zp = dg_zero_edge;
+    // weights: coalesced copy to LDS ([64][49], odd stride: conflict-free column reads), then 48 registers per lane
+    __shared__ float wS[CF_K * 49];
+    for (int e = threadIdx.x; e < CF_K * 48; e += 256) wS[(e / 48) * 49 + e % 48] = w[e];
+    __syncthreads();
+    float wb[2][CF_S];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int s = 0; s < CF_S; ++s) {
+            const int c = s >> 3, r = (s >> 1) & 3, q = 2 * (s & 1) + h;
+            wb[nb][s] = wS[(nb * 32 + p) * 49 + c * 16 + r * 4 + q];
+        }
+    float a[2][CF_S];
+    // image gathers: raw buffer loads, 32-bit byte offsets; an invalid row / column / pixel pushes the offset
+    // past the descriptor's range and the hardware returns 0 (no per-load select, 8 adds per 24 loads)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+    const int HW4 = H * W * 4;
+    constexpr int BIG = 0x40000000;
+    auto gather = [&](int g, float* dst) {
+        const int pix = g * 32 + p;
+        const bool okp = g < ngroups && pix < (int)npix;
+        const int ox = pix & (Wo - 1), oy = (pix >> lgWo) & (Ho - 1), n = pix >> (lgWo + lgHo);
+        const int base = n * 3 * HW4;
+        int colb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ix = 2 * ox - 1 + 2 * j + h;
+            colb[j] = (unsigned)ix < (unsigned)W ? ix * 4 : BIG;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = 2 * oy - 1 + r;
+            const int rowb = (okp && (unsigned)iy < (unsigned)H) ? base + iy * W * 4 : BIG;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int voff = rowb + colb[j];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    dst[c * 8 + r * 2 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, c * HW4, 0));
+            }
+        }
+    };
+    int g = wave;
+    if (g < ngroups) gather(g, a[0]);
+    auto body = [&](auto PB, int gcur) {
+        constexpr int P = decltype(PB)::value;
+        gather(gcur + nwaves, a[P ^ 1]);          // prefetch (masked to zero-block reads past the end)
+        f32x16 acc0 = {0.f}, acc1 = {0.f};
+#pragma unroll
+        for (int s = 0; s < CF_S; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[P][s], wb[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[P][s], wb[1][s], acc1, 0, 0, 0);
+        }
+        const long pix0 = (long)gcur * 32;
+        float* o = y + (pix0 + h * 4) * CF_K + p;
+        if (pix0 + 32 <= npix) {                  // whole group in range (wave-uniform): straight-line stores
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                o[i * CF_K] = dg_apply_act(acc0[v], ACT, slope);
+                o[i * CF_K + 32] = dg_apply_act(acc1[v], ACT, slope);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                if (pix0 + h * 4 + i < npix) {
+                    o[i * CF_K] = dg_apply_act(acc0[v], ACT, slope);
+                    o[i * CF_K + 32] = dg_apply_act(acc1[v], ACT, slope);
+                }
+            }
+        }
+    };
+    for (; g < ngroups; g += 2 * nwaves) {
+        body(std::integral_constant<int, 0>{}, g);
+        if (g + nwaves < ngroups) body(std::integral_constant<int, 1>{}, g + nwaves);
+    }
+}
+
+extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int act,
+                                     float slope, hipStream_t st) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long npix = (long)N * Ho * Wo;
+    const long ngroups = (npix + 31) / 32;
+    if (ngroups >= (1L << 30)) return dg_fail(DG_ERR_INVALID, "dg_conv4x4s2_c3_fwd: too many pixels");
+    // 8 groups per wave and one workgroup per CU (96 KB of LDS reserved so the dispatcher spreads the grid):
+    // measured 26 us vs 34 us at 4 groups / 2 workgroups per CU (256 x 3 x 64 x 64 -> 64 ch); the fixed
+    // per-workgroup prologue (weights, first gather) is what the longer waves amortise
+    long wgs = (ngroups + 31) / 32;
+    if (wgs > 4096) wgs = 4096;
+    if (wgs < 1) wgs = 1;
+#define CF_LAUNCH(ACT)                                                                                              \
+    { static const hipError_t once = hipFuncSetAttribute((const void*)c3_fwd_mfma_kernel<ACT>,                         \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      \
+      (void)once; }                                                                                                     \
+    hipLaunchKernelGGL(c3_fwd_mfma_kernel<ACT>, dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W,     \
+                       dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
+    if (act == DG_ACT_LEAKY) { CF_LAUNCH(DG_ACT_LEAKY); }
+    else if (act == DG_ACT_RELU) { CF_LAUNCH(DG_ACT_RELU); }
+    else { CF_LAUNCH(DG_ACT_NONE); }
+#undef CF_LAUNCH
+    return DG_OK;
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------
 // dw[k][c][r][s] (+)= sum_{pixels} dy[pix][k] * x[n,c,2oy-1+r,2ox-1+s]
 // Each wave streams its own pixels: the MFMA A operand dy^T[k][pixel] and the B operand
@@ -214,7 +340,6 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
 // = 128 B; B: each lane owns a fixed (c,r,s) and gathers from the NCHW image), 8 k-steps (16 pixels) per
 // batch, two batches in flight.  No LDS, no barriers; masked lanes read a zero block.
 #define CW_B 8       // k-steps (of 2 pixels) per batch
-__device__ float dg_zero_edge[64];   // zero-initialised; masked lanes read [0] and [32] from here
 __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ part, int N, int H, int W, int K,
                                                                int lgHo, int lgWo, long npix, int pix_per_wave) {

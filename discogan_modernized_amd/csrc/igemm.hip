@@ -846,6 +846,8 @@ extern "C" int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw
     return dg_conv_wgrad(x, dy, dw, N, 4, 4, Cout, Cin, 1, 0, acc, ws, wsb, s);
 }
 
+extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int act,
+                                     float slope, hipStream_t st);   // edge.hip
 // ---- 3-channel image side, forward direction (conv1 forward / last-convT input-grad) ----------------
 extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
                                    int act, float slope, dg_stream_t stream) {
@@ -854,6 +856,13 @@ extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd: H,W must be powers of two");
     DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_fwd: tensor too large");
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd: bad act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 64 && dg_get_option(DG_OPT_KT) != 16 && (long)N * 3 * H * W * 4 < (1L << 30) && (long)N * (H / 2) * (W / 2) < (1L << 30)) {       // streaming per-wave kernel (edge.hip); kt=16 forces the tiled path
+        int rc = dg_c3_fwd_mfma_launch(x_nchw, w, y_nhwc, N, H, W, act, slope, st);
+        if (rc != DG_OK) return rc;
+        DG_CHECK_LAUNCH("dg_conv4x4s2_c3_fwd");
+        return DG_OK;
+    }
     IgemmArgs a = IgemmArgs();
     a.A = x_nchw; a.B = w; a.C = y_nhwc;
     a.N = N; a.H = H; a.W = W; a.Cc = 3; a.K = K;
@@ -862,7 +871,6 @@ extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y
     a.M = N * a.Ho * a.Wo; a.Ng = K; a.R = 48;
     a.nIt = 3; a.itPerSplit = 3; a.splits = 1;
     a.act = act; a.slope = slope;
-    hipStream_t st = (hipStream_t)stream;
     if (K <= 64) {
         a.tilesM = (a.M + 255) / 256; a.tilesN = 1;
         launch_igemm<MODE_FWD_C3, 4, 1, 16>(a, 1, st);

