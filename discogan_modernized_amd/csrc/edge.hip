@@ -340,9 +340,14 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float*
 // = 128 B; B: each lane owns a fixed (c,r,s) and gathers from the NCHW image), 8 k-steps (16 pixels) per
 // batch, two batches in flight.  No LDS, no barriers; masked lanes read a zero block.
 #define CW_B 8       // k-steps (of 2 pixels) per batch
+// BUF: both tensors < 1 GiB -> raw buffer loads with 32-bit offsets, masked lanes read out of range (= 0).
+// FACT: the dy operand is taken through the backward of the layer's fused LeakyReLU/ReLU on the fly
+//       (dy * act'(act_out), act_out = the saved forward output), instead of a separate act_bwd pass.
+template <bool BUF, bool FACT>
 __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ part, int N, int H, int W, int K,
-                                                               int lgHo, int lgWo, long npix, int pix_per_wave) {
+                                                               int lgHo, int lgWo, long npix, int pix_per_wave,
+                                                               const float* __restrict__ act_out, float slope) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -374,22 +379,58 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
     const float* dyk = dy + kg * 64 + l31;
 
     float fa[2][CW_B][2], fb[2][CW_B][2];
+    constexpr int BIG = 0x40000000;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, BUF ? (int)(npix * K * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, BUF ? (int)(npix * K * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, BUF ? N * 3 * H * W * 4 : 0, 0x00020000);
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, int off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    };
     auto load_batch = [&](int set, long p0) {
 #pragma unroll
         for (int st = 0; st < CW_B; ++st) {
-            const long pp = p0 + 2 * st + lh;
-            const bool pok = pp < p_end;
-            const int ox = (int)(pp & (Wo - 1)), oy = (int)((pp >> lgWo) & (Ho - 1)), n = (int)(pp >> (lgWo + lgHo));
-            const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
-            const long xb = ((long)n * 3 * H + iy0) * W + ix0;
-            const float* ap = pok ? dyk + pp * K : zp;
-            fa[set][st][0] = ap[0];
-            fa[set][st][1] = ap[32];
+            if constexpr (BUF) {
+                const int pp = (int)p0 + 2 * st + lh;
+                const bool pok = pp < (int)p_end;
+                const int ox = pp & (Wo - 1), oy = (pp >> lgWo) & (Ho - 1), n = pp >> (lgWo + lgHo);
+                const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+                const int xb = (n * 3 * H + iy0) * W + ix0;
+                const int aoff = pok ? (pp * K + kg * 64 + l31) * 4 : BIG;
+                float a0 = bload(rdy, aoff), a1 = bload(rdy, aoff + 128);
+                if constexpr (FACT) {
+                    const float o0 = bload(rao, aoff), o1 = bload(rao, aoff + 128);
+                    a0 = o0 > 0.f ? a0 : a0 * slope;
+                    a1 = o1 > 0.f ? a1 : a1 * slope;
+                }
+                fa[set][st][0] = a0;
+                fa[set][st][1] = a1;
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                const bool ok = pok && jok[jn] && (unsigned)(iy0 + jr[jn]) < (unsigned)H && (unsigned)(ix0 + js[jn]) < (unsigned)W;
-                const float* bp = ok ? x + xb + joff[jn] : zp;
-                fb[set][st][jn] = *bp;
+                for (int jn = 0; jn < 2; ++jn) {
+                    const bool ok = pok && jok[jn] && (unsigned)(iy0 + jr[jn]) < (unsigned)H && (unsigned)(ix0 + js[jn]) < (unsigned)W;
+                    fb[set][st][jn] = bload(rx, ok ? (xb + (int)joff[jn]) * 4 : BIG);
+                }
+            } else {
+                const long pp = p0 + 2 * st + lh;
+                const bool pok = pp < p_end;
+                const int ox = (int)(pp & (Wo - 1)), oy = (int)((pp >> lgWo) & (Ho - 1)), n = (int)(pp >> (lgWo + lgHo));
+                const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+                const long xb = ((long)n * 3 * H + iy0) * W + ix0;
+                const float* ap = pok ? dyk + pp * K : zp;
+                float a0 = ap[0], a1 = ap[32];
+                if constexpr (FACT) {
+                    const float* op = pok ? act_out + kg * 64 + l31 + pp * K : zp;
+                    const float o0 = op[0], o1 = op[32];
+                    a0 = o0 > 0.f ? a0 : a0 * slope;
+                    a1 = o1 > 0.f ? a1 : a1 * slope;
+                }
+                fa[set][st][0] = a0;
+                fa[set][st][1] = a1;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const bool ok = pok && jok[jn] && (unsigned)(iy0 + jr[jn]) < (unsigned)H && (unsigned)(ix0 + js[jn]) < (unsigned)W;
+                    const float* bp = ok ? x + xb + joff[jn] : zp;
+                    fb[set][st][jn] = *bp;
+                }
             }
         }
     };
@@ -463,20 +504,43 @@ extern "C" size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K) {
     c3_wgrad_plan(npix, &nb, &ppw);
     return (size_t)nb * K * 48 * sizeof(float);
 }
+static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
+                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                                      int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    DG_CHECK_ARG(dy_nhwc && x_nchw && dw, "dg_conv4x4s2_c3_wgrad: null pointer");
-    DG_CHECK_ARG(N >= 1 && K >= 64 && K % 64 == 0, "dg_conv4x4s2_c3_wgrad: K=%d must be a multiple of 64", K);
-    DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_wgrad: H,W must be powers of two");
-    DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_wgrad: tensor too large");
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad", dy_nhwc, nullptr, DG_ACT_NONE, 0.f, x_nchw, dw, N, H, W, K, accumulate, ws,
+                        ws_bytes, stream);
+}
+extern "C" int dg_conv4x4s2_c3_wgrad_act(const float* dy_nhwc, const float* act_out_nhwc, int act, float slope,
+                                         const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
+                                         void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(act == DG_ACT_NONE || ((act == DG_ACT_LEAKY || act == DG_ACT_RELU) && act_out_nhwc),
+                 "dg_conv4x4s2_c3_wgrad_act: act %d needs the saved activation output (LeakyReLU / ReLU only)", act);
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_act", dy_nhwc, act == DG_ACT_NONE ? nullptr : act_out_nhwc, act,
+                        act == DG_ACT_RELU ? 0.f : slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream);
+}
+static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
+                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(dy_nhwc && x_nchw && dw, "%s: null pointer", who);
+    DG_CHECK_ARG(N >= 1 && K >= 64 && K % 64 == 0, "%s: K=%d must be a multiple of 64", who, K);
+    DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "%s: H,W must be powers of two", who);
+    DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "%s: tensor too large", who);
     const long npix = (long)N * (H / 2) * (W / 2);
     int nb, ppw;
     c3_wgrad_plan(npix, &nb, &ppw);
     const size_t need = (size_t)nb * K * 48 * sizeof(float);
-    if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "dg_conv4x4s2_c3_wgrad: workspace %zu < %zu", ws_bytes, need);
+    if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(c3_wgrad_mfma_kernel, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                       dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw);
+    const bool buf = npix * K * 4 < (1L << 30) && (long)N * 3 * H * W * 4 < (1L << 30);
+    const bool fact = act_out != nullptr;
+#define CW_LAUNCH(B, F)                                                                                                  \
+    hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
+                       K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
+    if (buf && fact) CW_LAUNCH(true, true);
+    else if (buf) CW_LAUNCH(true, false);
+    else if (fact) CW_LAUNCH(false, true);
+    else CW_LAUNCH(false, false);
+#undef CW_LAUNCH
     DG_CHECK_LAUNCH("c3_wgrad_mfma");
     const int total = K * 48;
     hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);

@@ -522,14 +522,41 @@ __global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restric
         *(f32x4*)(dx + (long)n * J + j4 * 4) = b * g;
     }
 }
+// 16 float4 lanes along J x 16 batch lanes; each batch lane walks n = lane, lane+16, ... (4 loads in flight),
+// fixed-order tree over the batch lanes through LDS (deterministic).
 __global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ dw, int N, int J, int accumulate) {
-    const int j4 = blockIdx.x * 256 + threadIdx.x;
-    if (j4 * 4 >= J) return;
+    __shared__ f32x4 red[256];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j4 = blockIdx.x * 16 + tx;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < N; ++n) s += *(const f32x4*)(x + (long)n * J + j4 * 4) * dy[n];
-    if (accumulate) s += *(const f32x4*)(dw + j4 * 4);
-    *(f32x4*)(dw + j4 * 4) = s;
+    if (j4 * 4 < J) {
+        const float* px = x + j4 * 4;
+        int n = ty;
+        for (; n + 48 < N; n += 64) {
+            f32x4 v[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = *(const f32x4*)(px + (long)(n + 16 * u) * J);
+                d[u] = dy[n + 16 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u] * d[u];
+        }
+        for (; n < N; n += 16) s += *(const f32x4*)(px + (long)n * J) * dy[n];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * 16];
+        __syncthreads();
+    }
+    if (ty == 0 && j4 * 4 < J) {
+        f32x4 r = red[tx];
+        if (accumulate) r += *(const f32x4*)(dw + j4 * 4);
+        *(f32x4*)(dw + j4 * 4) = r;
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
@@ -743,7 +770,7 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
     if (K == 1) {
         DG_CHECK_ARG(stride == 1, "dg_conv_wgrad: K==1 only for the 4x4 head");
         const int J = 16 * C;
-        hipLaunchKernelGGL(head1_wgrad_kernel, dim3((J / 4 + 255) / 256), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
+        hipLaunchKernelGGL(head1_wgrad_kernel, dim3((J / 4 + 15) / 16), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
         DG_CHECK_LAUNCH("head1_wgrad");
         return DG_OK;
     }

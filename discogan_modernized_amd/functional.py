@@ -134,15 +134,21 @@ class ConvC3Fn(Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         act, slope = ctx.act
-        g = ops.act_bwd(dy, y, act, slope) if act != ops.ACT_NONE else ops.as_nhwc(dy)
+        if ctx.needs_input_grad[0] or act == ops.ACT_NONE:
+            g = ops.act_bwd(dy, y, act, slope) if act != ops.ACT_NONE else ops.as_nhwc(dy)
+            fuse = {}
+        else:
+            # weight gradient only (image input): the activation backward rides in the wgrad kernel's dy loads
+            g = ops.as_nhwc(dy)
+            fuse = dict(act_out=y, act=act, slope=slope)
         dx = ops.c3_dgrad(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
-                _launch_wgrad(lambda: ops.c3_wgrad(g, x, out=fg, accumulate=True), g, x)
+                _launch_wgrad(lambda: ops.c3_wgrad(g, x, out=fg, accumulate=True, **fuse), g, x)
             else:
-                dw = ops.c3_wgrad(g, x)
+                dw = ops.c3_wgrad(g, x, **fuse)
         return dx, dw, None, None
 
 

@@ -179,8 +179,23 @@ class Sigmoid(_Act):
         super().__init__(0.0, False)
 
 
+def drain(gen):
+    """Run a ``*_steps`` generator to completion and return its value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
 def _run_fused(layers, x):
-    """Walk a list of layer modules fusing [conv][BatchNorm][activation] groups into kernel calls."""
+    return drain(_run_fused_steps(layers, x))
+
+
+def _run_fused_steps(layers, x):
+    """Walk a list of layer modules fusing [conv][BatchNorm][activation] groups into kernel calls.
+    A generator: yields after every group so that a caller can issue two networks layer by layer in lock
+    step (trainer.py); the final activation is the generator's return value."""
     i, n = 0, len(layers)
     while i < n:
         conv = layers[i]
@@ -193,7 +208,9 @@ def _run_fused(layers, x):
             y, st = conv(x, want_stats=FUSE_BN_STATS)       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
-            x = bn(conv(x), act, slope)
+            y = conv(x)
+            yield
+            x = bn(y, act, slope)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
             x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
         elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
@@ -203,6 +220,8 @@ def _run_fused(layers, x):
             if act_mod is not None:
                 x = act_mod(x)
         i = j + (1 if act_mod is not None else 0)
+        if i < n:
+            yield
     return x
 
 
@@ -224,16 +243,24 @@ class Discriminator(_FlatGradMixin, nn.Module):
         self.sigmoid = Sigmoid()
 
     def forward(self, input_tensor):
+        return drain(self.forward_steps(input_tensor))
+
+    def forward_steps(self, input_tensor):
+        """forward() as a generator that yields after every conv(+BN+act) group."""
         feats = []
         h = self.conv1(input_tensor, ops.ACT_LEAKY, self.relu1.negative_slope)
+        yield
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
             if bn.training and FUSE_BN_STATS:
                 y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
-                h = bn(conv(h), ops.ACT_LEAKY, relu.negative_slope)
+                y = conv(h)
+                yield
+                h = bn(y, ops.ACT_LEAKY, relu.negative_slope)
             feats.append(h)
+            yield
         out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))
         return out, feats
 
@@ -265,4 +292,12 @@ class Generator(_FlatGradMixin, nn.Module):
     def forward(self, input_tensor):
         if self.main is not None:
             return self.main(input_tensor)
-        return _run_fused(list(self.decoder), _run_fused(list(self.encoder), input_tensor))
+        return drain(self.forward_steps(input_tensor))
+
+    def forward_steps(self, input_tensor):
+        """forward() as a generator that yields after every conv(+BN+act) group."""
+        if self.main is not None:
+            return self.main(input_tensor)
+        h = yield from _run_fused_steps(list(self.encoder), input_tensor)
+        yield
+        return (yield from _run_fused_steps(list(self.decoder), h))

@@ -19,15 +19,35 @@ ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 PROFILE = None
 
 
+class _MfmaTurns:
+    """Cross-stream turn taking for the MFMA-bound conv kernels.  The trainer issues its two independent network
+    chains layer by layer in lock step on two HIP streams; with ``enabled`` every big conv launch first waits for
+    the previous big conv launch of the OTHER stream, so the chains alternate on the matrix cores
+    (A.conv_l | B.conv_l | A.conv_l+1 ...) and each chain's HBM-bound BatchNorm / reduction kernels run under the
+    other chain's conv instead of both chains idling the matrix cores at the same time."""
+    enabled = False
+    event = None
+    stream = None
+    min_flops = 1e9
+
+
+TURNS = _MfmaTurns()
+
+
 class _prof:
     def __init__(self, name, flops):
         self.on = PROFILE is not None
+        self.turn = TURNS.enabled and flops >= TURNS.min_flops
         if self.on:
             self.name, self.flops = name, flops
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
+        if self.turn:
+            cur = torch.cuda.current_stream()
+            if TURNS.event is not None and TURNS.stream != cur:
+                cur.wait_event(TURNS.event)
         if self.on:
             self.e0.record()
         return self
@@ -36,6 +56,11 @@ class _prof:
         if self.on:
             self.e1.record()
             PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        if self.turn:
+            cur = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            TURNS.event, TURNS.stream = ev, cur
         return False
 
 
@@ -220,8 +245,9 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     return dx
 
 
-def c3_wgrad(dy, x_nchw, out=None, accumulate=False):
-    """dw [K,3,4,4] contiguous from dy NHWC-memory [N,K,Ho,Wo] and x NCHW [N,3,H,W]."""
+def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE, slope=0.0):
+    """dw [K,3,4,4] contiguous from dy NHWC-memory [N,K,Ho,Wo] and x NCHW [N,3,H,W].  With ``act_out`` (the saved
+    output of the layer's fused LeakyReLU/ReLU) dy is taken through the activation backward on the fly."""
     _check_dev(dy, x_nchw)
     dy = as_nhwc(dy)
     x = x_nchw.contiguous()
@@ -230,6 +256,12 @@ def c3_wgrad(dy, x_nchw, out=None, accumulate=False):
     dw = out if out is not None else torch.empty((k, 3, 4, 4), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_wgrad_workspace_bytes(n, h, wd, k), dy.device)
+    if act_out is not None and act != ACT_NONE:
+        ao = as_nhwc(act_out)
+        assert ao.shape == dy.shape
+        _lib.check(L.dg_conv4x4s2_c3_wgrad_act(_ptr(dy), _ptr(ao), act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k,
+                                               int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_act")
+        return dw
     _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, int(accumulate), _ptr(ws), wsb,
                                        _stream()), "dg_conv4x4s2_c3_wgrad")
     return dw

@@ -45,7 +45,7 @@ def default_args(**over):
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
-                 cu_partition=None):
+                 cu_partition=None, mfma_turns=False):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -83,6 +83,9 @@ class DiscoGANTrainer:
         self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
         # cu_partition: give each chain its own half of the compute units (CU-masked HIP streams) instead of
         # letting two full-chip queues time-slice.  "xcd": XCDs 0-3 | 4-7, "half": CUs 0-127 | 128-255.
+        # mfma_turns: the chains take turns on the matrix cores (ops.TURNS).  Measured SLOWER (15.5 vs 14.1 ms at
+        # 64 px / batch 256: a cross-queue event per conv costs more than the overlap it buys) -> off.
+        self.mfma_turns = bool(mfma_turns) and two_streams
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -163,14 +166,43 @@ class DiscoGANTrainer:
         main = torch.cuda.current_stream(self.device)
         side = self.side_stream if self.two_streams else main
         on_side = (lambda: torch.cuda.stream(side)) if self.two_streams else contextlib.nullcontext
+        # loss vector (layout: dg_loss_mix_fwd): allocated BEFORE the fork so that the side stream's writes are
+        # ordered after whatever used this block on the main stream
+        nfm = self.discriminator_A.n_stages - 1
+        lv = torch.empty(8 + 2 * nfm, device=self.device, dtype=torch.float32)
         if self.two_streams:
             side.wait_stream(main)
+            # tensors that cross streams tell the caching allocator (a block is otherwise reusable on its
+            # allocation stream as soon as the host drops it, while the other stream may still read it)
+            for t_ in (A, B, lv):
+                t_.record_stream(side)
+        # The A-side chain (G_A, D_A) is issued on `side`, the B-side chain (G_B, D_B) on `main`, layer by layer
+        # in lock step (model.forward_steps): host issue order A.l1, B.l1, A.l2, B.l2, ...  With ops.TURNS the big
+        # conv kernels then alternate between the streams and each chain's BatchNorm / reduction kernels run
+        # under the other chain's conv.  autograd replays nodes in reverse creation order, so the backward pass
+        # is interleaved the same way.
+        def pair(gen_a, gen_b):
+            ra = rb = pend = object()
+            while ra is pend or rb is pend:
+                if ra is pend:
+                    with on_side():
+                        try:
+                            next(gen_a)
+                        except StopIteration as e:
+                            ra = e.value
+                if rb is pend:
+                    try:
+                        next(gen_b)
+                    except StopIteration as e:
+                        rb = e.value
+            return ra, rb
+
         # stage 1: the two first-stage translations are independent
         with gen_ctx():
-            with on_side():
-                BA = self.generator_A(B)                     # side: G_A
-            AB = self.generator_B(A)                         # main: G_B
+            BA, AB = pair(self.generator_A.forward_steps(B), self.generator_B.forward_steps(A))
         if self.two_streams:
+            AB.record_stream(side)
+            BA.record_stream(main)
             ev_ab, ev_ba = torch.cuda.Event(), torch.cuda.Event()
             ev_ab.record(main)
             ev_ba.record(side)
@@ -181,19 +213,15 @@ class DiscoGANTrainer:
             if self.two_streams:
                 side.wait_event(self._ev_dis_ready)
             self._ev_dis_ready = None
-        # stage 2 + discriminators: A-side chain on `side`, B-side chain on `main`.  Every loss term is written
-        # into its slot of one device vector (layout: dg_loss_mix_fwd); the mix and its gradient seeds are
-        # one launch each instead of ~45 scalar kernels.
-        nfm = None
-        with on_side():
-            with gen_ctx():
-                ABA = self.generator_A(AB)
-            A_dis_real, A_feats_real = self.discriminator_A(A)
-        if nfm is None:
-            nfm = len(A_feats_real)
-        lv = torch.empty(8 + 2 * nfm, device=self.device, dtype=torch.float32)
-        if self.two_streams:
-            lv.record_stream(side)
+        # stage 2 + discriminators.  Every loss term is written into its slot of one device vector (layout:
+        # dg_loss_mix_fwd); the mix and its gradient seeds are one launch each instead of ~45 scalar kernels.
+        with gen_ctx():
+            ABA, BAB = pair(self.generator_A.forward_steps(AB), self.generator_B.forward_steps(BA))
+        (A_dis_real, A_feats_real), (B_dis_real, B_feats_real) = pair(
+            self.discriminator_A.forward_steps(A), self.discriminator_B.forward_steps(B))
+        (A_dis_fake, A_feats_fake), (B_dis_fake, B_feats_fake) = pair(
+            self.discriminator_A.forward_steps(BA), self.discriminator_B.forward_steps(AB))
+        assert nfm == len(A_feats_real)
         sl = [lv[i] for i in range(8 + 2 * nfm)]
         terms = {}
 
@@ -203,15 +231,11 @@ class DiscoGANTrainer:
         with on_side():
             with gen_ctx():
                 terms[0] = F_.MSELossFn.apply(ABA, A, sl[0])
-            A_dis_fake, A_feats_fake = self.discriminator_A(BA)
             bce(A_dis_real, 1.0, 2); bce(A_dis_fake, 0.0, 3); bce(A_dis_fake, 1.0, 4)
             for l, (r, f) in enumerate(zip(A_feats_real, A_feats_fake)):
                 terms[8 + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + l])
         with gen_ctx():
-            BAB = self.generator_B(BA)
             terms[1] = F_.MSELossFn.apply(BAB, B, sl[1])
-        B_dis_real, B_feats_real = self.discriminator_B(B)
-        B_dis_fake, B_feats_fake = self.discriminator_B(AB)
         bce(B_dis_real, 1.0, 5); bce(B_dis_fake, 0.0, 6); bce(B_dis_fake, 1.0, 7)
         for l, (r, f) in enumerate(zip(B_feats_real, B_feats_fake)):
             terms[8 + nfm + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + nfm + l])
@@ -250,13 +274,16 @@ class DiscoGANTrainer:
         else:
             self.optim_gen.zero_grad()                   # image_translation.py:336-339
             self.optim_dis.zero_grad()
-        out = self.forward_losses(A, B, iters)
         from . import functional as _F
+        from . import ops as _ops
         _F.WGRAD_STREAM = self.wgrad_stream
+        _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
         try:
+            out = self.forward_losses(A, B, iters)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
+            _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
         if self.async_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:

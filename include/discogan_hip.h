@@ -126,6 +126,12 @@ int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, 
 size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K);
 int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
+/* Same, with the backward of the layer's fused LeakyReLU/ReLU applied to dy on the fly:
+ * dy_eff = dy * act'(act_out), act_out = the saved forward output (model.py:8-9, 80-81: Conv2d + in-place
+ * LeakyReLU).  Saves the separate dg_act_bwd pass when only the weight gradient is needed. */
+int dg_conv4x4s2_c3_wgrad_act(const float* dy_nhwc, const float* act_out_nhwc, int act, float slope,
+                              const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
+                              void* ws, size_t ws_bytes, dg_stream_t s);
 
 /* ---- BatchNorm2d (training mode) + activation, NHWC [M][C], M = N*H*W ------------------------
  * nn.BatchNorm2d (model.py:12...; eps 1e-5, momentum 0.1, biased batch var for normalisation,

@@ -158,6 +158,15 @@ def test_c3_edge(N, H, K):
     close(ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2), TF.leaky_relu(yr, 0.2), what="c3 fwd + lrelu")
     close(ops.c3_dgrad(dyg, wg, ops.ACT_NONE), xr.grad, rtol=2e-4, what="c3 dgrad")
     close(ops.c3_wgrad(dyg, xg), wr.grad, rtol=2e-4, what="c3 wgrad")
+    # weight gradient with the LeakyReLU backward fused into the dy loads (dg_conv4x4s2_c3_wgrad_act)
+    xr2, wr2 = x.clone(), w.clone().requires_grad_(True)
+    yl = TF.leaky_relu(TF.conv2d(xr2, wr2, stride=2, padding=1), 0.2)
+    yl.backward(dy)
+    yg = ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2)
+    close(ops.c3_wgrad(dyg, xg, act_out=yg, act=ops.ACT_LEAKY, slope=0.2), wr2.grad, rtol=2e-4, what="c3 wgrad + lrelu bwd")
+    acc = torch.ones(K, 3, 4, 4, device=DEV)
+    ops.c3_wgrad(dyg, xg, out=acc, accumulate=True, act_out=yg, act=ops.ACT_LEAKY, slope=0.2)
+    close(acc - 1.0, wr2.grad, rtol=2e-4, atol=2e-6, what="c3 wgrad + lrelu bwd, accumulate")
     # last ConvTranspose2d(K,3) + sigmoid == sigmoid(dgrad)
     ref = torch.sigmoid(TF.conv_transpose2d(dy, w, stride=2, padding=1))
     close(ops.c3_dgrad(dyg, wg, ops.ACT_SIGMOID), ref, what="c3 convT + sigmoid")
