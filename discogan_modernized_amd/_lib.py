@@ -64,6 +64,7 @@ SIGNATURES = {
     "dg_fm_workspace_bytes": (_z, [_i, _z]),
     "dg_fm_fwd": (_i, [_p, _p, _i, _z, _p, _p, _p, _z, _p]),
     "dg_fm_bwd": (_i, [_p, _i, _z, _p, _p, _p, _p]),
+    "dg_debug_igemm_stamps": (_i, [_p, _z]),
     "dg_stream_create_cu_mask": (_i, [_p, _i, _p]),
     "dg_stream_destroy": (_i, [_p]),
     "dg_device_cu_count": (_i, []),

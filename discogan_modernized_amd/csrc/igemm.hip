@@ -52,6 +52,9 @@ struct IgemmArgs {
     // {count, -, -, -, shift[Ng], sum(y - shift)[Ng], sum((y - shift)^2)[Ng]}; nullptr = off
     float* stat;
     int stat_rs;
+    // profiling hook (tools/igemm_stamps.py): per workgroup {wall0, cyc0, cyc after prologue, cyc after K loop,
+    // cyc after the epilogue stores are issued, wall1, XCC/CU id}; nullptr = off
+    long long* stamps;
 };
 
 #define NEG_BIG (-(1 << 28))
@@ -78,10 +81,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
     static_assert(256 % A_CQ == 0 && 256 % B_CQ == 0, "row mapping");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    constexpr int EPI_FLOATS = 4 * 32 * 68;          // epilogue transpose regions, one [32][68] per wave
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE > EPI_FLOATS ? 2 * STAGE : EPI_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    long long* const stp = (p.stamps != nullptr && tid == 0) ? p.stamps + (long)blockIdx.x * 8 : nullptr;
+    if (stp) {
+        stp[0] = wall_clock64();
+        stp[1] = clock64();
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stp[6] = ((long long)xcc << 32) | hwid;
+    }
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         for (int i = 0; i < NVB; ++i) store_B(smem, 0, i);
     }
     __syncthreads();
+    if (stp) stp[2] = clock64();
 
     // one K-tile; P = parity of (it - it_begin) = LDS buffer of the current tile = register set to refill
     auto body = [&](auto P, int it) {
@@ -349,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         if (it + 1 < it_end) body(std::integral_constant<int, 1>{}, it + 1);
     }
 
+    if (stp) stp[3] = clock64();
     // ---- fused BatchNorm statistics: one partial row per (tile, wave row), shifted by the wave tile's
     //      first row so that sum/sumsq never cancel catastrophically; merged by bn_partials_finalize.
     if ((MODE == MODE_FWD || MODE == MODE_DGRAD_S2) && p.stat != nullptr && p.part == nullptr) {
@@ -385,14 +401,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         }
     }
 
-    // ---- epilogue: acc[i][jn][r] -> row (r&3)+8*(r>>2)+4*lh, col l31 of the 32x32 sub-tile --------
+    // ---- epilogue: acc[i][jn][r] = row (r&3)+8*(r>>2)+4*lh, col jn*32+l31 of the wave's 32x64 half tile.
+    // Transposed through the (now idle) LDS, one private [32][68] region per wave, so that every lane stores
+    // float4 and 16 lanes cover one 256-B output row segment: 16 store instructions per wave instead of 64
+    // dword stores (the epilogue is store-ISSUE bound; stamps: 4.6-22 us -> see DESIGN.md 3.1).
     const bool to_part = p.part != nullptr;
+    float* const eps = smem + wave * (32 * 68);
+    const int erow = lane >> 4, ec4 = (lane & 15) * 4;
+    const int ncol = n0 + wn * 64 + ec4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= p.M) continue;
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            eps[lr * 68 + l31] = acc[i][0][r];
+            eps[lr * 68 + 32 + l31] = acc[i][1][r];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + erow;
+            f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
+            const int m = m0 + wm * 64 + i * 32 + row;
+            if (m >= p.M || ncol >= p.Ng) continue;
             float* dst;
             if (to_part) {
                 const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m
@@ -404,17 +434,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             } else {
                 dst = p.C + (long)m * p.Ng;
             }
+            dst += ncol;
+            if (!to_part && p.accumulate) v += *(const f32x4*)dst;
+            if (MODE == MODE_FWD_C3) {
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                const int n = n0 + wn * 64 + jn * 32 + l31;
-                if (n < p.Ng) {
-                    float v = acc[i][jn][r];
-                    if (!to_part && p.accumulate) v += dst[n];
-                    if (MODE == MODE_FWD_C3) v = dg_apply_act(v, p.act, p.slope);
-                    dst[n] = v;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = dg_apply_act(v[e], p.act, p.slope);
             }
+            *(f32x4*)dst = v;
         }
+    }
+    if (stp) {
+        stp[4] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[5] = wall_clock64();
+        stp[7] = clock64();
     }
 }
 
@@ -667,8 +700,21 @@ static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
     hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT>), dim3(grid), dim3(256), 0, st, a);
 }
 
+static long long* g_stamp_buf = nullptr;
+static size_t g_stamp_cap = 0;
+// profiling hook: stamps of the NEXT igemm launches go to buf (8 int64 per workgroup); (nullptr, 0) = off
+extern "C" int dg_debug_igemm_stamps(void* buf, size_t bytes) {
+    g_stamp_buf = (long long*)buf;
+    g_stamp_cap = bytes;
+    return DG_OK;
+}
+
 static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStream_t st) {
     IgemmArgs& a = pl.a;
+    {
+        const size_t grid = (size_t)a.tilesM * a.tilesN * (pl.mode == MODE_DGRAD_S2 ? 4 : 1) * a.splits;
+        a.stamps = (g_stamp_buf != nullptr && g_stamp_cap >= grid * 64) ? g_stamp_buf : nullptr;
+    }
     if (a.splits > 1) {
         if (ws == nullptr || ws_bytes < pl.ws_bytes)
             return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < required %zu", who, ws_bytes, pl.ws_bytes);

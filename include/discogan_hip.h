@@ -176,6 +176,11 @@ int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff
               void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);
 
+/* Profiling hook: the next implicit-GEMM launches write 8 int64 per workgroup into buf ({wall0, cyc0, cyc after
+ * prologue, cyc after the K loop, cyc after the epilogue stores are issued, wall1, XCC<<32|HW_ID, cyc end});
+ * (NULL, 0) switches it off.  wall = 100 MHz constant clock, cyc = shader clock. */
+int dg_debug_igemm_stamps(void* buf, size_t bytes);
+
 /* Streams restricted to a subset of the compute units (mask: one bit per CU, 32 per word): the host layer
  * runs its two independent network chains (G_A/D_A and G_B/D_B, image_translation.py:342-365) on disjoint
  * halves of the chip.  Host plumbing, no reference counterpart. */
