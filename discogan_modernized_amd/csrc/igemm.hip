@@ -55,6 +55,7 @@ struct IgemmArgs {
     // profiling hook (tools/igemm_stamps.py): per workgroup {wall0, cyc0, cyc after prologue, cyc after K loop,
     // cyc after the epilogue stores are issued, wall1, XCC/CU id}; nullptr = off
     long long* stamps;
+    unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
 };
 
 #define NEG_BIG (-(1 << 28))
@@ -64,7 +65,13 @@ struct IgemmArgs {
 // global load and serialise HBM latency into the MFMA stream.
 __device__ float dg_zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-template <int MODE, int WM, int WN, int KT>
+// BUF: operands are addressed through buffer descriptors with 32-bit byte offsets; a masked (padding / ragged)
+// vector gets an out-of-range offset and the hardware returns zeros.  Per tile load this is 1-3 VALU
+// instructions (add the wave-uniform tap offset, or-in the precomputed per-row validity bit) instead of the
+// ~12 of the 64-bit pointer path (mad_i64, three 64-bit adds, compares, pointer select), which matters because
+// everything between two MFMAs has to fit the ~48 issue cycles a 64-cycle MFMA leaves (stamps: the K loop ran
+// at 87 % of the sustained matrix rate with 12-instruction clumps per load).  !BUF = any size, pointer path.
+template <int MODE, int WM, int WN, int KT, bool BUF>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr bool A_KM = (MODE == MODE_WGRAD);
@@ -174,6 +181,52 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         wg_s = tap & 3;
     }
 
+    // ---- BUF: per-row byte offsets and per-row tap-validity bits ----------------------------------------
+    constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB tensor
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, BUF ? (int)p.abytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, BUF ? (int)p.bbytes : 0, 0x00020000);
+    int a_ob[NVA], a_inv[NVA], b_ob[NVB];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        a_ob[i] = 0;
+        a_inv[i] = 0;
+        if (BUF && MODE == MODE_FWD) {
+            a_ob[i] = (a_pix[i] * Cc + acq * 4) * 4;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const bool ok = (unsigned)(a_y[i] + (t >> 2)) < (unsigned)H && (unsigned)(a_x[i] + (t & 3)) < (unsigned)W;
+                a_inv[i] |= ok ? 0 : (1 << t);
+            }
+        } else if (BUF && MODE == MODE_DGRAD_S2) {
+            a_ob[i] = (a_pix[i] * K + acq * 4) * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = t >> 1, tx = t & 1;
+                const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+                const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+                const bool ok = (unsigned)(a_y[i] + dyo) < (unsigned)Ho && (unsigned)(a_x[i] + dxo) < (unsigned)Wo;
+                a_inv[i] |= ok ? 0 : (1 << t);
+            }
+        } else if (BUF && MODE == MODE_WGRAD) {
+            const int kcol = m0 + acq * 4;
+            a_ob[i] = kcol < K ? ((arow0 + i * A_RSTEP) * K + kcol) * 4 : OOR;   // rows >= R run off the end: zeros
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        b_ob[i] = 0;
+        if (BUF && MODE == MODE_FWD) {
+            const int k = n0 + brow0 + i * B_RSTEP;
+            b_ob[i] = k < K ? (k * 16 * Cc + bcq * 4) * 4 : OOR;
+        } else if (BUF && MODE == MODE_DGRAD_S2) {
+            const int col = n0 + bcq * 4;
+            b_ob[i] = col < Cc ? ((brow0 + i * B_RSTEP) * 16 * Cc + col) * 4 : OOR;
+        }
+    }
+    auto ld4b = [&](const __amdgpu_buffer_rsrc_t& r, int byte_off) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+    };
+
     // ---- K-iteration state ------------------------------------------------------------------------
     // FWD: (tap, chunk) over (16, Cc/KT);  DGRAD_S2: (t, chunk) over (4, K/KT)
     int kchunks = 1, tap = 0, chunk = 0;
@@ -196,7 +249,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         return *(const f32x4*)ptr;
     };
     auto load_A = [&](int set, int i, int it) {
-        if (MODE == MODE_FWD) {
+        if (BUF && MODE == MODE_FWD) {
+            const int r = tap >> 2, sx = tap & 3;
+            const int soff = ((r * W + sx) * Cc + chunk * KT) * 4;                  // wave-uniform
+            ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1));
+        } else if (BUF && MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1;
+            const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+            const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+            const int soff = ((dyo * Wo + dxo) * K + chunk * KT) * 4;               // wave-uniform
+            ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1));
+        } else if (BUF && MODE == MODE_DGRAD_PLAIN) {
+            const int kcol = it * KT + acq * 4;
+            ra[set][i] = ld4b(rA, (a_y[i] >= 0 && kcol < K) ? (a_pix[i] * K + kcol) * 4 : OOR);
+        } else if (BUF && MODE == MODE_WGRAD) {
+            ra[set][i] = ld4b(rA, a_ob[i] + it * (KT * 4) * K);
+        } else if (MODE == MODE_FWD) {
             const int r = tap >> 2, s = tap & 3, c0 = chunk * KT;
             const int iy = a_y[i] + r, ix = a_x[i] + s;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
@@ -230,7 +298,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         }
     };
     auto load_B = [&](int set, int i, int it) {
-        if (MODE == MODE_FWD) {
+        if (BUF && MODE == MODE_FWD) {
+            rb[set][i] = ld4b(rB, b_ob[i] + it * (KT * 4));
+        } else if (BUF && MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1;
+            const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+            const int sx = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+            rb[set][i] = ld4b(rB, b_ob[i] + ((chunk * KT * 16 + r * 4 + sx) * Cc) * 4);
+        } else if (BUF && MODE == MODE_DGRAD_PLAIN) {
+            const int col = n0 + bcq * 4;
+            const int k = it * KT + brow0 + i * B_RSTEP;
+            rb[set][i] = ld4b(rB, (k < K && col < p.Ng) ? (k * p.Ng + col) * 4 : OOR);
+        } else if (BUF && MODE == MODE_WGRAD) {
+            const int mrow = it * KT + brow0 + i * B_RSTEP;
+            const int ox = mrow & (Wo - 1), oy = (mrow >> lgWo) & (Ho - 1), n = mrow >> lgHW;
+            const int iy = oy * p.stride - p.pad + wg_r, ix = ox * p.stride - p.pad + wg_s;
+            const bool ok = wg_colok && mrow < p.R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            rb[set][i] = ld4b(rB, ok ? (((n * H + iy) * W + ix) * Cc + wg_c) * 4 : OOR);
+        } else if (MODE == MODE_FWD) {
             const int k = n0 + brow0 + i * B_RSTEP;
             rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)it * KT + bcq * 4, k < K);
         } else if (MODE == MODE_FWD_C3) {
@@ -301,14 +386,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int NG = KT / 8;            // k groups per tile (16 MFMAs each)
     constexpr int SC = NG * 4;            // sub-chunks of 4 MFMAs
     constexpr int NLD = NVA + NVB;        // global-load / LDS-store work items per tile
-    static_assert(NLD <= SC, "more load items than sub-chunks");
-    constexpr int ST0 = SC - NLD;         // first sub-chunk that carries an LDS store
+    constexpr int EB = 2;                 // the tile barrier sits EB sub-chunks (8 MFMAs) before the end of the tile
+    static_assert(NLD <= SC - EB, "more load items than sub-chunks");
+    static_assert(NG % 2 == 0, "fragment set 0 must be free during the last k group");
+    constexpr int ST0 = SC - EB - NLD;    // first sub-chunk that carries an LDS store
+    constexpr int SB = SC - EB;           // sub-chunk that opens with the barrier
 
     // Pipeline: tile t lives in LDS buffer (t & 1); tile t+1 sits in register set ((t+1) & 1) and is written
-    // to the other LDS buffer in the second half of iteration t; tile t+2 is loaded into register set
-    // (t & 1) in the first half of iteration t.  Global-load latency tolerance = 1.5 iterations.
+    // to the other LDS buffer in sub-chunks ST0..SB-1 of iteration t; tile t+2 is loaded into register set
+    // (t & 1) in the first half of iteration t.  Global-load latency tolerance = 1.4 iterations.
+    // The ONE barrier per tile comes 8 MFMAs before the end of the tile, and the first fragment group of tile
+    // t+1 is fetched right behind it: barrier skew and the LDS read latency are covered by the current
+    // tile's last MFMAs instead of opening every tile with an empty matrix pipe (stamps: the loop ran at
+    // 86-87 % of the sustained MFMA rate with the barrier at the tile boundary).
     // Tiles past the end are re-loaded from the last position and never used (no branches in the body).
     const int it_last = it_end - 1;
+    float fa[2][2][4], fb[2][2][4];   // double-buffered LDS fragments; set 0 is carried across tiles
     if (it_begin < it_end) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) load_A(0, i, it_begin);
@@ -327,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     }
     __syncthreads();
     if (stp) stp[2] = clock64();
+    fetch(smem, smem + A_FLOATS, 0, fa[0], fb[0]);
 
     // one K-tile; P = parity of (it - it_begin) = LDS buffer of the current tile = register set to refill
     auto body = [&](auto P, int it) {
@@ -335,16 +429,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         const float* Bs = As + A_FLOATS;
         float* nxt = smem + (p_ ^ 1) * STAGE;
         const int itn = min(it + 2, it_last);
-        float fa[2][2][4], fb[2][2][4];   // double-buffered LDS fragments
-        fetch(As, Bs, 0, fa[0], fb[0]);
 #pragma unroll
         for (int sc = 0; sc < SC; ++sc) {
             const int g = sc >> 2, j = sc & 3;
             __builtin_amdgcn_sched_barrier(0);
-            if (sc >= ST0) {          // tile it+1: registers (set p^1) -> LDS; read before the refill below is issued
+            if (sc >= ST0 && sc < SB) {   // tile it+1: registers (set p^1) -> LDS
                 const int q = sc - ST0;
                 if (q < NVA) store_A(nxt, p_ ^ 1, q);
                 else store_B(nxt, p_ ^ 1, q - NVA);
+            }
+            if (sc == SB) {
+                // every wave's stores of tile it+1 are done and every wave's reads of tile it were consumed
+                // (the last k group's fragments were waited for before sub-chunk SC-4)
+                __syncthreads();
+                fetch(nxt, nxt + A_FLOATS, 0, fa[0], fb[0]);
             }
             if (sc < NVA) load_A(p_, sc, itn);
             else if (sc < NLD) load_B(p_, sc - NVA, itn);
@@ -357,7 +455,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         advance(it + 3 < it_end ? 1 : 0);
-        __syncthreads();
     };
     for (int it = it_begin; it < it_end; it += 2) {
         body(std::integral_constant<int, 0>{}, it);
@@ -681,6 +778,13 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         a.M = g.K; a.Ng = 16 * g.C; a.R = npix;
         a.nIt = (npix + pl->kt - 1) / pl->kt;
     }
+    {   // operand sizes for the buffer-descriptor kernels; 0 = use the 64-bit pointer kernels
+        const long xb = (long)g.N * g.H * g.W * g.C * 4, yb = (long)npix * g.K * 4, wb = (long)g.K * 16 * g.C * 4;
+        const long ab = op == 0 ? xb : yb, bb = op == 2 ? xb : wb;
+        const bool fits = ab < (1L << 31) && bb < (1L << 31);
+        a.abytes = fits ? (unsigned)ab : 0u;
+        a.bbytes = fits ? (unsigned)bb : 0u;
+    }
     const int BM = 64 * pl->wm, BN = 64 * pl->wn;
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
@@ -697,7 +801,10 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
 template <int MODE, int WM, int WN, int KT>
 static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT>), dim3(grid), dim3(256), 0, st, a);
+    if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false>), dim3(grid), dim3(256), 0, st, a);
 }
 
 static long long* g_stamp_buf = nullptr;
