@@ -180,6 +180,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         wg_r = tap >> 2;
         wg_s = tap & 3;
     }
+    // WGRAD (BUF) addressing constants, see load_B
+    const bool wg_s2 = p.stride == 2;
+    const int wg_lpm = wg_s2 ? 2 : 4, wg_pxm = wg_s2 ? -1 : 0;
+    const int wg_cst = wg_s2 ? (wg_r - 1) * W + (wg_s - 1) : wg_r * 4 + wg_s;
+    const int wg_ybad = !wg_s2 ? -1 : (wg_r == 0 ? 0 : (wg_r == 3 ? Ho - 1 : -1));
+    const int wg_xbad = !wg_s2 ? -1 : (wg_s == 0 ? 0 : (wg_s == 3 ? Wo - 1 : -1));
+    const int wg_colbad = wg_colok ? 0 : -1;
 
     // ---- BUF: per-row byte offsets and per-row tap-validity bits ----------------------------------------
     constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB tensor
@@ -310,11 +317,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             const int k = it * KT + brow0 + i * B_RSTEP;
             rb[set][i] = ld4b(rB, (k < K && col < p.Ng) ? (k * p.Ng + col) * 4 : OOR);
         } else if (BUF && MODE == MODE_WGRAD) {
+            // reduction row = output pixel mrow = (n, oy, ox) packed (Ho, Wo powers of two).  k4 s2 p1 has
+            // H = 2Ho, W = 2Wo, so the input pixel of tap (r, s) is 4*mrow - 2*ox + (r-1)*W + (s-1) and only
+            // (r=0, oy=0), (r=3, oy=Ho-1) and the two column analogues fall into the padding; the 4x4 head
+            // (s1 p0) reads pixel 16*mrow + 4r + s.  All flags are per-thread constants (wg_*): no branches.
             const int mrow = it * KT + brow0 + i * B_RSTEP;
-            const int ox = mrow & (Wo - 1), oy = (mrow >> lgWo) & (Ho - 1), n = mrow >> lgHW;
-            const int iy = oy * p.stride - p.pad + wg_r, ix = ox * p.stride - p.pad + wg_s;
-            const bool ok = wg_colok && mrow < p.R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            rb[set][i] = ld4b(rB, ok ? (((n * H + iy) * W + ix) * Cc + wg_c) * 4 : OOR);
+            const int oxv = mrow & (Wo - 1), oyv = (mrow >> lgWo) & (Ho - 1);
+            const int bad = (oyv == wg_ybad) | (oxv == wg_xbad) | (mrow >= p.R);
+            const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst;
+            rb[set][i] = ld4b(rB, ((pix * Cc + wg_c) * 4) | wg_colbad | -bad);
         } else if (MODE == MODE_FWD) {
             const int k = n0 + brow0 + i * B_RSTEP;
             rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)it * KT + bcq * 4, k < K);
@@ -768,6 +779,8 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         a.M = npix; a.Ng = g.C; a.R = 4 * g.K;
         a.nIt = 4 * g.K / pl->kt;
         zmul = 4;
+        // 256x64 tile for <= 64 output columns, KT 16 so that two workgroups fit a CU (KT 32 = 91 KB of LDS, one
+        // workgroup per CU, was measured slower: 189 vs 165 us on 128->64 @32x32, nothing hides prologue/epilogue)
         if (g.C <= 64) { pl->wm = 4; pl->wn = 1; pl->kt = 16; a.nIt = 4 * g.K / 16; }
     } else if (op == 1) {
         pl->mode = MODE_DGRAD_PLAIN;
