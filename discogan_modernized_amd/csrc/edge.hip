@@ -531,7 +531,7 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
     const size_t need = (size_t)nb * K * 48 * sizeof(float);
     if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const bool buf = npix * K * 4 < (1L << 30) && (long)N * 3 * H * W * 4 < (1L << 30);
+    const bool buf = npix * K * 4 < (1L << 30) && (long)N * 3 * H * W * 4 < (1L << 30) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
     const bool fact = act_out != nullptr;
 #define CW_LAUNCH(B, F)                                                                                                  \
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \

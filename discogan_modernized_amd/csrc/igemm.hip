@@ -794,7 +794,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     {   // operand sizes for the buffer-descriptor kernels; 0 = use the 64-bit pointer kernels
         const long xb = (long)g.N * g.H * g.W * g.C * 4, yb = (long)npix * g.K * 4, wb = (long)g.K * 16 * g.C * 4;
         const long ab = op == 0 ? xb : yb, bb = op == 2 ? xb : wb;
-        const bool fits = ab < (1L << 31) && bb < (1L << 31);
+        const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
     }

@@ -87,6 +87,20 @@ def test_conv_s2_options(kt, splitk):
         _lib.set_option("splitk", 0)
 
 
+def test_pointer_path_kernels():
+    """Tensors of 2 GiB and more use the 64-bit addressing instantiations (no buffer descriptors); force them
+    on small shapes so that path stays covered."""
+    _lib.set_option("pointer_path", 1)
+    try:
+        test_conv_s2_fwd_dgrad_wgrad(2, 128, 256, 8)
+        test_conv_s2_fwd_dgrad_wgrad(3, 64, 128, 16)
+        test_conv_head_valid(5, 512, 100)
+        test_convT_s2(2, 128, 64, 8)
+        test_c3_edge(2, 16, 64)
+    finally:
+        _lib.set_option("pointer_path", 0)
+
+
 @pytest.mark.parametrize("N,C,K", [(2, 128, 100), (5, 512, 100), (4, 2048, 100), (2, 128, 1), (7, 512, 1), (32, 2048, 1)])
 def test_conv_head_valid(N, C, K):
     """Conv2d(C,K,4,1,0) on a 4x4 input (model.py:35,107): fwd / dgrad / wgrad."""
