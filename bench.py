@@ -78,15 +78,15 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def timed_run(trainer, A, B, steps, warmup, world, start_iter=0):
+def timed_run(trainer, A, B, steps, warmup, world, start_iter=0, need_losses=True):
     it = start_iter
     for _ in range(warmup):
-        trainer.train_iteration(A, B, it)
+        trainer.train_iteration(A, B, it, need_losses=need_losses)
         it += 1
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(steps):
-        trainer.train_iteration(A, B, it)
+        trainer.train_iteration(A, B, it, need_losses=need_losses)
         it += 1
     trainer.finish()
     barrier_sync(world)
@@ -195,6 +195,14 @@ def main():
                     by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
                                    tflops=round(v[1] / max(v[2], 1e-9) / 1e9, 1)) for k, v in by.items()})
     extra = {}
+    if not a.no_512:     # (same switch as the other extra line)
+        ui = trainer.args.update_interval
+        it2 = (it + 2 * ui) // ui * ui
+        dtl, _ = timed_run(trainer, A, B, a.steps, ui, world, start_iter=it2, need_losses=False)
+        extra["images_per_sec_unlogged_iterations"] = round(a.batch_size * world * a.steps / dtl, 2)
+        extra["note_unlogged"] = ("same workload when the iteration's loss values are not read (every iteration that prints "
+                                  "no log line: log_interval 50 in the reference): D-steps skip the two reconstruction "
+                                  "passes that feed only the log; weights identical. NOT the headline value.")
     del trainer
     torch.cuda.empty_cache()
     if not a.no_512:
@@ -206,7 +214,7 @@ def main():
         log("512px models built")
         dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)
         log(f"512px done: {dt5 / 6 * 1e3:.1f} ms/step")
-        extra = dict(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
+        extra.update(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
                      note="BASELINE configs[3]: tops2hanbok image_size=512 batch_size=32 per GPU, fp32, 6 timed steps")
         del tr512, A5, B5
         torch.cuda.empty_cache()

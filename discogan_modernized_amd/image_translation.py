@@ -138,7 +138,8 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
             sl = slice(i * args.batch_size, (i + 1) * args.batch_size)
             A = data_A.index_select(0, perm_A[sl])
             B = data_B.index_select(0, perm_B[sl])
-            out = trainer.train_iteration(A, B, iters)
+            # loss values are only read on log iterations; elsewhere a D-step may skip its log-only passes
+            out = trainer.train_iteration(A, B, iters, need_losses=(iters % args.log_interval == 0))
             if is_main and iters % args.log_interval == 0:
                 msg = trainer.format_log(iters, total_iterations, out)
                 dt = time.time() - t0

@@ -157,8 +157,9 @@ class DiscoGANTrainer:
         for p in self.optim_dis.params:
             p.requires_grad_(dstep)
 
-    def forward_losses(self, A, B, iters):
-        """image_translation.py:342-382."""
+    def forward_losses(self, A, B, iters, need_losses=True):
+        """image_translation.py:342-382.  need_losses=False (D-steps only): the reconstruction passes ABA / BAB and their
+        MSE terms feed nothing but the log line in a D-step, so they are not computed (recon_loss_* read NaN)."""
         a = self.args
         dstep = self.is_dis_step(iters)
         skip = self.skip_dead_work
@@ -215,8 +216,13 @@ class DiscoGANTrainer:
             self._ev_dis_ready = None
         # stage 2 + discriminators.  Every loss term is written into its slot of one device vector (layout:
         # dg_loss_mix_fwd); the mix and its gradient seeds are one launch each instead of ~45 scalar kernels.
-        with gen_ctx():
-            ABA, BAB = pair(self.generator_A.forward_steps(AB), self.generator_B.forward_steps(BA))
+        want_recon = need_losses or not (dstep and skip)
+        ABA = BAB = None
+        if want_recon:
+            with gen_ctx():
+                ABA, BAB = pair(self.generator_A.forward_steps(AB), self.generator_B.forward_steps(BA))
+        else:
+            lv[:2].fill_(float("nan"))
         (A_dis_real, A_feats_real), (B_dis_real, B_feats_real) = pair(
             self.discriminator_A.forward_steps(A), self.discriminator_B.forward_steps(B))
         (A_dis_fake, A_feats_fake), (B_dis_fake, B_feats_fake) = pair(
@@ -229,13 +235,19 @@ class DiscoGANTrainer:
             terms[k] = F_.BCELossFn.apply(p.reshape(p.size(0), -1), label, sl[k])
 
         with on_side():
-            with gen_ctx():
-                terms[0] = F_.MSELossFn.apply(ABA, A, sl[0])
+            if want_recon:
+                with gen_ctx():
+                    terms[0] = F_.MSELossFn.apply(ABA, A, sl[0])
+            else:
+                terms[0] = sl[0]
             bce(A_dis_real, 1.0, 2); bce(A_dis_fake, 0.0, 3); bce(A_dis_fake, 1.0, 4)
             for l, (r, f) in enumerate(zip(A_feats_real, A_feats_fake)):
                 terms[8 + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + l])
-        with gen_ctx():
-            terms[1] = F_.MSELossFn.apply(BAB, B, sl[1])
+        if want_recon:
+            with gen_ctx():
+                terms[1] = F_.MSELossFn.apply(BAB, B, sl[1])
+        else:
+            terms[1] = sl[1]
         bce(B_dis_real, 1.0, 5); bce(B_dis_fake, 0.0, 6); bce(B_dis_fake, 1.0, 7)
         for l, (r, f) in enumerate(zip(B_feats_real, B_feats_fake)):
             terms[8 + nfm + l] = F_.FeatureMatchFn.apply(r, f, sl[8 + nfm + l])
@@ -262,7 +274,7 @@ class DiscoGANTrainer:
             A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
             A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
 
-    def _fwd_bwd(self, A, B, iters):
+    def _fwd_bwd(self, A, B, iters, need_losses=True):
         dstep = self.is_dis_step(iters)
         self._set_requires_grad(dstep)
         if self.skip_dead_work:
@@ -279,7 +291,7 @@ class DiscoGANTrainer:
         _F.WGRAD_STREAM = self.wgrad_stream
         _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
         try:
-            out = self.forward_losses(A, B, iters)
+            out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
@@ -292,42 +304,44 @@ class DiscoGANTrainer:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         return out
 
-    def _graph_key(self, iters):
-        return ("D" if self.is_dis_step(iters) else "G", self.rate(iters))
+    def _graph_key(self, iters, need_losses=True):
+        return ("D" if self.is_dis_step(iters) else "G", self.rate(iters), bool(need_losses) or not self.is_dis_step(iters))
 
-    def _fwd_bwd_graphed(self, A, B, iters):
+    def _fwd_bwd_graphed(self, A, B, iters, need_losses=True):
         if self._static is None:
             self._static = (torch.empty_like(A), torch.empty_like(B))
         sA, sB = self._static
         sA.copy_(A)
         sB.copy_(B)
-        key = self._graph_key(iters)
+        key = self._graph_key(iters, need_losses)
         ent = self._graphs.get(key)
         if ent is None:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
-                out = self._fwd_bwd(sA, sB, iters)
+                out = self._fwd_bwd(sA, sB, iters, need_losses)
             ent = (g, out)
             self._graphs[key] = ent
         ent[0].replay()
         return ent[1]
 
-    def train_iteration(self, A, B, iters, do_step=True):
-        """One full iteration; returns the namespace of (device) loss scalars."""
+    def train_iteration(self, A, B, iters, do_step=True, need_losses=True):
+        """One full iteration; returns the namespace of (device) loss scalars.  need_losses=False tells the
+        trainer that this iteration's loss values will not be read (no log line): a D-step then skips the two
+        reconstruction passes, which feed only the log (weights and optimiser state are unaffected)."""
         if self.part_main is not None and torch.cuda.current_stream(self.device) != self.part_main:
             caller = torch.cuda.current_stream(self.device)
             self.part_main.wait_stream(caller)
             with torch.cuda.stream(self.part_main):
-                out = self.train_iteration(A, B, iters, do_step)
+                out = self.train_iteration(A, B, iters, do_step, need_losses)
             caller.wait_stream(self.part_main)
             return out
         dstep = self.is_dis_step(iters)
         opt = self.optim_dis if dstep else self.optim_gen
         if self.use_graph and iters >= self.args.update_interval:   # first cycle runs eagerly (warm-up)
-            out = self._fwd_bwd_graphed(A, B, iters)
+            out = self._fwd_bwd_graphed(A, B, iters, need_losses)
         else:
-            out = self._fwd_bwd(A, B, iters)
+            out = self._fwd_bwd(A, B, iters, need_losses)
         # gradients of the stepped side only: one flat message, summed; the /W rides in the Adam kernel
         if self.overlap_comm and dstep and do_step:
             main = torch.cuda.current_stream(self.device)

@@ -350,6 +350,30 @@ def test_graph_replay_equals_eager():
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_unread_losses_skip_only_log_work():
+    """need_losses=False (iterations that print no log line): D-steps skip the reconstruction passes.  Weights,
+    optimiser state and every loss that IS computed must be bitwise what the full iteration gives; the skipped
+    recon terms (and the gen_loss mix that contains them) read NaN; G-steps are unaffected."""
+    import math
+    A, B = synthetic_batch(4, 16, 0, DEV)
+    res = []
+    for lazy in (False, True):
+        for graph in (False, True):
+            tr = DiscoGANTrainer(default_args(), device=DEV, image_size=16, seed=1234, use_graph=graph)
+            vals = [tr.losses_to_floats(tr.train_iteration(A, B, it, need_losses=not lazy)) for it in range(9)]
+            torch.cuda.synchronize()
+            res.append((lazy, vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    ref = res[0]
+    for lazy, vals, pg, pd in res[1:]:
+        assert torch.equal(pg, ref[2]) and torch.equal(pd, ref[3])
+        for it, (v, r) in enumerate(zip(vals, ref[1])):
+            for k in r:
+                if lazy and it % 3 == 0 and (k.startswith("recon_loss") or k == "gen_loss"):   # gen_loss = mix incl. recon
+                    assert math.isnan(v[k]), (it, k, v[k])
+                else:
+                    assert v[k] == r[k], (it, k, v[k], r[k])
+
+
 def test_async_wgrad_stream_is_bitwise_neutral():
     """Weight-gradient kernels on their own stream (off the backward critical path): identical results."""
     A, B = synthetic_batch(4, 16, 0, DEV)
