@@ -35,12 +35,12 @@ PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pro
 
 
 def pmc_traffic_bytes(image_size, batch):
-    """HBM-side bytes per launch of the dominant instantiation (igemm_kernel<0,2,2,32>) from the committed
+    """HBM-side bytes per launch of the dominant instantiation (igemm_kernel<0,2,2,32,true>) from the committed
     rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/); only valid for the profiled workload."""
     if (image_size, batch) != (64, 256) or not os.path.exists(PMC_TRAFFIC_FILE):
         return None
     try:
-        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"]["void igemm_kernel<0, 2, 2, 32>(IgemmArgs)"]
+        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"]["void igemm_kernel<0, 2, 2, 32, true>(IgemmArgs)"]
         return int(k["hbm_MB_per_launch"] * 1024 * 1024)
     except Exception:
         return None
@@ -189,7 +189,7 @@ def main():
         roof = dict(bound="mfma", kernel="igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)",
                     achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic_bytes(a.image_size, a.batch_size),
-                    traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
+                    traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32,true> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
                     launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
                     avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
                     by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
