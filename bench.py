@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
     ap.add_argument("--cu_partition", default=os.environ.get("DG_CU_PARTITION", ""), choices=["", "xcd", "half"],
                     help="run the two chains on CU-masked streams (disjoint halves of the chip)")
+    ap.add_argument("--skew", type=int, default=int(os.environ.get("DG_SKEW", "0")), help="hold the B chain back by this many steps of the A chain")
     ap.add_argument("--turns", action="store_true", help="make the two chains take turns on the matrix cores (measured slower)")
     ap.add_argument("--async_wgrad", action="store_true",
                     help="weight-gradient kernels on a third stream (measured: neutral to slightly slower)")
@@ -172,7 +173,7 @@ def main():
     trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
                               use_graph=not a.no_graph, two_streams=not a.single_stream,
                               async_wgrad=a.async_wgrad and not a.single_stream,
-                              cu_partition=a.cu_partition or None, mfma_turns=a.turns)
+                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew)
     A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
     log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
     dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
@@ -209,7 +210,7 @@ def main():
         tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
                                 use_graph=not a.no_graph, two_streams=not a.single_stream,
                                 async_wgrad=a.async_wgrad and not a.single_stream,
-                              cu_partition=a.cu_partition or None, mfma_turns=a.turns)
+                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew)
         A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
         log("512px models built")
         dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)

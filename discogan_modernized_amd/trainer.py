@@ -45,7 +45,7 @@ def default_args(**over):
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
-                 cu_partition=None, mfma_turns=False):
+                 cu_partition=None, mfma_turns=False, skew_steps=0):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -86,6 +86,7 @@ class DiscoGANTrainer:
         # mfma_turns: the chains take turns on the matrix cores (ops.TURNS).  Measured SLOWER (15.5 vs 14.1 ms at
         # 64 px / batch 256: a cross-queue event per conv costs more than the overlap it buys) -> off.
         self.mfma_turns = bool(mfma_turns) and two_streams
+        self.skew_steps = int(skew_steps)
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -182,8 +183,11 @@ class DiscoGANTrainer:
         # conv kernels then alternate between the streams and each chain's BatchNorm / reduction kernels run
         # under the other chain's conv.  autograd replays nodes in reverse creation order, so the backward pass
         # is interleaved the same way.
+        skew = self.two_streams and self.skew_steps > 0
+
         def pair(gen_a, gen_b):
             ra = rb = pend = object()
+            k = 0
             while ra is pend or rb is pend:
                 if ra is pend:
                     with on_side():
@@ -191,6 +195,13 @@ class DiscoGANTrainer:
                             next(gen_a)
                         except StopIteration as e:
                             ra = e.value
+                k += 1
+                if skew and k == self.skew_steps:
+                    # hold the B chain back by the A chain's first step(s): the chains are symmetric, so without
+                    # this they run in phase (both in conv, then both in BatchNorm with idle matrix cores)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    main.wait_event(ev)
                 if rb is pend:
                     try:
                         next(gen_b)
