@@ -569,7 +569,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
         const int c4 = (int)(idx - row * ng4);
         const float* src = p.part + row * p.Ng + c4 * 4;
         f32x4 s = *(const f32x4*)src;
-        for (int k = 1; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
+        int k = 1;
+        for (; k + 7 < p.splits; k += 8) {      // 8 slab loads in flight, summed in slab order (fixed -> deterministic)
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (k + u) * slab);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
         float* dst;
         if (MODE == MODE_DGRAD_S2) {
             const int parity = (int)(row / p.M);
@@ -579,6 +587,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
         } else {
             dst = p.C + row * p.Ng + c4 * 4;
         }
+        if (p.accumulate) s += *(const f32x4*)dst;
+        *(f32x4*)dst = s;
+    }
+}
+
+// Small outputs (heads, deep weight gradients): the serial form above would leave a few dozen workgroups walking
+// up to 64 slabs each.  Here a block is 16 float4 outputs x 16 slab lanes; lane j sums slabs j, j+16, ... and the
+// 16 lane sums are added in lane order by one thread (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const IgemmArgs p, long total4) {
+    __shared__ f32x4 red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const long idx = (long)blockIdx.x * 16 + tx;
+    const int ng4 = p.Ng >> 2;
+    const long slab = (long)p.M * p.Ng;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    long row = 0;
+    int c4 = 0;
+    if (idx < total4) {
+        row = idx / ng4;
+        c4 = (int)(idx - row * ng4);
+        const float* src = p.part + row * p.Ng + c4 * 4;
+        for (int k = ty; k < p.splits; k += 16) s += *(const f32x4*)(src + k * slab);
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && idx < total4) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) s += red[j][tx];
+        float* dst = p.C + row * p.Ng + c4 * 4;
         if (p.accumulate) s += *(const f32x4*)dst;
         *(f32x4*)dst = s;
     }
@@ -865,6 +902,11 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         const long total4 = (long)zmul * a.M * a.Ng / 4;
         int grid = (int)((total4 + 255) / 256);
         if (grid > 4096) grid = 4096;
+        if (pl.mode != MODE_DGRAD_S2 && a.splits >= 8 && total4 <= 65536) {
+            hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, a, total4);
+            DG_CHECK_LAUNCH("splitk_reduce_small");
+            return DG_OK;
+        }
         switch (pl.mode) {
             case MODE_DGRAD_S2: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_DGRAD_S2>, dim3(grid), dim3(256), 0, st, a, total4); break;
             default: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_FWD>, dim3(grid), dim3(256), 0, st, a, total4); break;
