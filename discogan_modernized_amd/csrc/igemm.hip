@@ -199,11 +199,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         a_inv[i] = 0;
         if (BUF && MODE == MODE_FWD) {
             a_ob[i] = (a_pix[i] * Cc + acq * 4) * 4;
+            int colok = 0, okmask = 0;             // 4 column bits, replicated into every valid filter row
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const bool ok = (unsigned)(a_y[i] + (t >> 2)) < (unsigned)H && (unsigned)(a_x[i] + (t & 3)) < (unsigned)W;
-                a_inv[i] |= ok ? 0 : (1 << t);
-            }
+            for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(a_x[i] + sx) < (unsigned)W) ? (1 << sx) : 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(a_y[i] + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
+            a_inv[i] = ~okmask & 0xFFFF;
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             a_ob[i] = (a_pix[i] * K + acq * 4) * 4;
 #pragma unroll
