@@ -109,10 +109,21 @@ def roofline_pass(trainer, A, B, start_iter):
     trainer.two_streams = False          # isolated kernel durations: one stream, one kernel at a time
     trainer.wgrad_stream = None
     ops.PROFILE = []
+    ops.PROFILE_HBM = []
     for k in range(ui):
         trainer.train_iteration(A, B, start_iter + k)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    hrec, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+    hbm = {}
+    for name, nbytes, e0, e1 in hrec:
+        d = hbm.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += nbytes
+        d[2] += e0.elapsed_time(e1)
+    roofline_pass.hbm = {k: dict(launches=v[0], algorithmic_GB=round(v[1] / 1e9, 3), ms=round(v[2], 3),
+                                 GBps=round(v[1] / max(v[2], 1e-9) / 1e6, 1),
+                                 frac_of_8TBps=round(v[1] / max(v[2], 1e-9) / 1e6 / 8000.0, 3)) for k, v in hbm.items()}
     rec = [r for r in rec if r[0] != "head1"]   # K==1 head uses plain reduction kernels, not the MFMA family
     trainer.use_graph, trainer.two_streams, trainer.wgrad_stream = was_graph, was_two, was_aw
     fam = [r for r in rec if r[0] != "c3_fwd"]   # the 3-channel forward is its own streaming kernel (edge.hip)
@@ -125,6 +136,25 @@ def roofline_pass(trainer, A, B, start_iter):
         d[1] += f
         d[2] += e0.elapsed_time(e1)
     return flops, ms, len(fam), by
+
+
+def step_split_ms(trainer, A, B, start_iter, cycles=4):
+    """D-step and G-step time separately: HIP events around single iterations, default dispatch mode."""
+    ui = trainer.args.update_interval
+    it = (start_iter + 2 * ui) // ui * ui
+    for k in range(ui):
+        trainer.train_iteration(A, B, it + k)
+    it += ui
+    acc = {"D": [], "G": []}
+    for k in range(cycles * ui):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        trainer.train_iteration(A, B, it + k)
+        e1.record()
+        acc["D" if trainer.is_dis_step(it + k) else "G"].append((e0, e1))
+    trainer.finish()
+    torch.cuda.synchronize()
+    return {f"ms_{k}_step": round(sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1), 3) for k, v in acc.items()}
 
 
 def cpu_baseline(image_size, batch, update_interval=3):
@@ -196,6 +226,16 @@ def main():
                     by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
                                    tflops=round(v[1] / max(v[2], 1e-9) / 1e9, 1)) for k, v in by.items()})
     extra = {}
+    if roof is not None:
+        extra["hbm_bound_families"] = getattr(roofline_pass, "hbm", {})
+        extra["note_hbm"] = ("HBM-bound kernel families (SURVEY 8(d)): algorithmic bytes / HIP-event time per op in the same "
+                             "instrumented single-stream cycle; an op may be several kernels (bn_backward = partial + finalize + apply)")
+    # whole-step arithmetic rate from the live algorithmic FLOPs of a D,G,G cycle (5.568 GFLOP/img at 64 px,
+    # 640.8 at 512 px), and the D-step / G-step split
+    live = {64: 5.568e9, 512: 640.8e9}.get(a.image_size)
+    if live is not None:
+        extra["whole_step_tflops"] = round(value / world * live / 1e12, 2)
+    extra.update(step_split_ms(trainer, A, B, it))
     if not a.no_512:     # (same switch as the other extra line)
         ui = trainer.args.update_interval
         it2 = (it + 2 * ui) // ui * ui

@@ -64,6 +64,30 @@ class _prof:
         return False
 
 
+# Same hook for the HBM-bound kernel families: (family, algorithmic bytes, start event, end event).
+PROFILE_HBM = None
+
+
+class _hbm:
+    def __init__(self, name, nbytes):
+        self.on = PROFILE_HBM is not None
+        if self.on:
+            self.name, self.nbytes = name, nbytes
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE_HBM.append((self.name, self.nbytes, self.e0, self.e1))
+        return False
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -225,7 +249,8 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
     n, _, h, wd = x.shape
     k = w.shape[0]
     y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
-    with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48):
+    with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), \
+            _hbm("edge_c3_fwd", 4.0 * (x.numel() + y.numel())):
         _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
                    "dg_conv4x4s2_c3_fwd")
     return y
@@ -240,8 +265,9 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     dx = torch.empty((n, 3, 2 * ho, 2 * wo), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_dgrad_workspace_bytes(k), dy.device)
-    _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb, _stream()),
-               "dg_conv4x4s2_c3_dgrad")
+    with _hbm("edge_c3_dgrad", 4.0 * (dy.numel() + dx.numel())):
+        _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
+                                           _stream()), "dg_conv4x4s2_c3_dgrad")
     return dx
 
 
@@ -259,11 +285,13 @@ def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE,
     if act_out is not None and act != ACT_NONE:
         ao = as_nhwc(act_out)
         assert ao.shape == dy.shape
-        _lib.check(L.dg_conv4x4s2_c3_wgrad_act(_ptr(dy), _ptr(ao), act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k,
-                                               int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_act")
+        with _hbm("edge_c3_wgrad", 4.0 * (2 * dy.numel() + x.numel())):
+            _lib.check(L.dg_conv4x4s2_c3_wgrad_act(_ptr(dy), _ptr(ao), act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k,
+                                                   int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_act")
         return dw
-    _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, int(accumulate), _ptr(ws), wsb,
-                                       _stream()), "dg_conv4x4s2_c3_wgrad")
+    with _hbm("edge_c3_wgrad", 4.0 * (dy.numel() + x.numel())):
+        _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, int(accumulate), _ptr(ws), wsb,
+                                           _stream()), "dg_conv4x4s2_c3_wgrad")
     return dw
 
 
@@ -276,8 +304,9 @@ def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
     saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
-    _lib.check(L.dg_bn_train_stats(_ptr(y), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
-                                   _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
+    with _hbm("bn_stats", 4.0 * m * c):
+        _lib.check(L.dg_bn_train_stats(_ptr(y), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                       _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
     return saved
 
 
@@ -295,8 +324,9 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     y = as_nhwc(y)
     n, c, h, w = y.shape
     z = empty_nhwc(n, c, h, w, y.device)
-    _lib.check(_lib.load().dg_bn_act_fwd(_ptr(y), _ptr(z), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
-                                         act, slope, _stream()), "dg_bn_act_fwd")
+    with _hbm("bn_apply", 8.0 * n * h * w * c):
+        _lib.check(_lib.load().dg_bn_act_fwd(_ptr(y), _ptr(z), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+                                             act, slope, _stream()), "dg_bn_act_fwd")
     return z
 
 
@@ -316,8 +346,9 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
         dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
-    _lib.check(L.dg_bn_act_bwd(_ptr(dz), _ptr(y), _ptr(dy), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act, slope,
-                               _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
+    with _hbm("bn_backward", 20.0 * m * c):
+        _lib.check(L.dg_bn_act_bwd(_ptr(dz), _ptr(y), _ptr(dy), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act, slope,
+                                   _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
     return dy, dgamma, dbeta
 
 
@@ -439,5 +470,7 @@ def adam_advance(state, lr, beta1, beta2):
 
 
 def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-    _lib.check(_lib.load().dg_adam_step_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2,
-                                             eps, weight_decay, grad_scale, _stream()), "dg_adam_step_flat")
+    with _hbm("adam", 28.0 * p.numel()):
+        _lib.check(_lib.load().dg_adam_step_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1,
+                                                 beta2,
+                                                 eps, weight_decay, grad_scale, _stream()), "dg_adam_step_flat")
