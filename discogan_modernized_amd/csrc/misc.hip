@@ -22,7 +22,6 @@ extern "C" int dg_set_option(const char* name, int value) {
     if (!strcmp(name, "splitk")) g_options[DG_OPT_SPLITK] = value;
     else if (!strcmp(name, "kt")) g_options[DG_OPT_KT] = value;
     else if (!strcmp(name, "target_wgs")) g_options[DG_OPT_TARGET_WGS] = value;
-    else if (!strcmp(name, "desync")) g_options[DG_OPT_DESYNC] = value;
     else if (!strcmp(name, "split_below")) g_options[DG_OPT_SPLIT_BELOW] = value;
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)
     else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);

@@ -48,7 +48,10 @@ typedef void* dg_stream_t;
 int dg_version(void);
 const char* dg_last_error(void);
 
-/* ---- tuning knobs (process-global, for benchmarking; 0 = heuristic) ------------------------ */
+/* ---- tuning knobs (process-global, for benchmarking and tests; 0 = heuristic) ----------------
+ * "kt" 16|32: K-tile of the conv kernels;  "splitk" n: force n K-splits;  "target_wgs" n: workgroups a split
+ * grid aims for (512);  "split_below" n: split K only when the tile grid has fewer workgroups (256);
+ * "pointer_path" 1: use the 64-bit addressing kernels that tensors >= 2 GiB fall back to. */
 int dg_set_option(const char* name, int value);
 
 /* ---- interior convolutions: implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------

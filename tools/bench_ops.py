@@ -36,12 +36,10 @@ def main():
     ap.add_argument("--kt", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--target_wgs", type=int, default=0)
-    ap.add_argument("--desync", type=int, default=0)
     a = ap.parse_args()
     _lib.set_option("kt", a.kt)
     _lib.set_option("splitk", a.splitk)
     _lib.set_option("target_wgs", a.target_wgs)
-    _lib.set_option("desync", a.desync)
     dev = "cuda"
     ch = stage_channels(a.size)
     N, S = a.batch, a.size
