@@ -253,8 +253,13 @@ def main():
                               cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew)
         A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
         log("512px models built")
-        dt5, _ = timed_run(tr512, A5, B5, 6, 6, world)
+        dt5, it5 = timed_run(tr512, A5, B5, 6, 6, world)
         log(f"512px done: {dt5 / 6 * 1e3:.1f} ms/step")
+        if not a.no_roofline:
+            f5, ms5, n5, _ = roofline_pass(tr512, A5, B5, it5)
+            extra["roofline_512px_bs32"] = dict(achieved=round(f5 / ms5 / 1e9, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                                frac=round(f5 / ms5 / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), launches_per_cycle=n5,
+                                                whole_step_tflops=round(32 * world * 6 / dt5 * 640.8e9 / world / 1e12, 2))
         extra.update(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
                      note="BASELINE configs[3]: tops2hanbok image_size=512 batch_size=32 per GPU, fp32, 6 timed steps")
         del tr512, A5, B5
