@@ -236,6 +236,15 @@ def main():
     if live is not None:
         extra["whole_step_tflops"] = round(value / world * live / 1e12, 2)
     extra.update(step_split_ms(trainer, A, B, it))
+    if not a.no_512 and world == 1:
+        trb = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
+                              use_graph=not a.no_graph, two_streams=not a.single_stream, mfma_dtype="bf16")
+        dtb, _ = timed_run(trb, A, B, a.steps, a.warmup, world)
+        extra["images_per_sec_bf16_mfma"] = round(a.batch_size * world * a.steps / dtb, 2)
+        extra["note_bf16"] = ("same workload with mfma_dtype=bf16 (BASELINE configs[4] arithmetic: conv operands rounded to bf16, "
+                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate / BatchNorm / master weights / Adam). NOT the headline value.")
+        del trb
+        torch.cuda.empty_cache()
     if not a.no_512:     # (same switch as the other extra line)
         ui = trainer.args.update_interval
         it2 = (it + 2 * ui) // ui * ui
@@ -260,6 +269,13 @@ def main():
             extra["roofline_512px_bs32"] = dict(achieved=round(f5 / ms5 / 1e9, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                                                 frac=round(f5 / ms5 / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), launches_per_cycle=n5,
                                                 whole_step_tflops=round(32 * world * 6 / dt5 * 640.8e9 / world / 1e12, 2))
+        if world == 1:
+            del tr512
+            torch.cuda.empty_cache()
+            tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
+                                    use_graph=not a.no_graph, two_streams=not a.single_stream, mfma_dtype="bf16")
+            dtb5, _ = timed_run(tr512, A5, B5, 6, 6, world)
+            extra["images_per_sec_512px_bs32_bf16_mfma"] = round(32 * world * 6 / dtb5, 2)
         extra.update(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
                      note="BASELINE configs[3]: tops2hanbok image_size=512 batch_size=32 per GPU, fp32, 6 timed steps")
         del tr512, A5, B5

@@ -56,6 +56,7 @@ struct IgemmArgs {
     // cyc after the epilogue stores are issued, wall1, XCC/CU id}; nullptr = off
     long long* stamps;
     unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
+    int prec;                  // 1: bf16 MFMA operands (option "bf16"; BUF kernels only)
 };
 
 #define NEG_BIG (-(1 << 28))
@@ -71,7 +72,12 @@ __device__ float dg_zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0
 // ~12 of the 64-bit pointer path (mad_i64, three 64-bit adds, compares, pointer select), which matters because
 // everything between two MFMAs has to fit the ~48 issue cycles a 64-cycle MFMA leaves (stamps: the K loop ran
 // at 87 % of the sustained matrix rate with 12-instruction clumps per load).  !BUF = any size, pointer path.
-template <int MODE, int WM, int WN, int KT, bool BUF>
+// PREC 1: the GEMM operands are rounded to bf16 (RNE) on their way from LDS to the matrix cores and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors, LDS tiles, BatchNorm, master weights and Adam stay
+// fp32 (BASELINE configs[4]: "bf16 MFMA + fp32 BatchNorm accum").  Products of two bf16 values are exact in
+// fp32, so the result equals an fp32 convolution of the rounded operands up to summation order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int MODE, int WM, int WN, int KT, bool BUF, int PREC>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr bool A_KM = (MODE == MODE_WGRAD);
@@ -468,9 +474,69 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         advance(it + 3 < it_end ? 1 : 0);
     };
-    for (int it = it_begin; it < it_end; it += 2) {
-        body(std::integral_constant<int, 0>{}, it);
-        if (it + 1 < it_end) body(std::integral_constant<int, 1>{}, it + 1);
+    // bf16 operand path: 8 MFMAs of 32 cycles per K-tile instead of 64 of 64 cycles, so the loop is bound by
+    // operand movement, not by the matrix pipe; no hand interleave, the compiler schedules it
+    auto fetch_bf = [&](const float* As, const float* Bs, int g, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31, col = wn * 64 + i * 32 + l31;
+            float ta[8], tb[8];
+            if (!A_KM) {
+                const f32x4 v0 = *(const f32x4*)(As + row * LDA + g * 16 + 8 * lh), v1 = *(const f32x4*)(As + row * LDA + g * 16 + 8 * lh + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ta[j] = v0[j]; ta[4 + j] = v1[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ta[j] = As[(g * 16 + 8 * lh + j) * LDA + row];
+            }
+            if (!B_KM) {
+                const f32x4 v0 = *(const f32x4*)(Bs + col * LDB + g * 16 + 8 * lh), v1 = *(const f32x4*)(Bs + col * LDB + g * 16 + 8 * lh + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tb[j] = v0[j]; tb[4 + j] = v1[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tb[j] = Bs[(g * 16 + 8 * lh + j) * LDB + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[i][j] = (__bf16)ta[j]; b[i][j] = (__bf16)tb[j]; }
+        }
+    };
+    auto body_bf = [&](auto P, int it) {
+        constexpr int p_ = decltype(P)::value;
+        const float* As = smem + p_ * STAGE;
+        const float* Bs = As + A_FLOATS;
+        float* nxt = smem + (p_ ^ 1) * STAGE;
+        const int itn = min(it + 2, it_last);
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) load_A(p_, i, itn);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_B(p_, i, itn);
+#pragma unroll
+        for (int g = 0; g < KT / 16; ++g) {
+            bf16x8 a[2], b[2];
+            fetch_bf(As, Bs, g, a, b);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jn], acc[i][jn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) store_A(nxt, p_ ^ 1, i);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) store_B(nxt, p_ ^ 1, i);
+        advance(it + 3 < it_end ? 1 : 0);
+        __syncthreads();
+    };
+    if constexpr (PREC == 1) {
+        for (int it = it_begin; it < it_end; it += 2) {
+            body_bf(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < it_end) body_bf(std::integral_constant<int, 1>{}, it + 1);
+        }
+    } else {
+        for (int it = it_begin; it < it_end; it += 2) {
+            body(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < it_end) body(std::integral_constant<int, 1>{}, it + 1);
+        }
     }
 
     if (stp) stp[3] = clock64();
@@ -835,6 +901,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
+        a.prec = (fits && dg_get_option(DG_OPT_BF16) == 1) ? 1 : 0;
     }
     const int BM = 64 * pl->wm, BN = 64 * pl->wn;
     a.tilesM = (a.M + BM - 1) / BM;
@@ -852,10 +919,12 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
 template <int MODE, int WM, int WN, int KT>
 static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
-        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3>), dim3(grid), dim3(256), 0, st, a);
+    if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0 && a.prec == 1)
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, MODE != MODE_FWD_C3 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
+    else if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, 0>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false, 0>), dim3(grid), dim3(256), 0, st, a);
 }
 
 static long long* g_stamp_buf = nullptr;

@@ -45,7 +45,7 @@ def default_args(**over):
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
-                 cu_partition=None, mfma_turns=False, skew_steps=0):
+                 cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32"):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -87,6 +87,12 @@ class DiscoGANTrainer:
         # 64 px / batch 256: a cross-queue event per conv costs more than the overlap it buys) -> off.
         self.mfma_turns = bool(mfma_turns) and two_streams
         self.skew_steps = int(skew_steps)
+        # mfma_dtype "bf16": the interior conv GEMMs round their operands to bf16 and run on the bf16 matrix path
+        # with fp32 accumulation (BASELINE configs[4]); tensors, BatchNorm, losses, master weights, Adam stay fp32.
+        # Process-global library option, set for the lifetime of this trainer's calls.
+        if mfma_dtype not in ("f32", "bf16"):
+            raise ValueError("mfma_dtype must be 'f32' or 'bf16'")
+        self.mfma_dtype = mfma_dtype
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -301,6 +307,8 @@ class DiscoGANTrainer:
         from . import ops as _ops
         _F.WGRAD_STREAM = self.wgrad_stream
         _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
+        from . import _lib as _l
+        _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 0)
         try:
             out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)

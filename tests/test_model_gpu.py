@@ -374,6 +374,34 @@ def test_unread_losses_skip_only_log_work():
                     assert v[k] == r[k], (it, k, v[k], r[k])
 
 
+def test_bf16_mfma_training_step_tracks_fp32():
+    """mfma_dtype="bf16" (BASELINE configs[4]: bf16 MFMA operands, fp32 accumulate / BatchNorm / master weights /
+    Adam).  Kernel-level exactness is in test_ops_gpu.py::test_conv_bf16_operands; here the whole first iteration must
+    track the fp32 oracle within bf16 rounding (losses rtol 2e-2 at step 0) and training must stay
+    finite and deterministic."""
+    S, N = 64, 4
+    st = O.build_state(image_size=S, seed=1234)
+    A, B = O.synthetic_batch(N, S, seed=0)
+    ref = O.losses_to_floats(O.train_iteration(st, A, B, 0, do_step=False))
+    runs = []
+    for rep in range(2):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234, mfma_dtype="bf16")
+        vals = [tr.losses_to_floats(tr.train_iteration(A.to(DEV), B.to(DEV), it)) for it in range(6)]
+        torch.cuda.synchronize()
+        runs.append((vals, tr.optim_gen.flat_p.clone()))
+    got = runs[0][0][0]
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 2e-2 * abs(v) + 1e-4, f"bf16 step 0 {k}: {got[k]} vs fp32 oracle {v}"
+    for vals in runs[0][0]:
+        assert all(v == v and abs(v) < 1e6 for v in vals.values()), vals
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "bf16 path must be deterministic"
+    # and the fp32 path is untouched afterwards (the option is per trainer call)
+    tr32 = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+    g32 = tr32.losses_to_floats(tr32.train_iteration(A.to(DEV), B.to(DEV), 0, do_step=False))
+    for k, v in ref.items():
+        assert abs(g32[k] - v) <= 2e-4 * abs(v) + 1e-6, f"fp32 after bf16 {k}: {g32[k]} vs {v}"
+
+
 def test_async_wgrad_stream_is_bitwise_neutral():
     """Weight-gradient kernels on their own stream (off the backward critical path): identical results."""
     A, B = synthetic_batch(4, 16, 0, DEV)

@@ -87,6 +87,28 @@ def test_conv_s2_options(kt, splitk):
         _lib.set_option("splitk", 0)
 
 
+@pytest.mark.parametrize("N,C,K,H", [(2, 128, 256, 8), (3, 64, 128, 16), (4, 256, 64, 16), (2, 512, 512, 4)])
+def test_conv_bf16_operands(N, C, K, H):
+    """Option "bf16": operands rounded to bf16 (RNE), bf16 MFMA, fp32 accumulate.  bf16 x bf16 products are exact in
+    fp32, so the result must equal the fp32 op on the ROUNDED operands up to summation order (tolerance as fp32)."""
+    r = lambda t_: t_.bfloat16().float()
+    x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    yr = TF.conv2d(r(x).double(), r(w).double(), stride=2, padding=1).float()
+    dxr = TF.conv_transpose2d(r(dy).double(), r(w).double(), stride=2, padding=1).float()
+    dwr = torch.nn.grad.conv2d_weight(r(x).double(), w.shape, r(dy).double(), stride=2, padding=1).float()
+    _lib.set_option("bf16", 1)
+    try:
+        xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+        close(ops.conv_fwd(xg, wg, 2, 1), yr, what="bf16 conv fwd")
+        close(ops.conv_dgrad(dyg, wg, (H, H), 2, 1), dxr, rtol=2e-4, what="bf16 conv dgrad")
+        close(ops.conv_wgrad(dyg, xg, 2, 1), dwr, rtol=2e-4, what="bf16 conv wgrad")
+        # and it is NOT the fp32 result (the rounding is really applied)
+        yf = TF.conv2d(x, w, stride=2, padding=1)
+        assert (ops.conv_fwd(xg, wg, 2, 1).cpu() - yf).abs().max() > 1e-4 * yf.abs().max()
+    finally:
+        _lib.set_option("bf16", 0)
+
+
 def test_pointer_path_kernels():
     """Tensors of 2 GiB and more use the 64-bit addressing instantiations (no buffer descriptors); force them
     on small shapes so that path stays covered."""
