@@ -66,7 +66,8 @@ def main_worker(local_rank, args):
         from .trainer import DiscoGANTrainer
         device = torch.device("cuda", torch.cuda.current_device())
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
-                                  process_group=pg, use_graph=not args.no_graph)
+                                  process_group=pg, use_graph=not args.no_graph,
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"))
         load_checkpoints(args, trainer)
         if args.distributed:
             dist.barrier()

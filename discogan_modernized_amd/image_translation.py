@@ -63,6 +63,8 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
     p.add_argument("--save_train_state", action="store_true",
                    help="also write train_state_{iters}.pth (weights + Adam moments + iteration) at every model save")
     p.add_argument("--resume", type=str, default=None, help="train_state_*.pth to continue from (exact resume)")
+    p.add_argument("--mfma_dtype", type=str, default="f32", choices=["f32", "bf16"],
+                   help="bf16: conv operands rounded to bf16 on the matrix cores, fp32 accumulate/BatchNorm/weights/Adam")
     return p
 
 
@@ -113,7 +115,8 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
         model_path.mkdir(parents=True, exist_ok=True)
     if trainer is None:
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
-                                  process_group=process_group, use_graph=not args.no_graph)
+                                  process_group=process_group, use_graph=not args.no_graph,
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"))
     data_A, data_B = load_domains(args, device, rank)
     data_size = min(len(data_A), len(data_B))
     n_batches = data_size // args.batch_size
