@@ -1,8 +1,10 @@
 // 3-channel edge layers, image side NCHW (the reference hands over / receives NCHW images:
-// image_translation.py:332-333, model.py:8,80,142).  The forward direction (3 -> K) lives in
-// igemm.hip (MODE_FWD_C3).  Here: the K -> 3 direction and the [K][3][4][4] weight gradient.
-// All are HBM-bound (AI ~ 20 FLOP/B); both hot kernels feed the matrix cores so the VALU stays free.
+// image_translation.py:332-333, model.py:8,80,142): the 3 -> K forward for K == 64 (the tiled MODE_FWD_C3 path
+// in igemm.hip is the fallback for other K), the K -> 3 direction and the [K][3][4][4] weight gradient.
+// All are HBM-bound (AI ~ 20 FLOP/B); the hot kernels feed the matrix cores so the VALU stays free.
 //
+//   c3_fwd (K == 64): a wave owns groups of 32 consecutive output pixels; MFMA operands gathered straight from
+//       the NCHW image with range-checked buffer loads (no LDS, no barriers after the weights are staged).
 //   c3_dgrad (K == 64): out[n,c,2a+ph,2b+pw] for a 2x2 output quad is a [9 neighbours x 64 k] . [576 x 12]
 //       product: M = quads, N = 12 (c,ph,pw) padded to 16, K = 576, on v_mfma_f32_16x16x4_f32.  The
 //       [576][16] weight image is structurally 4/9 dense (each output parity uses 2x2 of the 3x3

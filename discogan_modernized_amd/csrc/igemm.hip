@@ -16,9 +16,13 @@
 // HBM: 16-byte global loads -> 16-byte ds_write_b128, no transposes anywhere.
 //
 // Tiling: 256 threads = 4 waves (WM x WN), each wave owns a 64x64 output tile = 2x2 MFMA 32x32
-// accumulators (64 VGPRs).  K-tile KT (32 or 16), LDS double buffered, ONE barrier per K-tile:
-//   global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
-//   buffer after them, so HBM/L2 latency hides under 64 (KT=32) MFMAs x 64 cycles.
+// accumulators (64 VGPRs).  K-tile KT (32 or 16), LDS double buffered, two register sets, ONE barrier per
+// K-tile placed 8 MFMAs before the end of the tile (see the pipeline comment in the kernel): tile t+2 is in
+// flight from HBM/L2 while tile t+1 waits in registers and tile t is multiplied out of LDS.
+// Addressing (BUF): buffer descriptors + 32-bit offsets, masked vectors read out of range (zeros); the 64-bit
+// pointer form (!BUF, masked vectors read a zero block) remains for tensors >= 2 GiB.
+// PREC 1: operands rounded to bf16 between LDS and the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+// Epilogue: accumulators transposed through LDS, float4 stores (16 lanes per 256-B row segment).
 // LDS operand images:
 //   "k-contiguous" [row][KT+4]  : lane reads one b128 = its A/B values for FOUR consecutive MFMAs
 //                                 (row stride 36 or 20 floats -> conflict-free b128 reads)
@@ -26,9 +30,9 @@
 // The k index inside an 8-wide group is permuted identically for A and B (lane-half h, step j ->
 // kk = 4h + j), which a GEMM is invariant to.
 //
-// Split-K: when the tile grid cannot fill 256 CUs x 2 workgroups, the K loop is split over
-// blockIdx; partial fp32 slabs go to the caller's workspace and a second kernel sums them in a fixed
-// order (bitwise reproducible; no float atomics).
+// Split-K: when the tile grid has fewer than one workgroup per CU (and for every weight gradient), the K loop
+// is split over blockIdx; partial fp32 slabs go to the caller's workspace and a second kernel sums them in a
+// fixed order (bitwise reproducible; no float atomics).
 #include "dg_common.h"
 #include <type_traits>
 
