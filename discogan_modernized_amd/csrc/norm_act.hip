@@ -93,7 +93,21 @@ __device__ __forceinline__ int bn_reduce_partials(const float* __restrict__ part
     const int c = blockIdx.x * BN_FIN_CH + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int r = pl; r < rchunks; r += 32) {
+        int r = pl;
+        for (; r + 96 < rchunks; r += 128) {       // 8 loads in flight, summed in row order
+            float vs[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vs[u] = part[(long)(r + 32 * u) * C + c];
+                vq[u] = part[((long)rchunks + r + 32 * u) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (double)vs[u];
+                q += (double)vq[u];
+            }
+        }
+        for (; r < rchunks; r += 32) {
             s += (double)part[(long)r * C + c];
             q += (double)part[((long)rchunks + r) * C + c];
         }
@@ -275,7 +289,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const int c = blockIdx.x * BN_FIN_CH + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int r = pl; r < rchunks; r += 32) {
+        int r = pl;
+        for (; r + 96 < rchunks; r += 128) {       // 8 loads in flight, summed in row order
+            double vs[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vs[u] = part[(long)(r + 32 * u) * C + c];
+                vq[u] = part[((long)rchunks + r + 32 * u) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += vs[u];
+                q += vq[u];
+            }
+        }
+        for (; r < rchunks; r += 32) {
             s += part[(long)r * C + c];
             q += part[((long)rchunks + r) * C + c];
         }
