@@ -308,13 +308,16 @@ class DiscoGANTrainer:
         _F.WGRAD_STREAM = self.wgrad_stream
         _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
         from . import _lib as _l
-        _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 0)
+        if self.mfma_dtype == "bf16":
+            _l.set_option("bf16", 1)
         try:
             out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
+            if self.mfma_dtype == "bf16":
+                _l.set_option("bf16", 0)          # the library default stays fp32 for everyone else
         if self.async_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:
