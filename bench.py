@@ -16,7 +16,10 @@ One JSON line on rank 0 with the contract fields plus
                  launch in one D,G,G cycle / summed HIP-event durations of those launches
   cpu_baseline : oracle/discogan_ref.py (PyTorch-CPU restatement of the reference step, pinned to the
                  reference's golden vectors) timed on the host cores for a bounded sample
-  extra        : the 512 px / batch 32 configuration (BASELINE configs[3]) for a few steps
+  extra        : side measurements, never the headline: the HBM-bound kernel families (GB/s), whole-step TFLOP/s,
+                 the D-step / G-step split, the rate on unlogged iterations, the 512 px / batch 32 configuration
+                 (BASELINE configs[3]) with its own roofline leg, and both sizes with bf16 MFMA operands
+                 (BASELINE configs[4] arithmetic)
 """
 import argparse
 import json
