@@ -33,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (never the 2:1-sparsity figure); only used with --mfma_dtype bf16
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                 "r01_pmc_traffic_per_launch_64px_bs256.json")
 
@@ -63,6 +64,8 @@ def parse():
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
     ap.add_argument("--cu_partition", default=os.environ.get("DG_CU_PARTITION", ""), choices=["", "xcd", "half"],
                     help="run the two chains on CU-masked streams (disjoint halves of the chip)")
+    ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[4] arithmetic for the MAIN run (the JSON then says dtype bf16); default f32")
     ap.add_argument("--skew", type=int, default=int(os.environ.get("DG_SKEW", "0")), help="hold the B chain back by this many steps of the A chain")
     ap.add_argument("--turns", action="store_true", help="make the two chains take turns on the matrix cores (measured slower)")
     ap.add_argument("--async_wgrad", action="store_true",
@@ -206,7 +209,8 @@ def main():
     trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
                               use_graph=not a.no_graph, two_streams=not a.single_stream,
                               async_wgrad=a.async_wgrad and not a.single_stream,
-                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew)
+                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew,
+                              mfma_dtype=a.mfma_dtype)
     A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
     log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
     dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
@@ -220,9 +224,13 @@ def main():
         flops, ms, nlaunch, by = roofline_pass(trainer, A, B, it)
         log(f"roofline pass done: {flops / ms / 1e9:.1f} TFLOP/s over {nlaunch} igemm launches")
         ach = flops / (ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)",
-                    achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic_bytes(a.image_size, a.batch_size),
+        peak = MFMA_F32_PEAK_TFLOPS if a.mfma_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
+        kname = ("igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)" if a.mfma_dtype == "f32" else
+                 "igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16, fp32 tensors: operand movement bound, see DESIGN.md 3.1)")
+        roof = dict(bound="mfma", kernel=kname,
+                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(ach / peak, 4),
+                    traffic=pmc_traffic_bytes(a.image_size, a.batch_size) if a.mfma_dtype == "f32" else None,
                     traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32,true> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
                     launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
                     avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
@@ -295,9 +303,10 @@ def main():
     if rank == 0:
         line = dict(metric="images/sec per DiscoGAN train step", value=round(value, 2), unit="images/s",
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.mfma_dtype, data="synthetic",
                     config=dict(workload=f"edges2shoes discogan image_size={a.image_size} batch_size={a.batch_size} per GPU "
-                                         f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped",
+                                         f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped"
+                                         + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)"),
                                 global_batch=a.batch_size * world, parallelism=f"dp{world}",
                                 hipgraph=used_graph, hip_streams=1 if a.single_stream else 2,
                                 allreduce_overlap=used_overlap),
