@@ -39,12 +39,12 @@ PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pro
 
 
 def pmc_traffic_bytes(image_size, batch):
-    """HBM-side bytes per launch of the dominant instantiation (igemm_kernel<0,2,2,32,true>) from the committed
+    """HBM-side bytes per launch of the dominant instantiation (igemm_kernel<0,2,2,32,true,0>) from the committed
     rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/); only valid for the profiled workload."""
     if (image_size, batch) != (64, 256) or not os.path.exists(PMC_TRAFFIC_FILE):
         return None
     try:
-        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"]["void igemm_kernel<0, 2, 2, 32, true>(IgemmArgs)"]
+        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"]["void igemm_kernel<0, 2, 2, 32, true, 0>(IgemmArgs)"]
         return int(k["hbm_MB_per_launch"] * 1024 * 1024)
     except Exception:
         return None
@@ -231,7 +231,7 @@ def main():
                     achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                     frac=round(ach / peak, 4),
                     traffic=pmc_traffic_bytes(a.image_size, a.batch_size) if a.mfma_dtype == "f32" else None,
-                    traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32,true> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
+                    traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32,true,0> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
                     launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
                     avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
                     by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),

@@ -250,10 +250,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     int kchunks = 1, tap = 0, chunk = 0;
     if (MODE == MODE_FWD) kchunks = Cc / KT;
     if (MODE == MODE_DGRAD_S2) kchunks = K / KT;
-    if (MODE == MODE_FWD || MODE == MODE_DGRAD_S2) {
+    // FWD walks the reduction channel-chunk major, taps inner, and the taps in the order r, s in (0, 2, 1, 3): the
+    // taps that read the same input pixels (s and s+2 shift by one output column, r and r+2 by one output row) are
+    // then 1 and 4 K-tiles apart instead of 2*kchunks and 8*kchunks, so the re-reads hit the XCD's L2 more often
+    // (PMC FETCH_SIZE, profiles/).  `tap` counts 0..15 in that order; (fwd_r, fwd_s) is the filter position.
+    if (MODE == MODE_FWD) {
+        chunk = it_begin >> 4;
+        tap = it_begin & 15;
+    } else if (MODE == MODE_DGRAD_S2) {
         tap = it_begin / kchunks;
         chunk = it_begin - tap * kchunks;
     }
+    auto fwd_r = [&]() { const int a = tap >> 2; return ((a & 1) << 1) | (a >> 1); };
+    auto fwd_s = [&]() { const int b = tap & 3; return ((b & 1) << 1) | (b >> 1); };
 
     f32x4 ra[2][NVA], rb[2][NVB];   // two register sets: tiles t+1 (waiting to be written to LDS) and t+2 (in flight)
 
@@ -268,9 +277,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     auto load_A = [&](int set, int i, int it) {
         if (BUF && MODE == MODE_FWD) {
-            const int r = tap >> 2, sx = tap & 3;
+            const int r = fwd_r(), sx = fwd_s();
             const int soff = ((r * W + sx) * Cc + chunk * KT) * 4;                  // wave-uniform
-            ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1));
+            ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1));
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         } else if (BUF && MODE == MODE_WGRAD) {
             ra[set][i] = ld4b(rA, a_ob[i] + it * (KT * 4) * K);
         } else if (MODE == MODE_FWD) {
-            const int r = tap >> 2, s = tap & 3, c0 = chunk * KT;
+            const int r = fwd_r(), s = fwd_s(), c0 = chunk * KT;
             const int iy = a_y[i] + r, ix = a_x[i] + s;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             ra[set][i] = ld4(Ag, (long)(a_pix[i] + r * W + s) * Cc + c0 + acq * 4, ok);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     auto load_B = [&](int set, int i, int it) {
         if (BUF && MODE == MODE_FWD) {
-            rb[set][i] = ld4b(rB, b_ob[i] + it * (KT * 4));
+            rb[set][i] = ld4b(rB, b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * 4);
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             rb[set][i] = ld4b(rB, ((pix * Cc + wg_c) * 4) | wg_colbad | -bad);
         } else if (MODE == MODE_FWD) {
             const int k = n0 + brow0 + i * B_RSTEP;
-            rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)it * KT + bcq * 4, k < K);
+            rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)((fwd_r() * 4 + fwd_s()) * Cc + chunk * KT) + bcq * 4, k < K);
         } else if (MODE == MODE_FWD_C3) {
             const int k = n0 + brow0 + i * B_RSTEP;
             rb[set][i] = ld4(Bg, (long)k * 48 + it * 16 + bcq * 4, k < K);
@@ -364,7 +373,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     // (tap, chunk) advance without control flow; `go` = 0 freezes the state on the last iteration
     auto advance = [&](int go) {
-        if (MODE == MODE_FWD || MODE == MODE_DGRAD_S2) {
+        if (MODE == MODE_FWD) {
+            tap += go;
+            const int wrap = (tap == 16) ? 1 : 0;
+            tap = wrap ? 0 : tap;
+            chunk += wrap;
+        } else if (MODE == MODE_DGRAD_S2) {
             chunk += go;
             const int wrap = (chunk == kchunks) ? 1 : 0;
             chunk = wrap ? 0 : chunk;
