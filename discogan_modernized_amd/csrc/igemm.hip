@@ -61,6 +61,7 @@ struct IgemmArgs {
     long long* stamps;
     unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
     int prec;                  // 1: bf16 MFMA operands (option "bf16"; BUF kernels only)
+    int xcd_group;             // workgroups sharing operand-A rows are placed on one XCD (needs tilesM * splits % 8 == 0)
 };
 
 #define NEG_BIG (-(1 << 28))
@@ -117,14 +118,32 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     const int l31 = lane & 31, lh = lane >> 5;
 
     int bid = blockIdx.x;
-    const int tn = bid % p.tilesN;
-    bid /= p.tilesN;
-    const int tm = bid % p.tilesM;
-    bid /= p.tilesM;
-    int parity = 0, split = bid;
-    if (MODE == MODE_DGRAD_S2) {
-        parity = bid & 3;
-        split = bid >> 2;
+    int tn, tm, parity = 0, split;
+    if (p.xcd_group) {
+        // Workgroups that read the same operand-A rows -- the N-tile columns of a row tile and, for the transposed
+        // conv, its four output-parity classes -- should share an L2.  Workgroups are dealt to the 8 XCDs round
+        // robin by blockIdx, so such a group of G workgroups gets blockIdx values 8 apart (same XCD, dispatched
+        // within one window of 8*G): inner = (bid / 8) % G, (row tile, split) index = (bid / (8G)) * 8 + bid % 8.
+        const int G = p.tilesN * (MODE == MODE_DGRAD_S2 ? 4 : 1);
+        int inner = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = inner & 3;
+            inner >>= 2;
+        }
+        tn = inner;
+        tm = rest % p.tilesM;
+        split = rest / p.tilesM;
+    } else {
+        tn = bid % p.tilesN;
+        bid /= p.tilesN;
+        tm = bid % p.tilesM;
+        bid /= p.tilesM;
+        split = bid;
+        if (MODE == MODE_DGRAD_S2) {
+            parity = bid & 3;
+            split = bid >> 2;
+        }
     }
     const int ph = parity >> 1, pw = parity & 1;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -247,9 +266,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     // ---- K-iteration state ------------------------------------------------------------------------
     // FWD: (tap, chunk) over (16, Cc/KT);  DGRAD_S2: (t, chunk) over (4, K/KT)
-    int kchunks = 1, tap = 0, chunk = 0;
-    if (MODE == MODE_FWD) kchunks = Cc / KT;
-    if (MODE == MODE_DGRAD_S2) kchunks = K / KT;
+    int tap = 0, chunk = 0;
     // FWD walks the reduction channel-chunk major, taps inner, and the taps in the order r, s in (0, 2, 1, 3): the
     // taps that read the same input pixels (s and s+2 shift by one output column, r and r+2 by one output row) are
     // then 1 and 4 K-tiles apart instead of 2*kchunks and 8*kchunks, so the re-reads hit the XCD's L2 more often
@@ -257,9 +274,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     if (MODE == MODE_FWD) {
         chunk = it_begin >> 4;
         tap = it_begin & 15;
-    } else if (MODE == MODE_DGRAD_S2) {
-        tap = it_begin / kchunks;
-        chunk = it_begin - tap * kchunks;
+    } else if (MODE == MODE_DGRAD_S2) {     // same idea: the 2x2 taps of a parity class are adjacent K-tiles
+        chunk = it_begin >> 2;
+        tap = it_begin & 3;
     }
     auto fwd_r = [&]() { const int a = tap >> 2; return ((a & 1) << 1) | (a >> 1); };
     auto fwd_s = [&]() { const int b = tap & 3; return ((b & 1) << 1) | (b >> 1); };
@@ -379,10 +396,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             tap = wrap ? 0 : tap;
             chunk += wrap;
         } else if (MODE == MODE_DGRAD_S2) {
-            chunk += go;
-            const int wrap = (chunk == kchunks) ? 1 : 0;
-            chunk = wrap ? 0 : chunk;
-            tap += wrap;
+            tap += go;
+            const int wrap = (tap == 4) ? 1 : 0;
+            tap = wrap ? 0 : tap;
+            chunk += wrap;
         }
     };
     auto store_A = [&](float* stage, int set, int i) { *(f32x4*)(stage + (arow0 + i * A_RSTEP) * LDA + acq * 4) = ra[set][i]; };
@@ -928,6 +945,10 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     a.splits = choose_splits(base, a.nIt);
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
+    // measured (PMC, MB per launch beyond L2, 64 px layers): forward 83 -> 76, weight-grad 222 -> 90, input-grad with
+    // the 256x64 tile 135 -> 104, input-grad with 128x128 tiles 64 -> 76 (worse: left in plain order)
+    a.xcd_group = ((a.tilesM * a.splits) % 8 == 0 && dg_get_option(DG_OPT_RESERVED) == 0 &&
+                   !(pl->mode == MODE_DGRAD_S2 && pl->wm != 4)) ? 1 : 0;   // option "no_xcd_group" switches it off
     pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
     pl->stat_rows = 0;
     if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)
