@@ -14,6 +14,11 @@ Differences that do not change any result:
     backward raise), and keeps BN / feature-matching statistics rank-local like DDP does.
   * steady-state iterations replay a captured hipGraph (zero_grad + forward + backward) instead of
     re-dispatching ~600 kernels from Python.
+  * the A-side chain (G_A, D_A) and the B-side chain (G_B, D_B) run on two HIP streams and are issued layer by
+    layer in lock step (``forward_steps`` generators); every loss term lands in one device vector and the
+    curriculum mix / its gradient seeds are one kernel each.
+  * ``need_losses=False`` (iterations whose loss values nobody reads): a D-step skips the two reconstruction
+    passes, which feed only the log line there.
 """
 from __future__ import annotations
 
