@@ -72,6 +72,20 @@ SIGNATURES = {
     "dg_loss_mix_bwd": (_i, [_p, _p, _i, _f, _i, _i, _p]),
     "dg_adam_advance": (_i, [_p, _d, _d, _d, _p]),
     "dg_adam_step_flat": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p]),
+    "dg_bce_target_fwd": (_i, [_p, _p, _i, _p, _p]),
+    "dg_bce_target_bwd": (_i, [_p, _p, _i, _p, _p, _p]),
+    "dg_hinge_fwd": (_i, [_p, _p, _z, _f, _p, _p, _z, _p]),
+    "dg_hinge_bwd": (_i, [_p, _p, _z, _f, _p, _p, _p]),
+    "dg_dp_unique_id_bytes": (_i, []),
+    "dg_dp_get_unique_id": (_i, [_p, _z]),
+    "dg_dp_init": (_i, [_i, _i, _p, _z]),
+    "dg_dp_world_size": (_i, []),
+    "dg_dp_rank": (_i, []),
+    "dg_dp_allreduce_sum": (_i, [_p, _z, _p]),
+    "dg_dp_broadcast": (_i, [_p, _z, _i, _p]),
+    "dg_dp_barrier": (_i, [_p, _p]),
+    "dg_dp_destroy": (_i, []),
+    "dg_u8hwc_to_f32chw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

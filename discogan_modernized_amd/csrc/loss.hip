@@ -75,6 +75,50 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     dp[i] = gout[0] * (v - label) / fmaxf((1.f - v) * v, 1e-12f) / (float)n;
 }
 
+// nn.BCELoss against an arbitrary target tensor (image_translation.py:157-166 builds ones / zeros tensors on the
+// host; the trainer passes the constant as a scalar, this form serves callers that keep the reference's tensors).
+__global__ __launch_bounds__(256) void bce_target_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int n,
+                                                             float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = p[i], y = t[i];
+        const float l1 = fmaxf(logf(v), -100.f), l0 = fmaxf(logf(1.f - v), -100.f);
+        s += (double)((y - 1.f) * l0 - y * l1);
+    }
+    s = dg_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / n);
+}
+__global__ __launch_bounds__(256) void bce_target_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int n,
+                                                             const float* __restrict__ gout, float* __restrict__ dp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = p[i];
+    dp[i] = gout[0] * (v - t[i]) / fmaxf((1.f - v) * v, 1e-12f) / (float)n;
+}
+
+// nn.HingeEmbeddingLoss(margin 1, mean): l_i = x_i (y_i == 1) | max(0, margin - x_i) (y_i == -1)
+// (image_translation.py:141-142 calls it with all-ones targets, where it is x.mean()).
+__global__ __launch_bounds__(256) void hinge_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, long n,
+                                                            float margin, double* __restrict__ part) {
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float xv = x[i], yv = y[i];
+        s += (yv == 1.f ? xv : 0.f) + (yv == -1.f ? fmaxf(margin - xv, 0.f) : 0.f);
+    }
+    block_partial_store(s, part);
+}
+__global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long n,
+                                                        float margin, const float* __restrict__ gout, float* __restrict__ dx) {
+    const float g = gout[0] / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float xv = x[i], yv = y[i];
+        dx[i] = (yv == 1.f ? g : 0.f) + ((yv == -1.f && margin - xv > 0.f) ? -g : 0.f);
+    }
+}
+
 // Feature matching, stage 1: batch-chunk partial sums.  grid = (J/4/256 blocks, nchunks); each thread
 // owns one float4 column and walks its chunk of the batch (coalesced 4 KB rows per block).
 // part layout: [2][nchunks][J]  (0: real, 1: fake)
@@ -214,6 +258,37 @@ extern "C" int dg_bce_bwd(const float* p, int n, float label, const float* gout,
     DG_CHECK_ARG(p && gout && dp && n > 0, "dg_bce_bwd: bad argument");
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, n, label, gout, dp);
     DG_CHECK_LAUNCH("bce_bwd");
+    return DG_OK;
+}
+extern "C" int dg_bce_target_fwd(const float* p, const float* target, int n, float* loss, dg_stream_t stream) {
+    DG_CHECK_ARG(p && target && loss && n > 0, "dg_bce_target_fwd: bad argument");
+    hipLaunchKernelGGL(bce_target_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, n, loss);
+    DG_CHECK_LAUNCH("bce_target_fwd");
+    return DG_OK;
+}
+extern "C" int dg_bce_target_bwd(const float* p, const float* target, int n, const float* gout, float* dp, dg_stream_t stream) {
+    DG_CHECK_ARG(p && target && gout && dp && n > 0, "dg_bce_target_bwd: bad argument");
+    hipLaunchKernelGGL(bce_target_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, target, n, gout, dp);
+    DG_CHECK_LAUNCH("bce_target_bwd");
+    return DG_OK;
+}
+extern "C" int dg_hinge_fwd(const float* x, const float* y, size_t n, float margin, float* loss, void* ws, size_t ws_bytes,
+                            dg_stream_t stream) {
+    DG_CHECK_ARG(x && y && loss && n > 0, "dg_hinge_fwd: bad argument");
+    if (!ws || ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_hinge_fwd: workspace too small");
+    const int g = loss_grid((long)n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hinge_partial_kernel, dim3(g), dim3(256), 0, st, x, y, (long)n, margin, (double*)ws);
+    DG_CHECK_LAUNCH("hinge_partial");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)n, loss);
+    DG_CHECK_LAUNCH("hinge_final");
+    return DG_OK;
+}
+extern "C" int dg_hinge_bwd(const float* x, const float* y, size_t n, float margin, const float* gout, float* dx,
+                            dg_stream_t stream) {
+    DG_CHECK_ARG(x && y && gout && dx && n > 0, "dg_hinge_bwd: bad argument");
+    hipLaunchKernelGGL(hinge_bwd_kernel, dim3(loss_grid((long)n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, margin, gout, dx);
+    DG_CHECK_LAUNCH("hinge_bwd");
     return DG_OK;
 }
 static int fm_chunks(int N, size_t J) {

@@ -83,3 +83,38 @@ extern "C" int dg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, in
     DG_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && N < 65536, "dg_nhwc_to_nchw: bad argument");
     return launch_transpose(x, y, N, H * W, C, (hipStream_t)s);  // [N][HW][C] -> [N][C][HW]
 }
+
+// ---- image ingest (dataset.py:62-66): uint8 [N][H][W][3] (decoded image rows) -> float [N][3][H][W] in [0,1] ----
+// The reference does `/255.` and `transpose(2,0,1)` per image on the host and copies 4 B/channel over PCIe; here the
+// uint8 batch crosses PCIe (1 B/channel) and one pass on the device normalises and re-lays it out.  Each thread
+// produces 4 consecutive x of one (n, y): reads 12 contiguous bytes, writes one float4 into each channel plane.
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long npix4,
+                                                              int HW4, int HW, int bgr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix4; i += (long)gridDim.x * 256) {
+        const long n = i / HW4;
+        const int q = (int)(i - n * HW4);                 // group of 4 pixels inside the image
+        const uint32_t* s = (const uint32_t*)(src + (n * HW + (long)q * 4) * 3);   // 12 bytes, 4-byte aligned
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+        uint8_t b[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[j] = (w0 >> (8 * j)) & 255; b[4 + j] = (w1 >> (8 * j)) & 255; b[8 + j] = (w2 >> (8 * j)) & 255; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = bgr ? 2 - c : c;
+            // dataset.py:65: image.astype(np.float32) / 255. -- a correctly rounded fp32 division (a multiply by
+            // 1/255.f can differ by one ulp), so divide
+            const f32x4 v = {(float)b[cs] / 255.f, (float)b[3 + cs] / 255.f, (float)b[6 + cs] / 255.f, (float)b[9 + cs] / 255.f};
+            *(f32x4*)(dst + (n * 3 + c) * HW + (long)q * 4) = v;
+        }
+    }
+}
+extern "C" int dg_u8hwc_to_f32chw(const uint8_t* src, float* dst, int N, int H, int W, int bgr, dg_stream_t s) {
+    DG_CHECK_ARG(src && dst && N > 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "dg_u8hwc_to_f32chw: bad argument (H*W must be a multiple of 4)");
+    const int HW = H * W;
+    const long npix4 = (long)N * (HW / 4);
+    long g = (npix4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(u8hwc_to_f32chw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, src, dst, npix4, HW / 4, HW, bgr);
+    DG_CHECK_LAUNCH("u8hwc_to_f32chw");
+    return DG_OK;
+}

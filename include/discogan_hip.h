@@ -212,6 +212,38 @@ int dg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, co
                       float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                       dg_stream_t s);
 
+/* nn.BCELoss against a target TENSOR (image_translation.py:157-166 materialises ones / zeros label tensors);
+ * same -100 log clamp and 1e-12 backward guard as dg_bce_fwd/_bwd.  p, target: [n]. */
+int dg_bce_target_fwd(const float* p, const float* target, int n, float* loss, dg_stream_t s);
+int dg_bce_target_bwd(const float* p, const float* target, int n, const float* gout, float* dp, dg_stream_t s);
+/* nn.HingeEmbeddingLoss(margin, mean) for targets in {+1, -1} (image_translation.py:141-142,269; with the
+ * reference's all-ones targets it is x.mean()).  ws >= dg_loss_workspace_bytes(). */
+int dg_hinge_fwd(const float* x, const float* y, size_t n, float margin, float* loss, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_hinge_bwd(const float* x, const float* y, size_t n, float margin, const float* gout, float* dx, dg_stream_t s);
+
+/* ---- data-parallel exchange group over RCCL / xGMI ---------------------------------------------
+ * Replaces dist.init_process_group("nccl") (distributed_image_translation.py:31-38), DistributedDataParallel's
+ * gradient all-reduce (:401-404,513-518), dist.barrier() (:398,573-574), destroy_process_group (:42-46).
+ * One communicator per process (one process per GPU; the current HIP device at dg_dp_init is the rank's GPU).
+ * Bootstrap: rank 0 calls dg_dp_get_unique_id into a HOST buffer of dg_dp_unique_id_bytes() bytes, ships it to the
+ * other ranks out of band (the host layer uses the c10d TCP store), every rank calls dg_dp_init with it.
+ * Collectives are in place, fp32, enqueued on the CALLER's stream (no internal stream, no synchronisation);
+ * all-reduce is a SUM -- DDP's division by the world size is folded into dg_adam_step_flat's grad_scale.
+ * The communicator handle is the only state the library keeps between calls.  RCCL is dlopen'ed on first use. */
+int dg_dp_unique_id_bytes(void);
+int dg_dp_get_unique_id(void* id_out_host, size_t bytes);
+int dg_dp_init(int rank, int world, const void* unique_id_host, size_t bytes);
+int dg_dp_world_size(void);   /* ranks in the communicator; 0 before dg_dp_init */
+int dg_dp_rank(void);         /* -1 before dg_dp_init */
+int dg_dp_allreduce_sum(float* buf, size_t n, dg_stream_t stream);
+int dg_dp_broadcast(float* buf, size_t n, int root, dg_stream_t stream);
+int dg_dp_barrier(float* scratch1 /* one device float owned by the caller */, dg_stream_t stream);
+int dg_dp_destroy(void);
+
+/* ---- image ingest (dataset.py:62-66): uint8 [N][H][W][3] -> float [N][3][H][W] = pixel / 255 -------------
+ * bgr != 0 swaps the channel order (cv2.imread-style BGR sources).  H*W must be a multiple of 4. */
+int dg_u8hwc_to_f32chw(const uint8_t* src, float* dst, int N, int H, int W, int bgr, dg_stream_t s);
+
 /* ---- layout helpers --------------------------------------------------------------------------- */
 int dg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);
 int dg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);

@@ -10,6 +10,12 @@ Outputs (committed, small JSON -- data only, no reference source):
                                     image_translation.get_gan_loss/get_fm_loss, driven through the
                                     loop body image_translation.py:336-390 for iterations 0,1,2
                                     (D,G,G) on synthetic tensors (seed 1234 models, seed 0 data, N=2).
+  tests/golden/ref_s512_n2_gstep.json   TRUE reference, ONE G-step taken from the seeded init (loop body driven
+                                    with iters=1 on fresh seed-1234 weights, N=2): generator gradient norms /
+                                    samples at the reference's only size without a preceding D update.
+  tests/golden/ref_s512_n32_dstep.json / ref_s512_n32_gstep.json
+                                    TRUE reference at BASELINE configs[3]'s own batch (N=32): iteration 0 (D-step)
+                                    and a G-step from the seeded init; ~35 GB RSS, minutes of CPU (--n32).
   tests/golden/oracle_s64_n4.json   same capture from oracle/discogan_ref.py for the derived 64 px
                                     network (the reference cannot run at 64 px).
   tests/golden/oracle_s16_n4.json   tiny 16 px variant (2 stride-2 stages) used by fast GPU tests.
@@ -43,14 +49,15 @@ def tensor_digest(t):
                 samples=[float(f[i]) for i in sample_idx(f.numel())])
 
 
-def capture_run(nets, optim_gen, optim_dis, crit, gan_fn, fm_fn, A, B, n_iters, args):
-    """Drives image_translation.py:336-390 and records everything the parity tests compare."""
+def capture_run(nets, optim_gen, optim_dis, crit, gan_fn, fm_fn, A, B, n_iters, args, iter_list=None, lean=False):
+    """Drives image_translation.py:336-390 and records everything the parity tests compare.
+    iter_list: the iteration indices to run (default 0..n_iters-1); lean: skip the per-feature digests."""
     rec = dict(init={}, iters=[])
     for name, net in nets.items():
         rec["init"][name] = {k: tensor_digest(v) for k, v in net.state_dict().items()
                              if v.dtype.is_floating_point}
     gA, gB, dA, dB = nets["gen_A"], nets["gen_B"], nets["dis_A"], nets["dis_B"]
-    for iters in range(n_iters):
+    for iters in (iter_list if iter_list is not None else range(n_iters)):
         t0 = time.time()
         for net in nets.values():
             net.zero_grad()
@@ -92,8 +99,8 @@ def capture_run(nets, optim_gen, optim_dis, crit, gan_fn, fm_fn, A, B, n_iters, 
                                B_fake=B_dis_fake.detach().reshape(-1).tolist()),
                   outputs=dict(AB=tensor_digest(AB), BA=tensor_digest(BA),
                                ABA=tensor_digest(ABA), BAB=tensor_digest(BAB)),
-                  feats=dict(A_real=[tensor_digest(f) for f in A_feats_real],
-                             B_fake=[tensor_digest(f) for f in B_feats_fake]),
+                  feats=({} if lean else dict(A_real=[tensor_digest(f) for f in A_feats_real],
+                                              B_fake=[tensor_digest(f) for f in B_feats_fake])),
                   grad_norms={}, grad_samples={}, after_step={}, buffers={})
         live = ("dis_A", "dis_B") if dstep else ("gen_A", "gen_B")
         for name in live:                      # only the stepped side's grads are results (F5)
@@ -121,7 +128,7 @@ ARGS = dict(learning_rate=2e-4, beta1=0.5, beta2=0.999, weight_decay=0.00001, ga
             starting_rate=0.01, default_rate=0.5, update_interval=3)
 
 
-def run_reference(n=2, n_iters=3):
+def run_reference(n=2, n_iters=3, iter_list=None):
     for name in ("cv2", "torchvision", "torchvision.transforms"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
@@ -144,8 +151,12 @@ def run_reference(n=2, n_iters=3):
     g = torch.Generator().manual_seed(0)
     A = torch.rand(n, 3, 512, 512, generator=g)
     B = torch.rand(n, 3, 512, 512, generator=g)
-    rec = capture_run(nets, og, od, crit, ref_it.get_gan_loss, ref_it.get_fm_loss, A, B, n_iters, ARGS)
+    rec = capture_run(nets, og, od, crit, ref_it.get_gan_loss, ref_it.get_fm_loss, A, B, n_iters, ARGS,
+                      iter_list=iter_list, lean=n > 2)
+    if n > 2:                      # the init digests are those of ref_s512_n2.json (same seed): keep the file small
+        rec["init"] = {}
     rec["meta"] = dict(source="reference /root/reference model.py + image_translation.py loop body :336-390",
+                       iter_list=list(iter_list) if iter_list is not None else list(range(n_iters)),
                        image_size=512, n=n, model_seed=1234, data_seed=0, torch=torch.__version__,
                        threads=torch.get_num_threads(), args=ARGS,
                        state_dict_keys={k: list(v.state_dict().keys()) for k, v in nets.items()})
@@ -170,7 +181,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ref", action="store_true")
     ap.add_argument("--skip-oracle", action="store_true")
+    ap.add_argument("--gstep", action="store_true", help="only: reference G-step from the seeded init, N=2")
+    ap.add_argument("--n32", choices=["dstep", "gstep"], default=None,
+                    help="only: reference at N=32 (BASELINE configs[3] batch), iteration 0 or a G-step from init")
     a = ap.parse_args()
+    if a.gstep or a.n32:
+        n = 32 if a.n32 else 2
+        kind = a.n32 or "gstep"
+        print(f"reference @512 N={n} {kind} from the seeded init ...", flush=True)
+        rec = run_reference(n=n, iter_list=[0] if kind == "dstep" else [1])
+        name = f"ref_s512_n{n}_{kind}.json"
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(rec, f)
+        print("wrote", name, flush=True)
+        return
     if not a.skip_ref:
         print("reference @512 N=2 ...", flush=True)
         rec = run_reference()

@@ -8,7 +8,9 @@
   * size-independent properties at the benchmark shapes (adjoint identities of the conv kernels)
 
 Tolerances: step-0 losses rtol 1e-4; steps 1-2 rtol 1e-2 (discriminator saturates,
-BCE clamp regime); gradients 1e-3 of the tensor norm.
+BCE clamp regime); gradients 1e-3 of the tensor norm against a fixture, and max(1e-4, 4 x the reference's own fp32
+error) against the fp64 oracle once the activation-kink ambiguity is removed (tests/kink_probe.py: the fp64 ground
+truth differentiates the same LeakyReLU/ReLU sign pattern the implementation under test used).
 """
 import json
 import os
@@ -22,6 +24,7 @@ from discogan_modernized_amd import model as M  # noqa: E402
 from discogan_modernized_amd import ops  # noqa: E402
 from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch  # noqa: E402
 from oracle import discogan_ref as O  # noqa: E402  (checker only)
+from tests import kink_probe as KP  # noqa: E402  (checker only)
 
 DEV = "cuda"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -64,26 +67,21 @@ def test_seeded_weights_and_state_dict_match_oracle(S, N):
         assert [n for n, _ in o.named_parameters()] == [n for n, _ in m.named_parameters()]
 
 
-def _kink_sensitivity(net, run):
-    """LeakyReLU/ReLU derivatives are discontinuous at 0: a BN output within fp32 rounding of 0 gets slope 1.0
-    in one implementation and 0.2 / 0 in another, and at these tiny batches ONE such element moves every
-    upstream gradient by ~1e-2.  Probe: fp64 copy of the oracle net with every BN bias shifted by +-5e-6
-    (~ the fp32 rounding of the BN output); returns {name: rel. change of that gradient}, '' = the input."""
-    import copy
-    res = []
-    for shift in (5e-6, -5e-6):
-        n64 = copy.deepcopy(net).double()
-        for m in n64.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.bias.data.add_(shift)
-        for p_ in n64.parameters():
-            p_.grad = None
-        xin = run(n64)
-        g = {n: p_.grad.clone() for n, p_ in n64.named_parameters()}
-        if xin is not None:
-            g[""] = xin
-        res.append(g)
-    return {k: rel_err(res[0][k], res[1][k]) for k in res[0]}
+def _masked64_grads(onet, masks, run):
+    """Gradients of the fp64 copy of `onet` that differentiates the recorded activation sign pattern."""
+    n64 = KP.masked_copy(onet, masks)
+    for p_ in n64.parameters():
+        p_.grad = None
+    xin = run(n64)
+    assert n64._mask_counter[0] == len(masks)
+    g = {n: p_.grad.clone() for n, p_ in n64.named_parameters()}
+    if xin is not None:
+        g[""] = xin
+    return g
+
+
+GRAD_ATOL_REL = 1e-4      # floor of the per-tensor gradient tolerance (relative L2)
+NOISE_MULT = 4            # x the reference's own fp32-vs-fp64 error on the same piecewise-linear function
 
 
 @pytest.mark.parametrize("S,N", [(16, 4), (64, 3)])
@@ -91,8 +89,10 @@ def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
     og, od, mg, md = build_pair(S)
     x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(3))
     # ---- generator
-    yo = og(x)
-    ym = mg(x.to(DEV))
+    with KP.record_masks_oracle({"g": og}) as mo:
+        yo = og(x)
+    with KP.record_masks_hip({"g": mg}) as mh:
+        ym = mg(x.to(DEV))
     assert ym.shape == yo.shape and ym.is_contiguous()
     max_close(ym, yo, 1e-4, 1e-5, "G forward")
     gout = torch.rand(yo.shape, generator=torch.Generator().manual_seed(4)) - 0.5
@@ -102,17 +102,19 @@ def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
     def run_g(n64):
         n64(x.double()).backward(gout.double())
         return None
-    sens = _kink_sensitivity(og, run_g)
+    truth_h, truth_o = _masked64_grads(og, mh["g"], run_g), _masked64_grads(og, mo["g"], run_g)
     for (n, po), (_, pm) in zip(og.named_parameters(), mg.named_parameters()):
-        e = rel_err(pm.grad, po.grad)
-        assert e < max(2e-3, 8 * sens[n]), f"G grad {n}: rel err {e:.2e} (kink sensitivity {sens[n]:.2e})"
+        e, noise = rel_err(pm.grad, truth_h[n]), rel_err(po.grad, truth_o[n])
+        assert e < max(GRAD_ATOL_REL, NOISE_MULT * noise), f"G grad {n}: rel err {e:.2e} (reference fp32 {noise:.2e})"
     for (n, bo), (_, bm) in zip(og.named_buffers(), mg.named_buffers()):
         max_close(bm.float(), bo.float(), 1e-4, 1e-6, f"G buffer {n}")
     # ---- discriminator (input requires grad: the fake pass back-props into the generator)
     xo = x.clone().requires_grad_(True)
     xm = x.clone().to(DEV).requires_grad_(True)
-    po_, fo = od(xo)
-    pm_, fm = md(xm)
+    with KP.record_masks_oracle({"d": od}) as mo:
+        po_, fo = od(xo)
+    with KP.record_masks_hip({"d": md}) as mh:
+        pm_, fm = md(xm)
     assert pm_.shape == po_.shape == (N, 1, 1, 1)
     max_close(pm_, po_, 1e-4, 1e-6, "D out")
     assert len(fm) == len(fo)
@@ -133,13 +135,12 @@ def test_generator_discriminator_fwd_bwd_vs_oracle(S, N):
             l = l + (b * wgts[i].double()).sum() * 0.01
         l.backward()
         return xi.grad
-    sens = _kink_sensitivity(od, run_d)
-    e = rel_err(xm.grad, xo.grad)
-    assert e < max(2e-3, 8 * sens[""]), f"D input grad rel err {e:.2e} (kink sensitivity {sens['']:.2e})"
+    truth_h, truth_o = _masked64_grads(od, mh["d"], run_d), _masked64_grads(od, mo["d"], run_d)
+    e, noise = rel_err(xm.grad, truth_h[""]), rel_err(xo.grad, truth_o[""])
+    assert e < max(GRAD_ATOL_REL, NOISE_MULT * noise), f"D input grad rel err {e:.2e} (reference fp32 {noise:.2e})"
     for (n, po), (_, pm) in zip(od.named_parameters(), md.named_parameters()):
-        e = rel_err(pm.grad, po.grad)
-        assert e < max(2e-3, 8 * sens[n]), f"D grad {n}: rel err {e:.2e} (kink sensitivity {sens[n]:.2e})"
-
+        e, noise = rel_err(pm.grad, truth_h[n]), rel_err(po.grad, truth_o[n])
+        assert e < max(GRAD_ATOL_REL, NOISE_MULT * noise), f"D grad {n}: rel err {e:.2e} (reference fp32 {noise:.2e})"
 
 
 def test_unfused_sequential_matches_fused():
@@ -179,21 +180,26 @@ def check_init_against_fixture(tr, fix):
             assert [float(f[i]) for i in sample_idx(f.numel())] == ref["samples"], f"init {name}.{k}"
 
 
-def run_and_compare(fix, S, N, grad_tol=1e-3):
-    """Free-running 3 iterations against a golden fixture.
+def run_and_compare(fix, S, N, grad_tol=1e-3, init_fix=None, tr=None):
+    """Free-running iterations against a golden fixture (iteration indices come from the records; the first
+    record always starts from the seeded init).
 
-    Iteration 0 (D-step from the seeded init) is held to the tight tolerances.  From iteration 1 on the
+    The first record is held to the tight tolerances.  From the iteration after a D update on the
     discriminators are saturated (D(real) == 1.0, D(fake) ~ e^-40, BCE -100 clamp): the generator
     gradient is proportional to e^logit, and one Adam step ~ lr*sign(g) on 10^8 weights turns fp32
     rounding noise into logit shifts, so free-running trajectories legitimately drift by percents
     (SURVEY.md 7(v),(vi)).  Those iterations are therefore checked loosely here and TIGHTLY in
-    test_teacher_forced_iterations_vs_oracle, where every iteration starts from identical weights."""
-    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
-    check_init_against_fixture(tr, fix)
+    test_teacher_forced_iterations_vs_oracle, where every iteration starts from identical weights.
+    Returns (trainer, worst sampled-gradient deviation / tensor norm, worst grad-norm deviation)."""
+    if tr is None:
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+    check_init_against_fixture(tr, init_fix if init_fix is not None else fix)
     A, B = synthetic_batch(N, S, 0, DEV)
-    for it, rec in enumerate(fix["iters"]):
+    worst = worst_norm = 0.0
+    for pos, rec in enumerate(fix["iters"]):
+        it = rec["iter"]
         out = tr.train_iteration(A, B, it, do_step=False)
-        strict = it == 0
+        strict = pos == 0
         rtol = 1e-4 if strict else 0.15
         got = tr.losses_to_floats(out)
         for k, v in rec["losses"].items():
@@ -204,16 +210,16 @@ def run_and_compare(fix, S, N, grad_tol=1e-3):
             for k, v in rec["dis_out"].items():
                 t = getattr(out, {"A_real": "A_dis_real", "A_fake": "A_dis_fake", "B_real": "B_dis_real", "B_fake": "B_dis_fake"}[k])
                 assert torch.allclose(t.detach().reshape(-1).cpu(), torch.tensor(v), rtol=1e-3, atol=1e-6), f"iter {it} D out {k}"
-            for k in ("AB", "ABA"):
+            for k in ("AB", "BA", "ABA", "BAB"):
                 f = getattr(out, k).detach().reshape(-1).cpu()
                 ref = rec["outputs"][k]
                 assert abs(float(f.double().sum()) - ref["sum"]) <= 1e-4 * ref["abssum"], f"iter {it} {k} sum"
             live = ("dis_A", "dis_B") if rec["step"] == "D" else ("gen_A", "gen_B")
-            worst = 0.0
             for name in live:
                 for pn, p in tr.nets[name].named_parameters():
                     ref_norm = rec["grad_norms"][name][pn]
                     gn = float(p.grad.double().norm())
+                    worst_norm = max(worst_norm, abs(gn - ref_norm) / max(ref_norm, 1e-30))
                     assert abs(gn - ref_norm) <= 2 * grad_tol * ref_norm + 1e-9, f"iter {it} grad norm {name}.{pn}: {gn} vs {ref_norm}"
                     gs = torch.tensor([float(p.grad.reshape(-1)[i]) for i in sample_idx(p.numel())])
                     rs = torch.tensor(rec["grad_samples"][name][pn])
@@ -240,7 +246,7 @@ def run_and_compare(fix, S, N, grad_tol=1e-3):
                 elif strict:
                     f = b.detach().reshape(-1).cpu()
                     assert abs(float(f.double().sum()) - ref["sum"]) <= 1e-4 * ref["abssum"] + 1e-6, f"iter {it} {name}.{bn_}"
-    return tr
+    return tr, worst, worst_norm
 
 
 @pytest.mark.parametrize("S", [16, 64])
@@ -249,56 +255,74 @@ def test_three_iterations_vs_oracle_fixture(S):
     run_and_compare(fix, S, 4)
 
 
+def _load(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
 def test_three_iterations_vs_reference_golden_512():
     """The only size the reference itself can execute (model.py is hard-wired to 512 px)."""
-    fix = json.load(open(os.path.join(GOLD, "ref_s512_n2.json")))
+    fix = _load("ref_s512_n2.json")
     assert fix["meta"]["source"].startswith("reference")
-    # Gradient tolerance 1e-2: at batch 2 the reference's own fp32 gradients are only good to 2-5e-3 of the
-    # tensor norm against an fp64 run of the same graph (LeakyReLU-derivative flips of BN outputs within
-    # rounding of 0; +-5e-6 BN-bias probe moves them by up to 1.3e-2), measured per tensor with the oracle:
-    # hip-vs-fp64 1e-3..8e-3, reference-fp32-vs-fp64 2e-3..5e-3.  Losses / D outputs stay at 1e-4 / 1e-3.
-    run_and_compare(fix, 512, 2, grad_tol=1e-2)
+    # Gradient tolerance 1e-2 at batch 2: the reference's own fp32 gradients sit 2-5e-3 of the tensor norm from an
+    # fp64 run of the same graph because a handful of BN outputs within rounding of 0 get the other LeakyReLU slope
+    # (counted per network by tests/kink_probe.py; with the sign pattern pinned both implementations are at 1e-5,
+    # test_masked_fp64_gradient_parity_512).  Losses / D outputs stay at 1e-4 / 1e-3.
+    _, worst, worst_norm = run_and_compare(fix, 512, 2, grad_tol=1e-2)
+    print(f"512px N=2 D-step vs reference: worst sampled grad dev {worst:.2e}, worst norm dev {worst_norm:.2e}")
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("S,N", [(16, 4), (64, 4), (128, 2)])
-def test_teacher_forced_iterations_vs_oracle(S, N):
-    """Every iteration starts from the ORACLE's current weights/buffers, so the comparison stays
-    well-conditioned through the saturated-discriminator regime (iterations 1, 2): losses, D outputs,
-    per-tensor gradients, BN buffers, and the Adam update op-wise on the oracle's gradients."""
-    import copy
-    st = O.build_state(image_size=S, seed=1234)
-    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+def test_gstep_from_init_vs_reference_golden_512():
+    """A G-step taken from the seeded init (loop body :336-390 driven with iters=1 on fresh seed-1234 weights, N=2):
+    generator gradients -- the decoder-side backward (convT wgrad/dgrad at 2048 channels, the 3-channel edge kernels at
+    256 -> 512 px) -- against the TRUE reference at its only size, before any discriminator update saturates the losses."""
+    fix = _load("ref_s512_n2_gstep.json")
+    assert fix["meta"]["source"].startswith("reference") and fix["iters"][0]["step"] == "G" and fix["iters"][0]["iter"] == 1
+    _, worst, worst_norm = run_and_compare(fix, 512, 2, grad_tol=1e-2)
+    print(f"512px N=2 G-step-from-init vs reference: worst sampled grad dev {worst:.2e}, worst norm dev {worst_norm:.2e}")
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ["dstep", "gstep"])
+def test_config3_full_batch_vs_reference_golden_512_n32(kind):
+    """BASELINE configs[3] at its own size (tops2hanbok 512 px, batch 32): iteration 0 (D-step) and a G-step from the
+    seeded init against outputs of the TRUE reference at N=32 (tests/golden/make_golden.py --n32; ~35 GB, minutes of
+    CPU in the authoring container).  Losses rtol 1e-4, D outputs 1e-3, gradients 2e-3 of the tensor norm (at batch 32
+    one activation-kink flip weighs 16x less than at batch 2), first Adam step, BN buffers; and the run is repeated:
+    bitwise deterministic."""
+    fix = _load(f"ref_s512_n32_{kind}.json")
+    assert fix["meta"]["source"].startswith("reference") and fix["meta"]["n"] == 32
+    init = _load("ref_s512_n2.json")                     # same seed-1234 construction
+    tr, worst, worst_norm = run_and_compare(fix, 512, 32, grad_tol=2e-3, init_fix=init)
+    print(f"512px N=32 {kind} vs reference: worst sampled grad dev {worst:.2e}, worst norm dev {worst_norm:.2e}")
+    flat = (tr.optim_dis if kind == "dstep" else tr.optim_gen).flat_p.clone()
+    del tr
+    torch.cuda.empty_cache()
+    tr2, _, _ = run_and_compare(fix, 512, 32, grad_tol=2e-3, init_fix=init)
+    assert torch.equal((tr2.optim_dis if kind == "dstep" else tr2.optim_gen).flat_p, flat), "not bitwise deterministic"
+    del tr2
+    torch.cuda.empty_cache()
+
+
+def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, need_noise=True):
+    """Every iteration starts from the ORACLE's current weights/buffers; gradients are compared with an fp64 run of
+    the oracle that differentiates the SAME activation sign pattern the implementation used (tests/kink_probe.py),
+    so no kink term is left and the bound is max(1e-4, 4 x the reference's own fp32 error)."""
+    st = st or O.build_state(image_size=S, seed=1234)
+    tr = tr or DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
     A, B = O.synthetic_batch(N, S, seed=0)
     Ag, Bg = A.to(DEV), B.to(DEV)
-    for it in range(4):
+    table = []
+    for it in (iter_list if iter_list is not None else range(n_iters)):
         for k in st.nets:
             tr.nets[k].load_state_dict(st.nets[k].state_dict())
-        # fp64 run of the same oracle = ground truth.  Two conditioning yardsticks per tensor:
-        #   noise: the oracle's own fp32-vs-fp64 error (first-layer / BN-bias gradients are only good to
-        #          ~1e-2 in the reference's own fp32 arithmetic at small batch);
-        #   sens : LeakyReLU/ReLU have a discontinuous derivative at 0.  A BN output within fp32 rounding
-        #          of 0 gets derivative 1.0 in one implementation and 0.2 (or 0) in another; at batch 4
-        #          ONE such element moves every upstream gradient by ~1% (measured).  We probe it by
-        #          shifting every BN bias by +-5e-6 in fp64 and differencing the gradients.
-        def oracle64_grads(shift):
-            s64 = copy.deepcopy(st)
-            for net in s64.nets.values():
-                net.double()
-                if shift != 0.0:
-                    for m in net.modules():
-                        if isinstance(m, torch.nn.BatchNorm2d):
-                            m.bias.data.add_(shift)
-            torch.set_default_dtype(torch.float64)
-            try:
-                O.train_iteration(s64, A.double(), B.double(), it, do_step=False)
-            finally:
-                torch.set_default_dtype(torch.float32)
-            return s64
-        st64 = oracle64_grads(0.0)
-        st64p, st64m = oracle64_grads(5e-6), oracle64_grads(-5e-6)   # ~ fp32 rounding of u = (y-mean)*gs+beta
-        ref = O.train_iteration(st, A, B, it, do_step=False)
-        out = tr.train_iteration(Ag, Bg, it, do_step=False)
+        with KP.record_masks_oracle(st.nets) as m32:
+            ref = O.train_iteration(st, A, B, it, do_step=False)
+        with KP.record_masks_hip(tr.nets) as mh:
+            out = tr.train_iteration(Ag, Bg, it, do_step=False)
+        torch.cuda.synchronize()
+        s_h = KP.run_masked64(O, st, mh, A, B, it)          # ground truth for the HIP path's piecewise-linear function
+        s_o = KP.run_masked64(O, st, m32, A, B, it) if need_noise else s_h   # ... and for the fp32 oracle's
         got, want = tr.losses_to_floats(out), O.losses_to_floats(ref)
         for k, v in want.items():
             assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-6, f"iter {it} {k}: {got[k]} vs {v}"
@@ -307,22 +331,25 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
                                   rtol=2e-3, atol=1e-30), f"iter {it} {k}"
         dstep = O.is_dis_step(it, st.args)
         live = ("dis_A", "dis_B") if dstep else ("gen_A", "gen_B")
+        worst = [0.0, 0.0, 0.0]
         for name in live:
-            for (pn, po), (_, pm), (_, p64), (_, pp), (_, pq) in zip(
-                    st.nets[name].named_parameters(), tr.nets[name].named_parameters(),
-                    st64.nets[name].named_parameters(), st64p.nets[name].named_parameters(),
-                    st64m.nets[name].named_parameters()):
-                noise = rel_err(po.grad, p64.grad)           # the reference's own fp32 error
-                sens = rel_err(pp.grad, pq.grad)             # activation-derivative discontinuity
-                e = rel_err(pm.grad, p64.grad)
-                assert e < max(1e-3, 8 * noise, 8 * sens), \
-                    f"iter {it} grad {name}.{pn}: rel err {e:.2e} (reference fp32 noise {noise:.2e}, kink sensitivity {sens:.2e})"
+            ph, po_, th, to = (dict(n.named_parameters()) for n in (tr.nets[name], st.nets[name], s_h.nets[name], s_o.nets[name]))
+            for pn in po_:
+                e = rel_err(ph[pn].grad, th[pn].grad)
+                noise = rel_err(po_[pn].grad, to[pn].grad) if need_noise else 0.0
+                worst = [max(worst[0], e), max(worst[1], noise), max(worst[2], e / max(noise, 1e-30))]
+                assert e < max(GRAD_ATOL_REL, NOISE_MULT * noise), \
+                    f"iter {it} grad {name}.{pn}: rel err {e:.2e} vs fp64 on the same activation pattern (reference fp32: {noise:.2e})"
+        flips = {k: sum(int((a.cpu() != b.cpu()).sum()) for a, b in zip(mh[k], m32[k])) for k in mh}
+        table.append((it, "D" if dstep else "G", worst, flips))
         for name in st.nets:
             for (bn_, bo), (_, bm) in zip(st.nets[name].named_buffers(), tr.nets[name].named_buffers()):
                 if bo.dtype == torch.int64:
                     assert int(bo) == int(bm), f"iter {it} {name}.{bn_}"
                 else:
                     max_close(bm, bo, 2e-4, 1e-6, f"iter {it} buffer {name}.{bn_}")
+        if not step:
+            continue
         # Adam op-wise: feed the oracle's gradients to the device optimiser
         for name in live:
             for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
@@ -333,6 +360,30 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
             for (pn, po), (_, pm) in zip(st.nets[name].named_parameters(), tr.nets[name].named_parameters()):
                 d = float((pm.detach().cpu() - po.detach()).abs().max())
                 assert d <= 1e-6, f"iter {it} Adam {name}.{pn}: max diff {d:.2e}"
+    for it, kind, w, flips in table:
+        print(f"S={S} N={N} iter {it} ({kind}): worst grad err hip {w[0]:.2e}, reference fp32 {w[1]:.2e}, worst ratio {w[2]:.2f}; "
+              f"activation sign differences hip vs reference: {flips}")
+    return table
+
+
+@pytest.mark.parametrize("S,N", [(16, 4), (64, 4), (128, 2)])
+def test_teacher_forced_iterations_vs_oracle(S, N):
+    """Losses, D outputs, per-tensor gradients, BN buffers and the Adam update op-wise on the oracle's gradients,
+    through the saturated-discriminator regime (iterations 1-3)."""
+    _teacher_forced(S, N, 4)
+
+
+def test_masked_fp64_gradient_parity_512():
+    """The reference's own network (512 px, batch 2): D-step from the seeded init and a G-step from the same init,
+    every gradient tensor against the fp64 oracle on the implementation's activation pattern.  Together with
+    tests/test_oracle_golden.py (oracle == TRUE reference, bit-equal init and 1e-5 losses) this bounds the HIP path's
+    generator AND discriminator gradients at the reference's only size far below the fixture comparison's flip noise."""
+    st = O.build_state(image_size=512, seed=1234)
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234)
+    # iteration index 0 = D-step, index 1 = G-step, both from the seeded init (no optimiser step in between); the
+    # reference-noise yardstick is skipped here (two more fp64 passes at 512 px): the bound is the 1e-4 floor
+    _teacher_forced(512, 2, 0, tr=tr, st=st, iter_list=[0, 1], step=False, need_noise=False)
+    torch.cuda.empty_cache()
 
 
 def test_graph_replay_equals_eager():
