@@ -1,76 +1,73 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the DiscoGAN training step on MI355X.
 
-    python bench.py --gpus 1 --steps 30 --warmup 9
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                                  # 1 GPU, the metric's 512 px / batch 32 configuration
+    python bench.py --gpus N --steps K --warmup W    # N > 1: starts its own N ranks (one per GPU) and relays rank 0's line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W       # the driver's form: ranks already exist (RANK/WORLD_SIZE in the env)
 
-Workload (BASELINE.json configs[1]): edges2shoes / discogan / image_size=64 / batch_size=256 PER GPU,
-fp32, synthetic uniform [0,1) batches resident in HBM, models from torch.manual_seed(1234).  A "step"
-is one training iteration (4 G passes + 4 D passes forward, backward + Adam of the side selected by
-``iters % 3``; image_translation.py:336-390).  K steps walk the D,G,G cycle; images = batch x ranks
-per step (one (A,B) index = one image, dataset.py:210-213).  Weak scaling: per-GPU batch is fixed.
+Workload of `value` (BASELINE.json metric "images/sec per DiscoGAN train step (64px bs64, 512px bs32)", configs[3]):
+tops2hanbok / discogan / image_size=512 / batch_size=32 PER GPU, fp32, synthetic uniform [0,1) batches resident in
+HBM, models from torch.manual_seed(1234).  A "step" is one training iteration (4 G passes + 4 D passes forward, backward
++ Adam of the side selected by ``iters % 3``; image_translation.py:336-390).  The K timed steps start on a D-step
+(warm-up is rounded up to whole D,G,G cycles) and K defaults to 12 = four whole cycles; images = batch x ranks per step
+(one (A,B) index = one image, dataset.py:210-213).  Weak scaling: per-GPU batch is fixed.
+``--image_size 64`` selects the 64 px network (configs[1]: batch 256; configs[2]'s per-GPU shape: --batch_size 64).
 
 One JSON line on rank 0 with the contract fields plus
-  roofline     : the dominant kernel family (igemm_kernel, fp32 MFMA): algorithmic conv FLOPs of every
-                 launch in one D,G,G cycle / summed HIP-event durations of those launches
-  cpu_baseline : oracle/discogan_ref.py (PyTorch-CPU restatement of the reference step, pinned to the
-                 reference's golden vectors) timed on the host cores for a bounded sample
-  extra        : side measurements, never the headline: the HBM-bound kernel families (GB/s), whole-step TFLOP/s,
-                 the D-step / G-step split, the rate on unlogged iterations, the 512 px / batch 32 configuration
-                 (BASELINE configs[3]) with its own roofline leg, and both sizes with bf16 MFMA operands
-                 (BASELINE configs[4] arithmetic)
+  roofline     : the dominant kernel family (igemm_kernel, fp32 MFMA): algorithmic conv FLOPs of every launch in one
+                 D,G,G cycle / summed HIP-event durations of those launches (events on the launch stream); traffic =
+                 HBM-side bytes per launch of the dominant instantiation from the committed rocprofv3 PMC passes
+  cpu_baseline : oracle/discogan_ref.py (PyTorch-CPU restatement of the reference step, pinned to the reference's
+                 golden vectors) timed on the host cores for a bounded sample of the same 512 px workload
+  comm         : (N > 1) transport, RCCL world size, all-reduce ms per D-step / G-step exchange, overlap mode
+  extra        : side measurements, never the headline: D-step / G-step split, HBM-bound kernel families, the 64 px
+                 configurations (batch 256 with its own roofline leg, batch 64 in both data-parallel dispatch modes),
+                 bf16-MFMA runs (configs[4] arithmetic), the CPU baseline at 64 px / 64
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (never the 2:1-sparsity figure); only used with --mfma_dtype bf16
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r01_pmc_traffic_per_launch_64px_bs256.json")
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (never the 2:1-sparsity figure)
+LIVE_GFLOP_PER_IMAGE = {64: 5.568, 512: 640.8}   # live conv FLOPs of a D,G,G cycle / 3, per image
+WORKLOADS = {512: "tops2hanbok discogan image_size=512 batch_size={b} per GPU (BASELINE configs[3])",
+             64: "edges2shoes discogan image_size=64 batch_size={b} per GPU (BASELINE configs[1]; batch 64 = configs[2]'s per-GPU shape)"}
 
 
-def pmc_traffic_bytes(image_size, batch):
-    """HBM-side bytes per launch of the dominant instantiation (igemm_kernel<0,2,2,32,true,0>) from the committed
-    rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/); only valid for the profiled workload."""
-    if (image_size, batch) != (64, 256) or not os.path.exists(PMC_TRAFFIC_FILE):
-        return None
-    try:
-        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"]["void igemm_kernel<0, 2, 2, 32, true, 0>(IgemmArgs)"]
-        return int(k["hbm_MB_per_launch"] * 1024 * 1024)
-    except Exception:
-        return None
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=9)
-    ap.add_argument("--image_size", type=int, default=64)
-    ap.add_argument("--batch_size", type=int, default=256, help="per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 12 at 512 px, 30 at 64 px)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps, rounded up to whole D,G,G cycles (default 6 / 9)")
+    ap.add_argument("--image_size", type=int, default=512, choices=[64, 512])
+    ap.add_argument("--batch_size", type=int, default=None, help="per GPU (default 32 at 512 px, 256 at 64 px)")
     ap.add_argument("--no_graph", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_512", action="store_true")
+    ap.add_argument("--no_extra", action="store_true", help="headline + roofline only")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
-    ap.add_argument("--cu_partition", default=os.environ.get("DG_CU_PARTITION", ""), choices=["", "xcd", "half"],
-                    help="run the two chains on CU-masked streams (disjoint halves of the chip)")
     ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = BASELINE configs[4] arithmetic for the MAIN run (the JSON then says dtype bf16); default f32")
-    ap.add_argument("--skew", type=int, default=int(os.environ.get("DG_SKEW", "0")), help="hold the B chain back by this many steps of the A chain")
-    ap.add_argument("--turns", action="store_true", help="make the two chains take turns on the matrix cores (measured slower)")
-    ap.add_argument("--async_wgrad", action="store_true",
-                    help="weight-gradient kernels on a third stream (measured: neutral to slightly slower)")
-    return ap.parse_args()
+    ap.add_argument("--comm", default="auto", choices=["auto", "capi", "c10d"], help="data-parallel transport (dp.ExchangeGroup)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="data-parallel exchange overlapped with compute (eager dispatch) or behind a replayed hipGraph")
+    a = ap.parse_args(argv)
+    if a.batch_size is None:
+        a.batch_size = 32 if a.image_size == 512 else 256
+    if a.steps is None:
+        a.steps = 12 if a.image_size == 512 else 30
+    if a.warmup is None:
+        a.warmup = 6 if a.image_size == 512 else 9
+    return a
 
 
 def log(msg):
@@ -78,7 +75,35 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# N > 1 typed as `python bench.py --gpus N`: the parent starts the ranks.  It must not have touched the GPU
+# (a process that initialised HIP must never be replaced or forked into GPU work), so this runs before
+# anything imports torch.cuda state: only `subprocess` is used here.
+def self_launch(a, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    return rc if rc != 0 or line else 1
+
+
 def barrier_sync(world):
+    import torch
+    import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -86,10 +111,13 @@ def barrier_sync(world):
 
 
 def timed_run(trainer, A, B, steps, warmup, world, start_iter=0, need_losses=True):
+    import torch
+    import torch.distributed as dist
     it = start_iter
     for _ in range(warmup):
         trainer.train_iteration(A, B, it, need_losses=need_losses)
         it += 1
+    trainer.finish()
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -106,32 +134,36 @@ def timed_run(trainer, A, B, steps, warmup, world, start_iter=0, need_losses=Tru
 
 
 def roofline_pass(trainer, A, B, start_iter):
-    """One instrumented D,G,G cycle (eager dispatch): HIP events around every igemm launch."""
+    """One instrumented D,G,G cycle (eager dispatch, one stream): HIP events around every igemm launch."""
+    import torch
     from discogan_modernized_amd import ops
     ui = trainer.args.update_interval
     start_iter = (start_iter + ui - 1) // ui * ui            # align to a D-step
-    was_graph, was_two, was_aw = trainer.use_graph, trainer.two_streams, trainer.wgrad_stream
+    saved = (trainer.use_graph, trainer.two_streams, trainer.wgrad_stream)
     trainer.use_graph = False
     trainer.two_streams = False          # isolated kernel durations: one stream, one kernel at a time
     trainer.wgrad_stream = None
     ops.PROFILE = []
     ops.PROFILE_HBM = []
-    for k in range(ui):
-        trainer.train_iteration(A, B, start_iter + k)
-    torch.cuda.synchronize()
-    rec, ops.PROFILE = ops.PROFILE, None
-    hrec, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+    try:
+        for k in range(ui):
+            trainer.train_iteration(A, B, start_iter + k)
+        trainer.finish()
+        torch.cuda.synchronize()
+    finally:
+        rec, ops.PROFILE = ops.PROFILE, None
+        hrec, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+        trainer.use_graph, trainer.two_streams, trainer.wgrad_stream = saved
     hbm = {}
     for name, nbytes, e0, e1 in hrec:
         d = hbm.setdefault(name, [0, 0.0, 0.0])
         d[0] += 1
         d[1] += nbytes
         d[2] += e0.elapsed_time(e1)
-    roofline_pass.hbm = {k: dict(launches=v[0], algorithmic_GB=round(v[1] / 1e9, 3), ms=round(v[2], 3),
-                                 GBps=round(v[1] / max(v[2], 1e-9) / 1e6, 1),
-                                 frac_of_8TBps=round(v[1] / max(v[2], 1e-9) / 1e6 / 8000.0, 3)) for k, v in hbm.items()}
+    hbm = {k: dict(launches=v[0], algorithmic_GB=round(v[1] / 1e9, 3), ms=round(v[2], 3),
+                   GBps=round(v[1] / max(v[2], 1e-9) / 1e6, 1),
+                   frac_of_8TBps=round(v[1] / max(v[2], 1e-9) / 1e6 / 8000.0, 3)) for k, v in hbm.items()}
     rec = [r for r in rec if r[0] != "head1"]   # K==1 head uses plain reduction kernels, not the MFMA family
-    trainer.use_graph, trainer.two_streams, trainer.wgrad_stream = was_graph, was_two, was_aw
     fam = [r for r in rec if r[0] != "c3_fwd"]   # the 3-channel forward is its own streaming kernel (edge.hip)
     flops = sum(r[1] for r in fam)
     ms = sum(r[2].elapsed_time(r[3]) for r in fam)
@@ -141,13 +173,31 @@ def roofline_pass(trainer, A, B, start_iter):
         d[0] += 1
         d[1] += f
         d[2] += e0.elapsed_time(e1)
-    return flops, ms, len(fam), by
+    return flops, ms, len(fam), by, hbm, start_iter + ui
 
 
-def step_split_ms(trainer, A, B, start_iter, cycles=4):
+def pmc_traffic(image_size, batch):
+    """HBM-side bytes per launch of the dominant instantiation (the stride-2 forward igemm) from the committed rocprofv3
+    PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see profiles/README.md); only for the profiled workloads."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_per_launch_{image_size}px_bs{batch}.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            ks = json.load(open(path))["kernels"]
+            cand = [(k, v) for k, v in ks.items() if k.startswith("void igemm_kernel<0,")]
+            k, v = max(cand, key=lambda kv: kv[1]["launches"] * kv[1]["hbm_MB_per_launch"])
+            return int(v["hbm_MB_per_launch"] * 1024 * 1024), f"bytes/launch beyond L2 for {k} from profiles/{os.path.basename(path)} (PMC, offline)"
+        except Exception:
+            continue
+    return None, "no PMC profile committed for this workload"
+
+
+def step_split_ms(trainer, A, B, start_iter, cycles):
     """D-step and G-step time separately: HIP events around single iterations, default dispatch mode."""
+    import torch
     ui = trainer.args.update_interval
-    it = (start_iter + 2 * ui) // ui * ui
+    it = (start_iter + ui - 1) // ui * ui
     for k in range(ui):
         trainer.train_iteration(A, B, it + k)
     it += ui
@@ -160,157 +210,190 @@ def step_split_ms(trainer, A, B, start_iter, cycles=4):
         acc["D" if trainer.is_dis_step(it + k) else "G"].append((e0, e1))
     trainer.finish()
     torch.cuda.synchronize()
-    return {f"ms_{k}_step": round(sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1), 3) for k, v in acc.items()}
+    out = {f"ms_{k}_step": round(sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1), 3) for k, v in acc.items()}
+    out["ms_per_step_whole_cycles"] = round((out["ms_D_step"] + (ui - 1) * out["ms_G_step"]) / ui, 3)
+    return out, it + cycles * ui
 
 
-def cpu_baseline(image_size, batch, update_interval=3):
-    """Oracle step on the host cores: 1 warm-up iteration + one D,G,G cycle."""
+def cpu_baseline(image_size, batch, budget_s, update_interval=3):
+    """Oracle step on the host cores: 1 warm-up iteration + whole D,G,G cycles until the budget is spent."""
     from oracle import discogan_ref as O
     st = O.build_state(image_size=image_size, seed=1234)
     A, B = O.synthetic_batch(batch, image_size, seed=1000)
     O.train_iteration(st, A, B, 1)                      # warm-up (G-step; allocs, oneDNN primitives)
     t0 = time.perf_counter()
     it, n = update_interval, 0
-    while True:                                         # whole D,G,G cycles until ~10 s of CPU work
+    while True:
         for _ in range(update_interval):
             O.train_iteration(st, A, B, it)
             it += 1
             n += 1
         dt = time.perf_counter() - t0
-        if dt >= 10.0 or n >= 60:
+        if dt >= budget_s or n >= 60:
             break
     return batch * n / dt, dt, n
 
 
+def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None):
+    from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args
+    ov = {"auto": None, "on": True, "off": False}[a.overlap] if overlap is None else overlap
+    return DiscoGANTrainer(default_args(), device=dev, image_size=image_size, seed=1234, process_group=pg,
+                           use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
+                           mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov, comm=comm or a.comm)
+
+
+def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycles=0, image_size=None):
+    """value + optional roofline leg + optional D/G split for one trainer; returns a dict."""
+    ui = tr.args.update_interval
+    warmup = (warmup + ui - 1) // ui * ui                 # timed region starts on a D-step
+    dt, it = timed_run(tr, A, B, steps, warmup, world)
+    res = dict(images_per_sec=round(batch * world * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+               warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=bool(tr.overlap_comm))
+    live = LIVE_GFLOP_PER_IMAGE.get(image_size or tr.image_size)
+    if live:
+        res["whole_step_tflops"] = round(batch * steps / dt * live / 1e3, 2)
+    if roofline:
+        flops, ms, nlaunch, by, hbm, it = roofline_pass(tr, A, B, it)
+        bf = tr.mfma_dtype == "bf16"
+        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        res["roofline"] = dict(
+            bound="mfma",
+            kernel=("igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv family)" if bf else
+                    "igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)"),
+            achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+            launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
+            avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
+            by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
+                           tflops=round(v[1] / max(v[2], 1e-9) / 1e9, 1)) for k, v in by.items()})
+        res["hbm_bound_families"] = hbm
+    if split_cycles:
+        sp, it = step_split_ms(tr, A, B, it, split_cycles)
+        res.update(sp)
+    res["_next_iter"] = it
+    return res
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, argv))
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the product path)")
-    if os.environ.get("DG_DIST_BACKEND", "nccl") != "nccl":
-        local = local % max(torch.cuda.device_count(), 1)          # rehearsal: ranks share the visible GPU(s)
+    backend = os.environ.get("DG_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI; gloo = several ranks rehearsed on ONE GPU
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" == RCCL over xGMI; DG_DIST_BACKEND=gloo lets the launch be rehearsed with several ranks on ONE GPU
-        backend = os.environ.get("DG_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
-    from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
+    from discogan_modernized_amd.trainer import synthetic_batch
     dev = torch.device("cuda", local)
+    S, N = a.image_size, a.batch_size
 
-    trainer = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
-                              use_graph=not a.no_graph, two_streams=not a.single_stream,
-                              async_wgrad=a.async_wgrad and not a.single_stream,
-                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew,
-                              mfma_dtype=a.mfma_dtype)
-    A, B = synthetic_batch(a.batch_size, a.image_size, 1000 + rank, dev)
-    log(f"models built; running {a.warmup} warm-up + {a.steps} timed steps @{a.image_size}px batch {a.batch_size} x {world} GPU")
-    dt, it = timed_run(trainer, A, B, a.steps, a.warmup, world)
-    used_graph, used_overlap = bool(trainer.use_graph), bool(trainer.overlap_comm)
-    log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
-    images = a.batch_size * world * a.steps
-    value = images / dt
-
-    roof = None
-    if not a.no_roofline:
-        flops, ms, nlaunch, by = roofline_pass(trainer, A, B, it)
-        log(f"roofline pass done: {flops / ms / 1e9:.1f} TFLOP/s over {nlaunch} igemm launches")
-        ach = flops / (ms * 1e-3) / 1e12
-        peak = MFMA_F32_PEAK_TFLOPS if a.mfma_dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
-        kname = ("igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)" if a.mfma_dtype == "f32" else
-                 "igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16, fp32 tensors: operand movement bound, see DESIGN.md 3.1)")
-        roof = dict(bound="mfma", kernel=kname,
-                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(ach / peak, 4),
-                    traffic=pmc_traffic_bytes(a.image_size, a.batch_size) if a.mfma_dtype == "f32" else None,
-                    traffic_note="bytes/launch beyond L2 for igemm_kernel<0,2,2,32,true,0> from profiles/r01_pmc_traffic_per_launch_64px_bs256.json (PMC, offline)",
-                    launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
-                    avg_launch_us=round(ms * 1e3 / max(nlaunch, 1), 2),
-                    by_op={k: dict(launches=v[0], gflop=round(v[1] / 1e9, 2), ms=round(v[2], 3),
-                                   tflops=round(v[1] / max(v[2], 1e-9) / 1e9, 1)) for k, v in by.items()})
-    extra = {}
+    # ---- headline ------------------------------------------------------------------------------------------
+    tr = make_trainer(a, dev, pg, S)
+    tr.time_comm = world > 1
+    A, B = synthetic_batch(N, S, 1000 + rank, dev)
+    log(f"models built; {a.warmup} warm-up + {a.steps} timed steps @{S}px batch {N} x {world} GPU")
+    head = measure(a, tr, A, B, N, world, a.steps, a.warmup, roofline=not a.no_roofline,
+                   split_cycles=0 if a.no_extra else (2 if S == 512 else 4))
+    log(f"timed region done: {head['ms_per_step']:.3f} ms/step, {head['images_per_sec']:.1f} img/s")
+    comm = None
+    if world > 1:
+        ms = tr.comm_ms()
+        from discogan_modernized_amd import _lib
+        rccl_ws = _lib.load().dg_dp_world_size() if tr.xg.transport == "capi" else (dist.get_world_size() if backend == "nccl" else None)
+        comm = dict(transport=tr.xg.describe(), backend=backend, world_size=dist.get_world_size(), rccl_world_size=rccl_ws,
+                    allreduce_ms_per_D_step=round(ms.get("D", 0.0), 3), allreduce_ms_per_G_step=None,
+                    allreduce_overlap=bool(tr.overlap_comm), exchanges=tr.xg.calls,
+                    payload_MB=dict(D=round(tr.optim_dis.numel * 4 / 1e6, 1), G=round(tr.optim_gen.numel * 4 / 1e6, 1)))
+        if "G" in ms:
+            comm["allreduce_ms_per_G_step"] = round(ms["G"], 3)
+            comm["G_step_buckets"] = len(tr._buckets.buckets) if tr._buckets is not None else 1
+    roof = head.get("roofline")
     if roof is not None:
-        extra["hbm_bound_families"] = getattr(roofline_pass, "hbm", {})
+        traffic, note = pmc_traffic(S, N) if a.mfma_dtype == "f32" else (None, "not profiled for bf16")
+        roof["traffic"], roof["traffic_note"] = traffic, note
+    extra = {k: v for k, v in head.items() if k in ("ms_D_step", "ms_G_step", "ms_per_step_whole_cycles", "whole_step_tflops",
+                                                    "hbm_bound_families")}
+    if "hbm_bound_families" in extra:
         extra["note_hbm"] = ("HBM-bound kernel families (SURVEY 8(d)): algorithmic bytes / HIP-event time per op in the same "
                              "instrumented single-stream cycle; an op may be several kernels (bn_backward = partial + finalize + apply)")
-    # whole-step arithmetic rate from the live algorithmic FLOPs of a D,G,G cycle (SURVEY 8(d): 5.568 GFLOP/img at 64 px,
-    # 640.8 at 512 px), and the D-step / G-step split
-    live = {64: 5.568e9, 512: 640.8e9}.get(a.image_size)
-    if live is not None:
-        extra["whole_step_tflops"] = round(value / world * live / 1e12, 2)
-    extra.update(step_split_ms(trainer, A, B, it))
-    if not a.no_512 and world == 1:
-        trb = DiscoGANTrainer(default_args(), device=dev, image_size=a.image_size, seed=1234, process_group=pg,
-                              use_graph=not a.no_graph, two_streams=not a.single_stream, mfma_dtype="bf16")
-        dtb, _ = timed_run(trb, A, B, a.steps, a.warmup, world)
-        extra["images_per_sec_bf16_mfma"] = round(a.batch_size * world * a.steps / dtb, 2)
-        extra["note_bf16"] = ("same workload with mfma_dtype=bf16 (BASELINE configs[4] arithmetic: conv operands rounded to bf16, "
-                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate / BatchNorm / master weights / Adam). NOT the headline value.")
-        del trb
-        torch.cuda.empty_cache()
-    if not a.no_512:     # (same switch as the other extra line)
-        ui = trainer.args.update_interval
-        it2 = (it + 2 * ui) // ui * ui
-        dtl, _ = timed_run(trainer, A, B, a.steps, ui, world, start_iter=it2, need_losses=False)
-        extra["images_per_sec_unlogged_iterations"] = round(a.batch_size * world * a.steps / dtl, 2)
-        extra["note_unlogged"] = ("same workload when the iteration's loss values are not read (every iteration that prints "
-                                  "no log line: log_interval 50 in the reference): D-steps skip the two reconstruction "
-                                  "passes that feed only the log; weights identical. NOT the headline value.")
-    del trainer
+    tr.close()
+    del tr, A, B
     torch.cuda.empty_cache()
-    if not a.no_512:
-        tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
-                                use_graph=not a.no_graph, two_streams=not a.single_stream,
-                                async_wgrad=a.async_wgrad and not a.single_stream,
-                              cu_partition=a.cu_partition or None, mfma_turns=a.turns, skew_steps=a.skew)
-        A5, B5 = synthetic_batch(32, 512, 1000 + rank, dev)
-        log("512px models built")
-        dt5, it5 = timed_run(tr512, A5, B5, 6, 6, world)
-        log(f"512px done: {dt5 / 6 * 1e3:.1f} ms/step")
-        if not a.no_roofline:
-            f5, ms5, n5, _ = roofline_pass(tr512, A5, B5, it5)
-            extra["roofline_512px_bs32"] = dict(achieved=round(f5 / ms5 / 1e9, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                                                frac=round(f5 / ms5 / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), launches_per_cycle=n5,
-                                                whole_step_tflops=round(32 * world * 6 / dt5 * 640.8e9 / world / 1e12, 2))
-        if world == 1:
-            del tr512
+
+    # ---- side measurements (1 GPU only) --------------------------------------------------------------------------
+    if world == 1 and not a.no_extra:
+        def side(label, image_size, batch, steps, warmup, **kw):
+            t0 = time.time()
+            t = make_trainer(a, dev, None, image_size, **{k: v for k, v in kw.items() if k in ("mfma_dtype", "graph", "overlap", "comm")})
+            x, y = synthetic_batch(batch, image_size, 1000, dev)
+            r = measure(a, t, x, y, batch, 1, steps, warmup, roofline=kw.get("roofline", False), image_size=image_size)
+            r.pop("_next_iter", None)
+            if "roofline" in r:
+                r["roofline"].pop("by_op", None)
+            r.pop("hbm_bound_families", None)
+            t.close()
+            del t, x, y
             torch.cuda.empty_cache()
-            tr512 = DiscoGANTrainer(default_args(), device=dev, image_size=512, seed=1234, process_group=pg,
-                                    use_graph=not a.no_graph, two_streams=not a.single_stream, mfma_dtype="bf16")
-            dtb5, _ = timed_run(tr512, A5, B5, 6, 6, world)
-            extra["images_per_sec_512px_bs32_bf16_mfma"] = round(32 * world * 6 / dtb5, 2)
-        extra.update(images_per_sec_512px_bs32=round(32 * world * 6 / dt5, 2), ms_per_step_512px_bs32=round(dt5 / 6 * 1e3, 2),
-                     note="BASELINE configs[3]: tops2hanbok image_size=512 batch_size=32 per GPU, fp32, 6 timed steps")
-        del tr512, A5, B5
-        torch.cuda.empty_cache()
+            extra[label] = r
+            log(f"{label}: {r['images_per_sec']:.1f} img/s ({time.time() - t0:.0f} s)")
+
+        other = "bf16" if a.mfma_dtype == "f32" else "f32"
+        side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True)
+        if S == 512:
+            side("64px_bs256_f32", 64, 256, 30, 9, mfma_dtype="f32", roofline=True)
+            side("64px_bs256_bf16_mfma", 64, 256, 30, 9, mfma_dtype="bf16")
+        else:
+            side("512px_bs32_f32", 512, 32, 12, 6, mfma_dtype="f32", roofline=True)
+        # configs[2]'s per-GPU shape in the two data-parallel dispatch modes (world 1, 1-rank RCCL communicator):
+        # hipGraph replay + exchange behind it vs eager dispatch with the exchange overlapped
+        side("64px_bs64_dp_graph_mode", 64, 64, 30, 9, mfma_dtype="f32", graph=True, overlap=False, comm="capi")
+        side("64px_bs64_dp_eager_overlap_mode", 64, 64, 30, 9, mfma_dtype="f32", graph=False, overlap=True, comm="capi")
+        extra["note_dp_modes"] = ("64 px / 64 per GPU (BASELINE configs[2] per-GPU shape) on ONE GPU with a 1-rank RCCL communicator: "
+                                  "the exchange path runs for real, the collectives move nothing. Eager dispatch is host-bound at this "
+                                  "size, so data parallelism below 256 px defaults to graph replay + exchange behind it.")
+        extra["note_side"] = "side measurements, NOT the headline value; bf16 = conv operands on bf16 MFMA, fp32 accumulate/BatchNorm/weights/Adam (configs[4] arithmetic)"
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         torch.set_num_threads(min(16, os.cpu_count() or 1))   # the 1-GPU box's CPU share is 16 cores
         log("cpu baseline (oracle) ...")
-        v, cdt, cn = cpu_baseline(a.image_size, 64)
+        cb = 2 if S == 512 else 64
+        v, cdt, cn = cpu_baseline(S, cb, 20.0 if S == 512 else 10.0)
         cpu = dict(value=round(v, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                   sample=f"oracle/discogan_ref.py, image_size={a.image_size} batch 64 (BASELINE configs[0]), "
-                          f"{cn} iterations (whole D,G,G cycles) after 1 warm-up iteration, {cdt:.1f} s")
+                   sample=f"oracle/discogan_ref.py (CPU restatement pinned to the reference's golden vectors), image_size={S} "
+                          f"batch {cb}" + (" (the same 512 px network and step at a batch the host finishes in seconds; "
+                                           "the reference itself measured 0.23 img/s at batch 32 on 8 cores, BASELINE.md section 3)" if S == 512 else " (BASELINE configs[0])")
+                          + f", {cn} iterations (whole D,G,G cycles) after 1 warm-up iteration, {cdt:.1f} s")
+        if S == 512 and not a.no_extra:
+            v2, cdt2, cn2 = cpu_baseline(64, 64, 10.0)
+            extra["cpu_baseline_64px_bs64"] = dict(value=round(v2, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                                                   sample=f"BASELINE configs[0]: image_size=64 batch 64, {cn2} iterations, {cdt2:.1f} s")
     if rank == 0:
-        line = dict(metric="images/sec per DiscoGAN train step", value=round(value, 2), unit="images/s",
-                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+        line = dict(metric="images/sec per DiscoGAN train step", value=head["images_per_sec"], unit="images/s",
+                    n_gpus=world, steps=a.steps, warmup=head["warmup"], ms_per_step=head["ms_per_step"],
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.mfma_dtype, data="synthetic",
-                    config=dict(workload=f"edges2shoes discogan image_size={a.image_size} batch_size={a.batch_size} per GPU "
-                                         f"(BASELINE configs[1]); D,G,G cycle, fwd+bwd+Adam, dead backward work skipped"
-                                         + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)"),
-                                global_batch=a.batch_size * world, parallelism=f"dp{world}",
-                                hipgraph=used_graph, hip_streams=1 if a.single_stream else 2,
-                                allreduce_overlap=used_overlap),
-                    roofline=roof, cpu_baseline=cpu, extra=extra)
+                    config=dict(workload=WORKLOADS[S].format(b=N) + "; D,G,G cycle, fwd+bwd+Adam, dead backward work skipped"
+                                + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)"),
+                                image_size=S, global_batch=N * world, parallelism=f"dp{world}",
+                                hipgraph=head["hipgraph"], hip_streams=1 if a.single_stream else 2,
+                                allreduce_overlap=head["allreduce_overlap"],
+                                timed_region="starts on a D-step; " + ("whole D,G,G cycles" if a.steps % 3 == 0 else f"{a.steps} steps (not a multiple of the 3-step cycle)")),
+                    roofline=roof, cpu_baseline=cpu, comm=comm, extra=extra)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

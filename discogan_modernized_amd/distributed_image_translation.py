@@ -67,13 +67,18 @@ def main_worker(local_rank, args):
         device = torch.device("cuda", torch.cuda.current_device())
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
                                   process_group=pg, use_graph=not args.no_graph,
-                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"))
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), comm=getattr(args, "comm", "auto"))
         load_checkpoints(args, trainer)
         if args.distributed:
             dist.barrier()
-        it.train(args, trainer=trainer, rank=rank, world_size=world, is_main=(rank == 0), process_group=pg)
-        if args.distributed:
-            dist.barrier()
+        if rank == 0 and trainer.xg is not None:
+            print("data-parallel exchange:", trainer.xg.describe(), flush=True)
+        try:
+            it.train(args, trainer=trainer, rank=rank, world_size=world, is_main=(rank == 0), process_group=pg)
+            if args.distributed:
+                dist.barrier()
+        finally:
+            trainer.close()                       # dg_dp_destroy before the process group goes away
     finally:
         if args.distributed:
             cleanup()

@@ -24,6 +24,19 @@ def _flat_grad_of(param):
     return None
 
 
+# Bucketed gradient exchange (trainer._GradBuckets): FINAL_PASS is True while the trainer issues the forward calls
+# whose backward is the LAST one to touch each parameter of the stepped networks; FINAL_HOOK(param) is called right
+# after that backward has enqueued the kernel that completes the parameter's gradient in the flat buffer.
+FINAL_PASS = False
+FINAL_HOOK = None
+
+
+def _final(ctx_flag, *params):
+    if ctx_flag and FINAL_HOOK is not None:
+        for p in params:
+            FINAL_HOOK(p)
+
+
 # Auxiliary HIP stream for weight-gradient kernels (set by the trainer).  dgrad feeds the next BN-backward
 # on the chain's own stream; wgrad only feeds Adam at the end of the iteration, so it is launched on this
 # stream behind an event and fills the matrix pipes while the chain runs its HBM-bound BN-backward kernels.
@@ -56,6 +69,7 @@ class ConvFn(Function):
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
         ctx.wref = w
+        ctx.final = FINAL_PASS
         if not want_stats:
             return ops.conv_fwd(x, w, stride, pad)
         y, stat = ops.conv_fwd(x, w, stride, pad, want_stats=want_stats)
@@ -75,6 +89,7 @@ class ConvFn(Function):
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
                 _launch_wgrad(lambda: ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True), dy, x)
+                _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(dy, x, stride, pad)
         return dx, dw, None, None, None
@@ -90,6 +105,7 @@ class ConvTransposeFn(Function):
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad)
         ctx.wref = w
+        ctx.final = FINAL_PASS
         hin, win = x.shape[2], x.shape[3]
         hout, wout = (hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4
         ctx.out_hw = (hout, wout)
@@ -113,6 +129,7 @@ class ConvTransposeFn(Function):
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
                 _launch_wgrad(lambda: ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True), dy, x)
+                _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(x, dy, stride, pad)
         return dx, dw, None, None, None
@@ -128,6 +145,7 @@ class ConvC3Fn(Function):
         ctx.save_for_backward(x, w, y)
         ctx.act = (act, slope)
         ctx.wref = w
+        ctx.final = FINAL_PASS
         return y
 
     @staticmethod
@@ -147,6 +165,7 @@ class ConvC3Fn(Function):
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
                 _launch_wgrad(lambda: ops.c3_wgrad(g, x, out=fg, accumulate=True, **fuse), g, x)
+                _final(ctx.final, ctx.wref)
             else:
                 dw = ops.c3_wgrad(g, x, **fuse)
         return dx, dw, None, None
@@ -162,6 +181,7 @@ class ConvTransposeC3Fn(Function):
         ctx.save_for_backward(x, w, out)
         ctx.act = act
         ctx.wref = w
+        ctx.final = FINAL_PASS
         return out
 
     @staticmethod
@@ -174,6 +194,7 @@ class ConvTransposeC3Fn(Function):
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
                 _launch_wgrad(lambda: ops.c3_wgrad(x, g, out=fg, accumulate=True), g, x)
+                _final(ctx.final, ctx.wref)
             else:
                 dw = ops.c3_wgrad(x, g)
         return dx, dw, None
@@ -198,6 +219,7 @@ class BatchNormActFn(Function):
         ctx.save_for_backward(y, saved, gamma, beta)
         ctx.cfg = (act, slope, training)
         ctx.prefs = (gamma, beta)
+        ctx.final = FINAL_PASS
         return z
 
     @staticmethod
@@ -210,6 +232,7 @@ class BatchNormActFn(Function):
         fg, fb = _flat_grad_of(ctx.prefs[0]), _flat_grad_of(ctx.prefs[1])
         if need_p and fg is not None and fb is not None:
             dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb))
+            _final(ctx.final, ctx.prefs[0], ctx.prefs[1])
             return (dy,) + (None,) * 11
         dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
@@ -268,6 +291,40 @@ class BCELossFn(Function):
         (pc,) = ctx.saved_tensors
         label, shape = ctx.cfg
         return ops.bce_bwd(pc, label, gout.contiguous()).reshape(shape), None, None
+
+
+class BCETargetLossFn(Function):
+    """nn.BCELoss against a target TENSOR (no gradient w.r.t. the target), image_translation.py:157-166."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        shape = p.shape
+        loss, pc, tc = ops.bce_target_fwd(p.reshape(-1), target.detach().reshape(-1))
+        ctx.save_for_backward(pc, tc)
+        ctx.shape = shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pc, tc = ctx.saved_tensors
+        return ops.bce_target_bwd(pc, tc, gout.contiguous()).reshape(ctx.shape), None
+
+
+class HingeEmbeddingLossFn(Function):
+    """nn.HingeEmbeddingLoss(margin, mean) for targets in {+1, -1} (image_translation.py:141-142,269)."""
+
+    @staticmethod
+    def forward(ctx, x, y, margin):
+        loss, xd, yd = ops.hinge_fwd(x, y.detach(), margin)
+        ctx.save_for_backward(xd, yd)
+        ctx.margin = margin
+        ctx.in_shape = x.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        xd, yd = ctx.saved_tensors
+        return ops.hinge_bwd(xd, yd, ctx.margin, gout.contiguous()), None, None
 
 
 class FeatureMatchFn(Function):

@@ -6,9 +6,17 @@ Same flags and defaults (``--task_name --model_arch --image_size --batch_size --
 names (``gen_A_{iters}.pth`` ... ``*_final.pth``, :420-432).  The training loop dispatches into the
 HIP kernels through ``DiscoGANTrainer``.
 
-Image-file datasets (dataset.py) are outside the hot path: batches come either from ``--data_A/--data_B``
-tensor files (``torch.save``d float tensors [n,3,S,S] in [0,1]) or, by default, from synthetic uniform
-tensors (``--synthetic_size`` images per domain), which is what the benchmark metric is defined on.
+Image-file decoding (dataset.py's PIL/cv2 code) is outside the hot path: batches come from ``--data_A/--data_B``
+tensor files -- ``torch.save``d float tensors [n,3,S,S] in [0,1], or uint8 tensors [n,S,S,3] of decoded image rows,
+which stay uint8 in HBM (1 B/channel over PCIe) and are normalised / re-laid-out per batch on the device
+(dg_u8hwc_to_f32chw = dataset.py:65-66) -- or, by default, from synthetic uniform tensors (``--synthetic_size``
+images per domain), which is what the benchmark metric is defined on.
+
+Batch order.  Single process: A and B are shuffled independently every epoch (shuffle_data, dataset.py:24-35),
+``data_size // batch_size`` batches.  Data parallel: the ``DistributedSampler`` contract of
+distributed_image_translation.py:203-216,451-452 -- ONE permutation per epoch from a seed shared by all ranks
+(``set_epoch``), rank r takes ``perm[r::W]``, A_i is paired with B_i (dataset.py:215-222), the last batch of the
+shard may be short (no drop_last); a final batch of a single sample is skipped (train-mode BatchNorm needs two).
 
     python -m discogan_modernized_amd.image_translation --task_name edges2shoes --image_size 64 --batch_size 256
 """
@@ -62,7 +70,13 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
     p.add_argument("--weight_decay", type=float, default=0.00001)
     p.add_argument("--save_train_state", action="store_true",
                    help="also write train_state_{iters}.pth (weights + Adam moments + iteration) at every model save")
-    p.add_argument("--resume", type=str, default=None, help="train_state_*.pth to continue from (exact resume)")
+    p.add_argument("--resume", type=str, default=None,
+                   help="train_state_*.pth to continue from: weights, BN buffers, Adam moments, iteration and position in the data order")
+    p.add_argument("--skip_log_only_passes", action="store_true",
+                   help="on iterations that print no log line, D-steps skip the two reconstruction passes (they feed only the "
+                        "log). Same weights; the generators' BatchNorm running statistics then differ from the reference's")
+    p.add_argument("--comm", type=str, default="auto", choices=["auto", "capi", "c10d"],
+                   help="data-parallel transport: the library's own RCCL communicator (capi) or torch.distributed (c10d)")
     p.add_argument("--mfma_dtype", type=str, default="f32", choices=["f32", "bf16"],
                    help="bf16: conv operands rounded to bf16 on the matrix cores, fp32 accumulate/BatchNorm/weights/Adam")
     return p
@@ -72,15 +86,29 @@ def parse_args(argv=None):
     return build_parser().parse_args(argv)
 
 
-def load_domains(args, device, rank=0):
+def load_domains(args, device, rank=0, world_size=1):
+    """Both domains resident in HBM.  Synthetic data: per-rank seed in a single process (benchmark semantics), ONE
+    shared dataset under data parallelism (every rank then takes its DistributedSampler shard of it)."""
     if args.data_A and args.data_B:
-        A = torch.load(args.data_A, map_location="cpu").float()
-        B = torch.load(args.data_B, map_location="cpu").float()
+        A = torch.load(args.data_A, map_location="cpu")
+        B = torch.load(args.data_B, map_location="cpu")
+        A = A if A.dtype == torch.uint8 else A.float()
+        B = B if B.dtype == torch.uint8 else B.float()
     else:
-        g = torch.Generator().manual_seed(1000 + rank)
+        g = torch.Generator().manual_seed(1000 + (rank if world_size == 1 else 0))
         A = torch.rand(args.synthetic_size, 3, args.image_size, args.image_size, generator=g)
         B = torch.rand(args.synthetic_size, 3, args.image_size, args.image_size, generator=g)
     return A.to(device), B.to(device)
+
+
+def take_batch(data, idx):
+    """Rows ``idx`` of a resident domain as the float NCHW batch the networks take (image_translation.py:332-333).
+    uint8 [n,S,S,3] sources are normalised and transposed on the device (dataset.py:65-66)."""
+    x = data.index_select(0, idx)
+    if x.dtype == torch.uint8:
+        from . import ops
+        return ops.u8hwc_to_f32chw(x)
+    return x
 
 
 def run_dirs(args, rank_suffix=""):
@@ -92,15 +120,36 @@ def run_dirs(args, rank_suffix=""):
     return Path(args.results_dir) / sub, Path(args.models_dir) / sub
 
 
-def save_models(trainer, model_path, tag, iters=None, with_state=False):
+def save_models(trainer, model_path, tag, next_iter=None, with_state=False, loader=None):
     trainer.finish()                      # join the communication stream before reading parameters
-    if with_state and iters is not None:
-        torch.save(trainer.train_state(iters), model_path / f"train_state_{tag}.pth")
+    if with_state and next_iter is not None:
+        torch.save(trainer.train_state(next_iter, extra=loader), model_path / f"train_state_{tag}.pth")
     names = dict(gen_A=trainer.generator_A, gen_B=trainer.generator_B,
                  dis_A=trainer.discriminator_A, dis_B=trainer.discriminator_B)
     for k, net in names.items():
         sd = {n: (t.detach().contiguous().cpu()) for n, t in net.state_dict().items()}
         torch.save(sd, model_path / f"{k}_{tag}.pth")
+
+
+def epoch_batches(args, epoch, data_size, rank, world_size, gperm, device):
+    """Index tensors (idx_A, idx_B) of every batch of this epoch, in order (see the module docstring)."""
+    bs = args.batch_size
+    if world_size > 1:
+        from .dp import distributed_indices
+        idx = torch.tensor(distributed_indices(data_size, world_size, rank, epoch, seed=0), device=device)
+        out = [(idx[i:i + bs], idx[i:i + bs]) for i in range(0, len(idx), bs)]
+        return [b for b in out if len(b[0]) >= 2]
+    perm_A = torch.randperm(data_size, generator=gperm).to(device)     # shuffle_data, dataset.py:24-35
+    perm_B = torch.randperm(data_size, generator=gperm).to(device)
+    return [(perm_A[i * bs:(i + 1) * bs], perm_B[i * bs:(i + 1) * bs]) for i in range(data_size // bs)]
+
+
+def batches_per_epoch(args, data_size, world_size):
+    if world_size > 1:
+        shard = -(-data_size // world_size)
+        n = -(-shard // args.batch_size)
+        return n - 1 if shard % args.batch_size == 1 else n
+    return data_size // args.batch_size
 
 
 def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=None):
@@ -116,10 +165,12 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
     if trainer is None:
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
                                   process_group=process_group, use_graph=not args.no_graph,
-                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"))
-    data_A, data_B = load_domains(args, device, rank)
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), comm=getattr(args, "comm", "auto"))
+    data_A, data_B = load_domains(args, device, rank, world_size)
     data_size = min(len(data_A), len(data_B))
-    n_batches = data_size // args.batch_size
+    n_batches = batches_per_epoch(args, data_size, world_size)
+    if n_batches < 1:
+        raise ValueError(f"batch_size {args.batch_size} leaves no full batch in {data_size} images on {world_size} rank(s)")
     total_iterations = args.epochs * n_batches
     log_file = result_path / "training_log.txt"
     if is_main:
@@ -127,45 +178,60 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
             f.write(f"Task: {args.task_name}, Model: {args.model_arch}\n")
             f.write(f"Batch size: {args.batch_size}, Learning rate: {args.learning_rate}\n\n")
     iters = 0
+    start_epoch = start_batch = 0
     if getattr(args, "resume", None):
-        iters = trainer.load_train_state(torch.load(args.resume, map_location="cpu"))
+        st = torch.load(args.resume, map_location="cpu")
+        iters = trainer.load_train_state(st)
+        # position in the data order: the state's loader record, else derived from the iteration count
+        pos = st.get("loader") or dict(epoch=iters // n_batches, batch=iters % n_batches)
+        start_epoch, start_batch = int(pos["epoch"]), int(pos["batch"])
+        if start_batch >= n_batches:
+            start_epoch, start_batch = start_epoch + 1, 0
         if is_main:
-            print(f"resumed from {args.resume} at iteration {iters}")
+            print(f"resumed from {args.resume}: next iteration {iters} (epoch {start_epoch}, batch {start_batch})")
     start_iters = iters
     t0 = time.time()
+    lazy = bool(getattr(args, "skip_log_only_passes", False))
     gperm = torch.Generator(device="cpu").manual_seed(args.seed + 17 * rank)
-    for epoch in range(args.epochs):
-        perm_A = torch.randperm(data_size, generator=gperm).to(device)     # shuffle_data, dataset.py:24-35
-        perm_B = torch.randperm(data_size, generator=gperm).to(device)
-        for i in range(n_batches):
-            sl = slice(i * args.batch_size, (i + 1) * args.batch_size)
-            A = data_A.index_select(0, perm_A[sl])
-            B = data_B.index_select(0, perm_B[sl])
-            # loss values are only read on log iterations; elsewhere a D-step may skip its log-only passes
-            out = trainer.train_iteration(A, B, iters, need_losses=(iters % args.log_interval == 0))
-            if is_main and iters % args.log_interval == 0:
+    if world_size == 1:
+        for _ in range(start_epoch):                      # replay the generator to the resumed epoch (2 draws per epoch)
+            torch.randperm(data_size, generator=gperm)
+            torch.randperm(data_size, generator=gperm)
+    done = False
+    for epoch in range(start_epoch, args.epochs):
+        batches = epoch_batches(args, epoch, data_size, rank, world_size, gperm, device)
+        for i in range(start_batch if epoch == start_epoch else 0, len(batches)):
+            A = take_batch(data_A, batches[i][0])
+            B = take_batch(data_B, batches[i][1])
+            logging = iters % args.log_interval == 0
+            out = trainer.train_iteration(A, B, iters, need_losses=logging or not lazy)
+            if is_main and logging:
                 msg = trainer.format_log(iters, total_iterations, out)
                 dt = time.time() - t0
                 print(msg + f"  [{(iters - start_iters + 1) * args.batch_size * world_size / max(dt, 1e-9):.1f} img/s]", flush=True)
                 with open(log_file, "a") as f:
                     f.write(msg + "\n")
             if is_main and iters % args.model_save_interval == 0:
-                save_models(trainer, model_path, str(iters), iters, getattr(args, "save_train_state", False))
+                save_models(trainer, model_path, str(iters), iters + 1, getattr(args, "save_train_state", False),
+                            loader=dict(epoch=epoch, batch=i + 1))
             iters += 1
             if args.max_iters and iters >= args.max_iters:
+                done = True
                 break
-        if args.max_iters and iters >= args.max_iters:
+        if done:
             break
     if is_main:
-        save_models(trainer, model_path, "final", iters, getattr(args, "save_train_state", False))
+        save_models(trainer, model_path, "final", iters, getattr(args, "save_train_state", False),
+                    loader=dict(epoch=iters // n_batches, batch=iters % n_batches))
         print(f"Training completed. Final models saved to {model_path}")
         print(f"Results and logs saved to {result_path}")
+    train.last_paths = (result_path, model_path)
     return trainer
 
 
 def main(argv=None):
     args = parse_args(argv)
-    train(args)
+    return train(args)
 
 
 if __name__ == "__main__":

@@ -21,26 +21,30 @@ class MSELoss(nn.Module):
 
 
 class BCELoss(nn.Module):
-    """nn.BCELoss() (mean reduction, log clamped at -100).  ``target`` is a Python scalar label
-    (1.0 / 0.0) or a tensor filled with one constant (the only use in the reference)."""
+    """nn.BCELoss() (mean reduction, log clamped at -100).  ``target`` is a tensor of the input's size, as in the
+    reference (image_translation.py:157-166), or a Python scalar label (1.0 / 0.0), which skips materialising it."""
 
     def forward(self, input, target):
         if isinstance(target, torch.Tensor):
             label = getattr(target, "_dg_label", None)
             if label is None:
-                raise NotImplementedError(
-                    "BCELoss: pass the label as a Python float (or a tensor made by losses.label_like)")
+                return F.BCETargetLossFn.apply(input, target.to(input.device))
         else:
             label = float(target)
         return F.BCELossFn.apply(input, label)
 
 
 class HingeEmbeddingLoss(nn.Module):
-    """nn.HingeEmbeddingLoss() as the reference uses it: targets are all +1, so it is ``input.mean()``
-    (SURVEY.md Appendix C).  Kept for API parity; get_fm_loss fuses the whole layer term."""
+    """nn.HingeEmbeddingLoss(margin=1.0) (mean reduction), targets in {+1, -1}.  The reference only calls it with
+    all-ones targets (image_translation.py:141-142), where it is ``input.mean()`` (SURVEY.md Appendix C);
+    ``get_fm_loss`` below fuses that whole layer term into one kernel and does not go through this module."""
 
-    def forward(self, input, target=None):
-        raise NotImplementedError("HingeEmbeddingLoss is consumed by get_fm_loss (fused kernel)")
+    def __init__(self, margin: float = 1.0):
+        super().__init__()
+        self.margin = float(margin)
+
+    def forward(self, input, target):
+        return F.HingeEmbeddingLossFn.apply(input, target.to(input.device), self.margin)
 
 
 def label_like(batch_size, value, device):

@@ -141,6 +141,17 @@ def to_nchw_contiguous(x):
     return x.contiguous()
 
 
+def u8hwc_to_f32chw(x_u8, bgr=False):
+    """uint8 [N,H,W,3] (decoded image rows) -> float32 contiguous NCHW [N,3,H,W] = pixel / 255 (dataset.py:65-66)."""
+    if not x_u8.is_cuda or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or x_u8.shape[3] != 3:
+        raise _lib.DiscoganHipError("u8hwc_to_f32chw needs a uint8 HIP tensor of shape [N,H,W,3]")
+    x = x_u8.contiguous()
+    n, h, w, _ = x.shape
+    y = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_u8hwc_to_f32chw(_ptr(x), _ptr(y), n, h, w, int(bool(bgr)), _stream()), "dg_u8hwc_to_f32chw")
+    return y
+
+
 def krsc_param(w_logical):
     """[K,C,4,4] contiguous -> same logical tensor whose memory is [K,4,4,C] (dim 1 innermost)."""
     return w_logical.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
@@ -427,6 +438,37 @@ def bce_bwd(p, label, gout):
     dp = torch.empty_like(p)
     _lib.check(_lib.load().dg_bce_bwd(_ptr(p), p.numel(), float(label), _ptr(gout), _ptr(dp), _stream()), "dg_bce_bwd")
     return dp
+
+
+def bce_target_fwd(p, target, out=None):
+    _check_dev(p, target)
+    p, target = p.contiguous(), target.contiguous()
+    if p.numel() != target.numel():
+        raise ValueError(f"Using a target size ({tuple(target.shape)}) that is different to the input size ({tuple(p.shape)}) is deprecated. Please ensure they have the same size.")
+    loss = out if out is not None else torch.empty((), device=p.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_bce_target_fwd(_ptr(p), _ptr(target), p.numel(), _ptr(loss), _stream()), "dg_bce_target_fwd")
+    return loss, p, target
+
+
+def bce_target_bwd(p, target, gout):
+    dp = torch.empty_like(p)
+    _lib.check(_lib.load().dg_bce_target_bwd(_ptr(p), _ptr(target), p.numel(), _ptr(gout), _ptr(dp), _stream()), "dg_bce_target_bwd")
+    return dp
+
+
+def hinge_fwd(x, y, margin=1.0):
+    _check_dev(x, y)
+    x, y = same_layout_pair(x, y)
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    ws, wsb = _loss_ws(x.device)
+    _lib.check(_lib.load().dg_hinge_fwd(_ptr(x), _ptr(y), x.numel(), float(margin), _ptr(loss), _ptr(ws), wsb, _stream()), "dg_hinge_fwd")
+    return loss, x, y
+
+
+def hinge_bwd(x, y, margin, gout):
+    dx = _dense_like(x)
+    _lib.check(_lib.load().dg_hinge_bwd(_ptr(x), _ptr(y), x.numel(), float(margin), _ptr(gout), _ptr(dx), _stream()), "dg_hinge_bwd")
+    return dx
 
 
 def fm_fwd(real, fake, out=None):

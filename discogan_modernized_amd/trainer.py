@@ -9,16 +9,19 @@ Differences that do not change any result:
   * dead backward work is skipped: in a D-step the generators run without an autograd graph and the
     fakes are detached; in a G-step the discriminator parameters are frozen, so no D weight-grads
     and no backward through the real passes.  The reference computes those and discards them.
-  * data parallelism averages ONLY the stepped side's flat gradient buffer (one RCCL all-reduce),
-    never broadcasts BatchNorm buffers (the reference's per-forward broadcast is what makes its DDP
-    backward raise), and keeps BN / feature-matching statistics rank-local like DDP does.
+  * data parallelism averages ONLY the stepped side's flat gradient buffer (RCCL all-reduce: one message, or one
+    per gradient bucket when the exchange is overlapped with the backward pass), never broadcasts BatchNorm
+    buffers (the reference's per-forward broadcast is what makes its DDP backward raise), and keeps BN /
+    feature-matching statistics rank-local like DDP does.
   * steady-state iterations replay a captured hipGraph (zero_grad + forward + backward) instead of
     re-dispatching ~600 kernels from Python.
   * the A-side chain (G_A, D_A) and the B-side chain (G_B, D_B) run on two HIP streams and are issued layer by
     layer in lock step (``forward_steps`` generators); every loss term lands in one device vector and the
     curriculum mix / its gradient seeds are one kernel each.
-  * ``need_losses=False`` (iterations whose loss values nobody reads): a D-step skips the two reconstruction
-    passes, which feed only the log line there.
+  * ``need_losses=False`` (opt-in, ``--skip_log_only_passes``): a D-step skips the two reconstruction passes,
+    which feed only the log line there.  Weights and optimiser state are unaffected, but the generators' BatchNorm
+    running statistics then see one forward per D-step instead of two, so saved ``gen_*.pth`` buffers (used by
+    eval-mode inference) differ from the reference's; the default keeps the reference's full work.
 """
 from __future__ import annotations
 
@@ -50,7 +53,8 @@ def default_args(**over):
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
-                 cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32"):
+                 cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
+                 bucket_mb=128.0):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -59,6 +63,15 @@ class DiscoGANTrainer:
         self.image_size = image_size
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # exchange transport (dp.ExchangeGroup): "capi" = the library's own RCCL communicator (collectives on the
+        # caller's stream), "c10d" = torch.distributed, "auto" = capi under backend nccl.  comm="capi" may be forced at
+        # world size 1 (tests: the whole exchange path runs against a 1-rank RCCL communicator).
+        self.xg = None
+        if self.world_size > 1 or comm == "capi":
+            self.xg = dp.ExchangeGroup(process_group, transport=comm, device=torch.device(device))
+        self.time_comm = False                            # bench: HIP events around every exchange
+        self.comm_events = {"D": [], "G": []}
+        self.comm_steps = {"D": 0, "G": 0}
         self.use_graph = use_graph
         self.skip_dead_work = skip_dead_work
         if seed is not None:
@@ -113,13 +126,22 @@ class DiscoGANTrainer:
         # discriminator passes wait on the event.  (A G-step's update is needed by the very next kernel,
         # so it stays on the main stream.)  Needs mid-iteration waits -> eager dispatch, which keeps up
         # with the GPU (measured 14.8 ms vs 15.0 ms under graph replay at 64 px / batch 256).
+        # Measured on one MI355X at 64 px / 64 per GPU (BASELINE configs[2]'s per-GPU shape): eager dispatch is
+        # host-bound there (8.77 ms/step vs 4.86 under hipGraph replay), so the default for small images keeps the
+        # captured graph and runs exchange + Adam behind it; from 256 px the kernels are long enough for eager
+        # dispatch and the overlapped exchange is the default.
         if overlap_comm is None:
-            overlap_comm = self.world_size > 1
+            overlap_comm = self.world_size > 1 and image_size >= 256
         self.overlap_comm = bool(overlap_comm) and skip_dead_work
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap_comm else None
         self._ev_dis_ready = None
         if self.overlap_comm:
             self.use_graph = False
+        # G-step exchange overlap: the generators' flat gradient buffer is cut into buckets of whole layers; a
+        # bucket is all-reduced (and its Adam slice applied) on the communication stream as soon as the LAST backward
+        # pass through its layers has been issued (functional.FINAL_HOOK), while the rest of the backward runs.
+        self._buckets = _GradBuckets(self, bucket_mb) if self.overlap_comm else None
+        self._eager_until = self.args.update_interval      # first cycle runs eagerly (warm-up)
 
     def _masked_streams(self, mode):
         import ctypes
@@ -220,9 +242,14 @@ class DiscoGANTrainer:
                         rb = e.value
             return ra, rb
 
-        # stage 1: the two first-stage translations are independent
-        with gen_ctx():
-            BA, AB = pair(self.generator_A.forward_steps(B), self.generator_B.forward_steps(A))
+        # stage 1: the two first-stage translations are independent.  Their backward passes are the LAST ones to
+        # touch each generator's parameters (autograd replays in reverse), which the bucketed exchange keys on.
+        F_.FINAL_PASS = True
+        try:
+            with gen_ctx():
+                BA, AB = pair(self.generator_A.forward_steps(B), self.generator_B.forward_steps(A))
+        finally:
+            F_.FINAL_PASS = False
         if self.two_streams:
             AB.record_stream(side)
             BA.record_stream(main)
@@ -323,6 +350,9 @@ class DiscoGANTrainer:
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
             if self.mfma_dtype == "bf16":
                 _l.set_option("bf16", 0)          # the library default stays fp32 for everyone else
+        if self.skip_dead_work and not dstep:
+            for p in self.optim_dis.params:               # a G-step froze the D parameters: give them back
+                p.requires_grad_(True)
         if self.async_wgrad:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:
@@ -331,16 +361,21 @@ class DiscoGANTrainer:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         return out
 
-    def _graph_key(self, iters, need_losses=True):
-        return ("D" if self.is_dis_step(iters) else "G", self.rate(iters), bool(need_losses) or not self.is_dis_step(iters))
+    def _graph_key(self, A, B, iters, need_losses=True):
+        return ("D" if self.is_dis_step(iters) else "G", self.rate(iters), bool(need_losses) or not self.is_dis_step(iters),
+                tuple(A.shape), tuple(B.shape))
 
     def _fwd_bwd_graphed(self, A, B, iters, need_losses=True):
+        # static input buffers and captured graphs are per batch shape (a short last batch of an epoch gets its own)
+        shp = (tuple(A.shape), tuple(B.shape))
         if self._static is None:
-            self._static = (torch.empty_like(A), torch.empty_like(B))
-        sA, sB = self._static
+            self._static = {}
+        if shp not in self._static:
+            self._static[shp] = (torch.empty_like(A), torch.empty_like(B))
+        sA, sB = self._static[shp]
         sA.copy_(A)
         sB.copy_(B)
-        key = self._graph_key(iters, need_losses)
+        key = self._graph_key(A, B, iters, need_losses)
         ent = self._graphs.get(key)
         if ent is None:
             g = torch.cuda.CUDAGraph()
@@ -351,6 +386,19 @@ class DiscoGANTrainer:
             self._graphs[key] = ent
         ent[0].replay()
         return ent[1]
+
+    def _exchange(self, opt, kind):
+        """All-reduce (sum) of the stepped side's flat gradient buffer on the current stream; returns the 1/W scale."""
+        if self.xg is None:
+            return 1.0
+        if self.time_comm:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scale = self.xg.all_reduce_sum_(opt.flat_g)
+            e1.record()
+            self.comm_events[kind].append((e0, e1))
+            return scale
+        return self.xg.all_reduce_sum_(opt.flat_g)
 
     def train_iteration(self, A, B, iters, do_step=True, need_losses=True):
         """One full iteration; returns the namespace of (device) loss scalars.  need_losses=False tells the
@@ -365,10 +413,22 @@ class DiscoGANTrainer:
             return out
         dstep = self.is_dis_step(iters)
         opt = self.optim_dis if dstep else self.optim_gen
-        if self.use_graph and iters >= self.args.update_interval:   # first cycle runs eagerly (warm-up)
-            out = self._fwd_bwd_graphed(A, B, iters, need_losses)
-        else:
-            out = self._fwd_bwd(A, B, iters, need_losses)
+        bucketed = self._buckets is not None and not dstep and do_step and self.xg is not None and not self.async_wgrad
+        if self.time_comm:
+            self.comm_steps["D" if dstep else "G"] += 1
+        if bucketed:
+            self._buckets.begin(opt)
+        try:
+            if self.use_graph and iters >= self._eager_until:       # first cycle (and the first after a resume) runs eagerly
+                out = self._fwd_bwd_graphed(A, B, iters, need_losses)
+            else:
+                out = self._fwd_bwd(A, B, iters, need_losses)
+        finally:
+            if bucketed:
+                F_.FINAL_HOOK = None
+        if bucketed:
+            self._buckets.finish(self.active_ranges(dstep))
+            return out
         # gradients of the stepped side only: one flat message, summed; the /W rides in the Adam kernel
         if self.overlap_comm and dstep and do_step:
             main = torch.cuda.current_stream(self.device)
@@ -376,14 +436,24 @@ class DiscoGANTrainer:
             ev.record(main)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                scale, _ = dp.all_reduce_flat(opt.flat_g, self.pg) if self.world_size > 1 else (1.0, None)
+                scale = self._exchange(opt, "D")
                 opt.step(grad_scale=scale, active=self.active_ranges(dstep))
                 self._ev_dis_ready = torch.cuda.Event()
                 self._ev_dis_ready.record(self.comm_stream)
             return out
-        scale, _ = dp.all_reduce_flat(opt.flat_g, self.pg) if self.world_size > 1 else (1.0, None)
+        scale = self._exchange(opt, "D" if dstep else "G")
         if do_step:
             opt.step(grad_scale=scale, active=self.active_ranges(dstep))
+        return out
+
+    def comm_ms(self):
+        """All-reduce time per D-step / per G-step (ms; a G-step's buckets are summed) from the recorded HIP events
+        (time_comm=True)."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for k, evs in self.comm_events.items():
+            if evs and self.comm_steps[k]:
+                out[k] = sum(a.elapsed_time(b) for a, b in evs) / self.comm_steps[k]
         return out
 
     def finish(self):
@@ -407,14 +477,18 @@ class DiscoGANTrainer:
     def state_dicts(self):
         return {k: v.state_dict() for k, v in self.nets.items()}
 
-    def train_state(self, iters):
-        """Everything needed to resume exactly: weights + BN buffers, both Adam states, the iteration count
-        (the reference resumes weights only and restarts Adam and the GAN curriculum)."""
+    def train_state(self, next_iter, extra=None):
+        """Everything needed to resume exactly: weights + BN buffers, both Adam states and ``next_iter`` = the index
+        of the NEXT iteration to run (the reference resumes weights only and restarts Adam and the GAN curriculum,
+        SURVEY.md section 5).  ``extra`` carries the caller's data-loader position (CLI: epoch, batch, RNG state)."""
         self.finish()
         torch.cuda.synchronize(self.device)
-        return dict(iters=int(iters), nets={k: {n: t.detach().contiguous().cpu() for n, t in v.state_dict().items()}
-                                            for k, v in self.nets.items()},
-                    optim_gen=self.optim_gen.state_dict(), optim_dis=self.optim_dis.state_dict())
+        st = dict(iters=int(next_iter), nets={k: {n: t.detach().contiguous().cpu() for n, t in v.state_dict().items()}
+                                              for k, v in self.nets.items()},
+                  optim_gen=self.optim_gen.state_dict(), optim_dis=self.optim_dis.state_dict())
+        if extra:
+            st["loader"] = dict(extra)
+        return st
 
     def load_train_state(self, st):
         for k, v in self.nets.items():
@@ -422,7 +496,113 @@ class DiscoGANTrainer:
         self.optim_gen.load_state_dict(st["optim_gen"])
         self.optim_dis.load_state_dict(st["optim_dis"])
         self._graphs = {}
-        return int(st["iters"])
+        start = int(st["iters"])
+        # like a fresh run, the first D,G,G cycle after a resume is dispatched eagerly before anything is captured
+        self._eager_until = start + self.args.update_interval
+        return start
+
+    def close(self):
+        if self.xg is not None:
+            self.finish()
+            torch.cuda.synchronize(self.device)
+            self.xg.close()
+            self.xg = None
+
+
+class _GradBuckets:
+    """Overlap of the G-step gradient exchange with the backward pass (reference: DDP's bucketed reducer hooks,
+    distributed_image_translation.py:401-404,513-518).
+
+    The generators' flat gradient range is cut into buckets of whole layers (>= ``bucket_mb`` each, never across
+    the two networks).  A parameter's gradient is final once the backward of its network's FIRST forward call of the
+    iteration (issued last by autograd) has written it; functional.py reports that through FINAL_HOOK right after
+    enqueueing the kernel.  When every parameter of a bucket has reported, an event is recorded on the producing
+    stream and the communication stream runs all-reduce(bucket) + Adam(bucket slice) behind it, concurrently with
+    the rest of the backward.  Buckets that never report (networks outside the loss in recongan / gan, or the
+    last-to-finish ones) are flushed after the backward.  Results are bitwise those of the one-message path: the
+    all-reduce is elementwise and the Adam kernel is elementwise with one shared step state."""
+
+    def __init__(self, trainer, bucket_mb):
+        self.tr = trainer
+        opt = trainer.optim_gen
+        target = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []
+        self.of_param = {}
+        for net in (trainer.generator_A, trainer.generator_B):
+            ids = {id(p) for p in net.parameters()}
+            cur = None
+            for p, off in zip(opt.params, opt.offsets):
+                if id(p) not in ids:
+                    continue
+                end = off + (p.numel() + optim._ALIGN - 1) // optim._ALIGN * optim._ALIGN
+                if cur is None or cur["end"] - cur["begin"] >= target:
+                    cur = dict(begin=off, end=end, nparams=0, pending=0, done=False)
+                    self.buckets.append(cur)
+                cur["end"] = end
+                cur["nparams"] += 1
+                self.of_param[id(p)] = cur
+        self.opt = opt
+        self.launched = 0
+
+    def begin(self, opt):
+        assert opt is self.opt
+        tr = self.tr
+        main = torch.cuda.current_stream(tr.device)
+        for b in self.buckets:
+            b["pending"], b["done"] = b["nparams"], False
+        self.launched = 0
+        # the step counter / bias corrections advance once, on the communication stream, behind everything queued
+        tr.comm_stream.wait_stream(main)
+        with torch.cuda.stream(tr.comm_stream):
+            g = opt.param_groups[0]
+            opt._sync_foreign_grads()
+            from . import ops
+            ops.adam_advance(opt.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+        F_.FINAL_HOOK = self.notify
+
+    def notify(self, param):
+        b = self.of_param.get(id(param))
+        if b is None or b["done"]:
+            return
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b, torch.cuda.current_stream(self.tr.device), early=True)
+
+    def _launch(self, b, producer_stream, early, active=None):
+        tr, opt = self.tr, self.opt
+        b["done"] = True
+        ev = torch.cuda.Event()
+        ev.record(producer_stream)
+        tr.comm_stream.wait_event(ev)
+        with torch.cuda.stream(tr.comm_stream):
+            sl = slice(b["begin"], b["end"])
+            scale = 1.0
+            if tr.xg is not None:
+                if tr.time_comm:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    scale = tr.xg.all_reduce_sum_(opt.flat_g[sl])
+                    e1.record()
+                    tr.comm_events["G"].append((e0, e1))
+                else:
+                    scale = tr.xg.all_reduce_sum_(opt.flat_g[sl])
+            if active is None or any(lo <= b["begin"] and b["end"] <= hi for lo, hi in active):
+                g = opt.param_groups[0]
+                from . import ops
+                ops.adam_step_flat(opt.flat_p[sl], opt.flat_g[sl], opt.exp_avg[sl], opt.exp_avg_sq[sl], opt.state,
+                                   float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                   float(scale))
+        if early:
+            self.launched += 1
+
+    def finish(self, active):
+        """After the backward: flush the buckets that did not report, then make the main stream wait for the updates."""
+        tr = self.tr
+        main = torch.cuda.current_stream(tr.device)
+        for b in self.buckets:
+            if not b["done"]:
+                self._launch(b, main, early=False, active=active)
+        main.wait_stream(tr.comm_stream)
 
 
 def synthetic_batch(n, image_size, seed, device):

@@ -92,6 +92,81 @@ def test_two_rank_gloo_equals_sequential_emulation():
     assert diff
 
 
+def _xg_worker(rank, world, initfile, outdir):
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        xg = dp.ExchangeGroup(dist.group.WORLD)                      # gloo -> the c10d transport
+        assert xg.transport == "c10d" and xg.world == world and "gloo" in xg.describe()
+        flat = torch.arange(10.0) * (rank + 1)
+        scale = xg.all_reduce_sum_(flat[2:8])                         # a bucket = a slice of the flat buffer
+        b = torch.full((4,), float(rank))
+        xg.broadcast_(b, 0)
+        xg.barrier()
+        torch.save(dict(flat=flat, scale=scale, b=b), os.path.join(outdir, f"xg{rank}.pt"))
+        xg.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_group_c10d_two_ranks():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_xg_worker, args=(W, os.path.join(d, "init"), d), nprocs=W, join=True)
+        r = [torch.load(os.path.join(d, f"xg{k}.pt")) for k in range(W)]
+    for k in range(W):
+        want = torch.arange(10.0) * (k + 1)
+        want[2:8] = torch.arange(10.0)[2:8] * 3                      # (1 + 2) x, only inside the bucket
+        assert torch.equal(r[k]["flat"], want) and r[k]["scale"] == 0.5
+        assert torch.equal(r[k]["b"], torch.zeros(4))
+
+
+def test_distributed_indices_equal_torch_distributed_sampler():
+    """dp.distributed_indices is DistributedSampler(shuffle=True) + set_epoch, bit for bit
+    (distributed_image_translation.py:203-208,451-452): disjoint 1/W shards from ONE permutation per epoch."""
+    from torch.utils.data import DistributedSampler
+    for n, w in [(10, 4), (1000, 8), (7, 3), (3, 8), (64, 2)]:
+        for epoch in (0, 1, 5):
+            shards = []
+            for r in range(w):
+                ds = DistributedSampler(range(n), num_replicas=w, rank=r, shuffle=True)
+                ds.set_epoch(epoch)
+                got = dp.distributed_indices(n, w, r, epoch)
+                assert got == list(ds), (n, w, epoch, r)
+                shards.append(got)
+            assert len({len(s) for s in shards}) == 1
+            if n % w == 0:
+                assert sorted(sum(shards, [])) == list(range(n))       # a partition of the dataset
+
+
+def test_cli_epoch_batches_shard_the_dataset():
+    from types import SimpleNamespace
+    from discogan_modernized_amd import image_translation as it
+    args = SimpleNamespace(batch_size=4)
+    seen = []
+    for r in range(2):
+        bs = it.epoch_batches(args, 3, 22, r, 2, None, "cpu")
+        assert len(bs) == it.batches_per_epoch(args, 22, 2) == 3 and [len(a) for a, _ in bs] == [4, 4, 3]
+        assert all(torch.equal(a, b) for a, b in bs)                  # A_i paired with B_i (dataset.py:215-222)
+        seen += [int(i) for a, _ in bs for i in a]
+    assert sorted(seen) == list(range(22))
+    # a trailing batch of ONE sample is skipped (train-mode BatchNorm needs two); single process: independent shuffles
+    assert it.batches_per_epoch(args, 18, 2) == 2 and len(it.epoch_batches(args, 0, 18, 0, 2, None, "cpu")) == 2
+    g = torch.Generator().manual_seed(0)
+    one = it.epoch_batches(args, 0, 22, 0, 1, g, "cpu")
+    assert len(one) == 5 and not all(torch.equal(a, b) for a, b in one)
+
+
+def test_launcher_command_line():
+    """launch.py mirrors distributed_training.sh's flags; world size = length of the --gpus list."""
+    from discogan_modernized_amd import launch
+    cmd, env, log = launch.build_command(["--gpus=0,1,4,5", "--task_name=celebA", "--style_A=Male", "--style_B=Smiling",
+                                          "--batch_size=64", "--max_iters", "7", "--log_dir=/tmp/x"], {})
+    assert "--nproc-per-node=4" in cmd and "--world_size=4" in cmd and env["HIP_VISIBLE_DEVICES"] == "0,1,4,5"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and "discogan_modernized_amd.distributed_image_translation" in cmd
+    for f in ("--task_name=celebA", "--style_A=Male", "--style_B=Smiling", "--batch_size=64", "--epochs=50", "--image_size=64", "--distributed"):
+        assert f in cmd, f
+    assert cmd[-2:] == ["--max_iters", "7"] and log == "/tmp/x/train.log"
+
+
 def test_single_process_is_identity():
     flat = torch.arange(8.0)
     scale, work = dp.all_reduce_flat(flat.clone(), None)
