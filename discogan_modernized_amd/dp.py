@@ -63,8 +63,8 @@ class ExchangeGroup:
             _lib.check(L.dg_dp_get_unique_id(buf, nbytes), "dg_dp_get_unique_id")
             raw = bytes(buf.raw)
         idbuf = ctypes.create_string_buffer(raw, nbytes)
-        if self.device is not None:
-            torch.cuda.set_device(self.device)
+        if self.device is not None and torch.device(self.device).index is not None:
+            torch.cuda.set_device(self.device)                    # ncclCommInitRank binds the CURRENT HIP device
         _lib.check(L.dg_dp_init(self.rank, self.world, idbuf, nbytes), "dg_dp_init")
         if L.dg_dp_world_size() != self.world:
             raise _lib.DiscoganHipError(f"RCCL communicator has {L.dg_dp_world_size()} ranks, expected {self.world}")

