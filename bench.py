@@ -280,6 +280,12 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, argv))
 
+    # stdout carries exactly ONE line (the JSON): everything else that lands on fd 1 meanwhile -- RCCL prints a version
+    # banner there when a communicator is created -- is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,7 +400,8 @@ def main():
                                 allreduce_overlap=head["allreduce_overlap"],
                                 timed_region="starts on a D-step; " + ("whole D,G,G cycles" if a.steps % 3 == 0 else f"{a.steps} steps (not a multiple of the 3-step cycle)")),
                     roofline=roof, cpu_baseline=cpu, comm=comm, extra=extra)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,7 +16,11 @@ from discogan_modernized_amd import _lib, ops  # noqa: E402
 from discogan_modernized_amd.model import stage_channels  # noqa: E402
 
 
-def timeit(fn, iters=10, warm=3):
+ITERS = 10
+
+
+def timeit(fn, iters=None, warm=3):
+    iters = iters or ITERS
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -36,7 +40,12 @@ def main():
     ap.add_argument("--kt", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--target_wgs", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--bf16", type=int, default=0)
     a = ap.parse_args()
+    global ITERS
+    ITERS = a.iters
+    _lib.set_option("bf16", a.bf16)
     _lib.set_option("kt", a.kt)
     _lib.set_option("splitk", a.splitk)
     _lib.set_option("target_wgs", a.target_wgs)
@@ -57,7 +66,8 @@ def main():
         t1 = timeit(lambda: ops.conv_fwd(x, w, 2, 1))
         t2 = timeit(lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1))
         t3 = timeit(lambda: ops.conv_wgrad(dy, x, 2, 1))
-        print(f"conv s2 {C:4d}->{K:4d} @{H:3d}       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
+        amb = (x.numel() + w.numel() + dy.numel()) * 4 / 1e6
+        print(f"conv s2 {C:4d}->{K:4d} @{H:3d} [{amb:7.1f} MB] {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
         tot["fwd"] += t1; tot["dgrad"] += t2; tot["wgrad"] += t3; totf += gf
         h //= 2
     # heads

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Merge two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) into the per-kernel
-traffic JSON under profiles/.  usage: pmc_traffic.py fetch.csv write.csv out.json
+traffic JSON under profiles/.  usage: pmc_traffic.py fetch.csv write.csv out.json [size batch]
 hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1024: on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane reads
 (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted, so this is traffic beyond the per-XCD L2,
 an upper bound on HBM bytes."""
@@ -16,11 +16,12 @@ def means(path, counter):
 
 
 fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
+size, batch = (sys.argv[4], sys.argv[5]) if len(sys.argv) > 5 else ("64", "256")
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/pmc_round.sh) over "
-               "tools/bench_ops.py --size 64 --batch 256; mean per launch. hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1024 "
+               f"tools/bench_ops.py --size {size} --batch {batch}; mean per launch. hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1024 "
                "(gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md); Infinity-Cache hits are counted: traffic beyond "
-               "the per-XCD L2, an upper bound on HBM bytes. igemm_kernel<0,2,2,32,true,0> averages the three 17.18-GFLOP "
-               "stride-2 forward layers and the 100-channel head (algorithmic mean 49.8 MB/launch).",
+               "the per-XCD L2, an upper bound on HBM bytes. An igemm_kernel<0,...> entry averages the stride-2 forward "
+               "layers and the 100-channel head bench_ops.py runs (their algorithmic MB are printed by bench_ops.py).",
        "kernels": {}}
 for k in sorted(set(fetch) & set(write)):
     f, n = fetch[k]
