@@ -21,7 +21,8 @@
 // flight from HBM/L2 while tile t+1 waits in registers and tile t is multiplied out of LDS.
 // Addressing (BUF): buffer descriptors + 32-bit offsets, masked vectors read out of range (zeros); the 64-bit
 // pointer form (!BUF, masked vectors read a zero block) remains for tensors >= 2 GiB.
-// PREC 1: operands rounded to bf16 between LDS and the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+// PREC 1: operands rounded to bf16 when they are STAGED into LDS (bf16 tiles, K-tile 64), v_mfma_f32_32x32x16_bf16,
+// fp32 accumulate; k-major operand images are read with the hardware transpose ds_read_b64_tr_b16.
 // Epilogue: accumulators transposed through LDS, float4 stores (16 lanes per 256-B row segment).
 // LDS operand images:
 //   "k-contiguous" [row][KT+4]  : lane reads one b128 = its A/B values for FOUR consecutive MFMAs
@@ -100,7 +101,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     static_assert(256 % A_CQ == 0 && 256 % B_CQ == 0, "row mapping");
 
     constexpr int EPI_FLOATS = 4 * 32 * 68;          // epilogue transpose regions, one [32][68] per wave
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE > EPI_FLOATS ? 2 * STAGE : EPI_FLOATS];
+    // PREC 1 (bf16 LDS images, element = 2 bytes): k-contiguous [row][KT+8] (row stride 144 / 80 B: the 16 lanes of a
+    // ds_read_b128 group land on 16 different 16-B slots), k-major [kk][cols+32] (row stride = 64 mod 256 B: the four
+    // rows of a ds_read_b64_tr_b16 block land on four different 64-B bank segments) -- both conflict-free.
+    constexpr int LDAH = A_KM ? (BM + 32) : (KT + 8);
+    constexpr int LDBH = B_KM ? (BN + 32) : (KT + 8);
+    constexpr int AH_BYTES = A_ROWS * LDAH * 2, BH_BYTES = B_ROWS * LDBH * 2;
+    constexpr int STAGEH_FLOATS = (AH_BYTES + BH_BYTES) / 4;
+    constexpr int MAIN_FLOATS = PREC == 1 ? 2 * STAGEH_FLOATS : 2 * STAGE;
+    __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // Tiles past the end are re-loaded from the last position and never used (no branches in the body).
     const int it_last = it_end - 1;
     float fa[2][2][4], fb[2][2][4];   // double-buffered LDS fragments; set 0 is carried across tiles
+    if constexpr (PREC == 0) {
     if (it_begin < it_end) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) load_A(0, i, it_begin);
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     __syncthreads();
     if (stp) stp[2] = clock64();
     fetch(smem, smem + A_FLOATS, 0, fa[0], fb[0]);
+    }
 
     // one K-tile; P = parity of (it - it_begin) = LDS buffer of the current tile = register set to refill
     auto body = [&](auto P, int it) {
@@ -509,63 +520,89 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         advance(it + 3 < it_end ? 1 : 0);
     };
-    // bf16 operand path: 8 MFMAs of 32 cycles per K-tile instead of 64 of 64 cycles, so the loop is bound by
-    // operand movement, not by the matrix pipe; no hand interleave, the compiler schedules it
-    auto fetch_bf = [&](const float* As, const float* Bs, int g, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wm * 64 + i * 32 + l31, col = wn * 64 + i * 32 + l31;
-            float ta[8], tb[8];
-            if (!A_KM) {
-                const f32x4 v0 = *(const f32x4*)(As + row * LDA + g * 16 + 8 * lh), v1 = *(const f32x4*)(As + row * LDA + g * 16 + 8 * lh + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { ta[j] = v0[j]; ta[4 + j] = v1[j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ta[j] = As[(g * 16 + 8 * lh + j) * LDA + row];
-            }
-            if (!B_KM) {
-                const f32x4 v0 = *(const f32x4*)(Bs + col * LDB + g * 16 + 8 * lh), v1 = *(const f32x4*)(Bs + col * LDB + g * 16 + 8 * lh + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { tb[j] = v0[j]; tb[4 + j] = v1[j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tb[j] = Bs[(g * 16 + 8 * lh + j) * LDB + col];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { a[i][j] = (__bf16)ta[j]; b[i][j] = (__bf16)tb[j]; }
-        }
+    // ---- PREC 1: bf16 LDS tiles.  The fp32 operand vectors are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) when they
+    // are staged into LDS -- once per element instead of once per use -- so LDS carries half the bytes, the K-tile is
+    // 64 and a fragment (8 k values of one row) is ONE ds_read_b128 (k-contiguous images) or two ds_read_b64_tr_b16
+    // (k-major images [kk][cols]: the hardware transposes a 4 x 16 block per 16 lanes, so the NHWC / KRSC operands that
+    // arrive reduction-major need no transposing stores).  Pipeline: ONE register set; iteration t writes tile t+1
+    // (loaded during iteration t-1) into the other LDS buffer, re-issues the loads of tile t+2, multiplies tile t,
+    // barrier.  Two workgroups share a CU, so one's conversions / LDS writes run under the other's MFMAs.
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
+    char* const smb = (char*)smem;
+    auto sth_A = [&](char* stage, int i) {
+        *(bf16x4*)(stage + ((arow0 + i * A_RSTEP) * LDAH + acq * 4) * 2) = __builtin_convertvector(ra[0][i], bf16x4);
     };
-    auto body_bf = [&](auto P, int it) {
+    auto sth_B = [&](char* stage, int i) {
+        *(bf16x4*)(stage + AH_BYTES + ((brow0 + i * B_RSTEP) * LDBH + bcq * 4) * 2) = __builtin_convertvector(rb[0][i], bf16x4);
+    };
+    // transposed fragment read: lane l = 16g + 4q + p supplies row (k0 + q), columns c0 + 16*(g&1) + 4p .. +3 and
+    // receives column c0 + (l & 31), rows k0 .. k0+3 (k0 already includes the lane half's 8*(l>>5))
+    const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    auto frag_km = [&](const char* img, int ld, int k0, int c0) -> bf16x8 {
+        const char* p0 = img + ((k0 + tr_q) * ld + c0 + tr_c) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * ld * 2));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto body_h = [&](auto P, int it) {
         constexpr int p_ = decltype(P)::value;
-        const float* As = smem + p_ * STAGE;
-        const float* Bs = As + A_FLOATS;
-        float* nxt = smem + (p_ ^ 1) * STAGE;
-        const int itn = min(it + 2, it_last);
+        const char* As = smb + p_ * (AH_BYTES + BH_BYTES);
+        const char* Bs = As + AH_BYTES;
+        char* nxt = smb + (p_ ^ 1) * (AH_BYTES + BH_BYTES);
+        if (it + 1 < it_end) {                       // tile it+1: registers -> bf16 -> the other LDS buffer
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) load_A(p_, i, itn);
+            for (int i = 0; i < NVA; ++i) sth_A(nxt, i);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) load_B(p_, i, itn);
+            for (int i = 0; i < NVB; ++i) sth_B(nxt, i);
+        }
+        const int itn = min(it + 2, it_last);        // tile it+2 -> registers (re-loads the last tile at the end)
 #pragma unroll
-        for (int g = 0; g < KT / 16; ++g) {
+        for (int i = 0; i < NVA; ++i) load_A(0, i, itn);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_B(0, i, itn);
+        advance(it + 3 < it_end ? 1 : 0);
+#pragma unroll
+        for (int s16 = 0; s16 < KT / 16; ++s16) {
             bf16x8 a[2], b[2];
-            fetch_bf(As, Bs, g, a, b);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
+                if (!A_KM) a[i] = *(const bf16x8*)(As + ((row + l31) * LDAH + s16 * 16 + 8 * lh) * 2);
+                else a[i] = frag_km(As, LDAH, s16 * 16 + 8 * lh, row);
+                if (!B_KM) b[i] = *(const bf16x8*)(Bs + ((col + l31) * LDBH + s16 * 16 + 8 * lh) * 2);
+                else b[i] = frag_km(Bs, LDBH, s16 * 16 + 8 * lh, col);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jn], acc[i][jn], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) store_A(nxt, p_ ^ 1, i);
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) store_B(nxt, p_ ^ 1, i);
-        advance(it + 3 < it_end ? 1 : 0);
         __syncthreads();
     };
     if constexpr (PREC == 1) {
+        static_assert(KT % 16 == 0 && (LDAH * 2) % 16 == 0 && (LDBH * 2) % 16 == 0 && AH_BYTES % 16 == 0, "bf16 LDS image alignment");
+        if (it_begin < it_end) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) load_A(0, i, it_begin);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) load_B(0, i, it_begin);
+            advance(it_begin + 1 < it_end ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) sth_A(smb, i);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) sth_B(smb, i);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) load_A(0, i, min(it_begin + 1, it_last));
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) load_B(0, i, min(it_begin + 1, it_last));
+            advance(it_begin + 2 < it_end ? 1 : 0);
+        }
+        __syncthreads();
+        if (stp) stp[2] = clock64();
         for (int it = it_begin; it < it_end; it += 2) {
-            body_bf(std::integral_constant<int, 0>{}, it);
-            if (it + 1 < it_end) body_bf(std::integral_constant<int, 1>{}, it + 1);
+            body_h(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < it_end) body_h(std::integral_constant<int, 1>{}, it + 1);
         }
     } else {
         for (int it = it_begin; it < it_end; it += 2) {
@@ -908,6 +945,12 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     const int npix = g.N * g.Ho * g.Wo;
     int kt_opt = dg_get_option(DG_OPT_KT);
     pl->wm = 2; pl->wn = 2; pl->kt = (kt_opt == 16) ? 16 : 32;
+    // bf16 MFMA operands (option "bf16"): bf16 LDS tiles, K-tile 64 (32 with the 256x64 tile, whose LDS would
+    // otherwise allow one workgroup per CU only); needs the buffer-descriptor kernels and whole K-tiles per tap
+    bool want_bf16 = dg_get_option(DG_OPT_BF16) == 1;
+    if (want_bf16 && op == 0 && g.C % 64 != 0) want_bf16 = false;
+    if (want_bf16 && op == 1 && g.stride == 2 && g.K % 64 != 0) want_bf16 = false;
+    if (want_bf16) pl->kt = 64;
     int zmul = 1;
     if (op == 0) {
         pl->mode = MODE_FWD;
@@ -920,7 +963,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         zmul = 4;
         // 256x64 tile for <= 64 output columns, KT 16 so that two workgroups fit a CU (KT 32 = 91 KB of LDS, one
         // workgroup per CU, was measured slower: 189 vs 165 us on 128->64 @32x32, nothing hides prologue/epilogue)
-        if (g.C <= 64) { pl->wm = 4; pl->wn = 1; pl->kt = 16; a.nIt = 4 * g.K / 16; }
+        if (g.C <= 64) { pl->wm = 4; pl->wn = 1; pl->kt = want_bf16 ? 32 : 16; a.nIt = 4 * g.K / pl->kt; }
     } else if (op == 1) {
         pl->mode = MODE_DGRAD_PLAIN;
         a.M = g.N; a.Ng = 16 * g.C; a.R = g.K;
@@ -936,7 +979,14 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
-        a.prec = (fits && dg_get_option(DG_OPT_BF16) == 1) ? 1 : 0;
+        a.prec = (fits && want_bf16) ? 1 : 0;
+        if (want_bf16 && !fits) {            // >= 2 GiB operands: fp32 pointer kernels with their own K-tile
+            pl->kt = (pl->mode == MODE_DGRAD_S2 && pl->wm == 4) ? 16 : 32;
+            if (pl->mode == MODE_FWD) a.nIt = 16 * g.C / pl->kt;
+            else if (pl->mode == MODE_DGRAD_S2) a.nIt = 4 * g.K / pl->kt;
+            else if (pl->mode == MODE_DGRAD_PLAIN) a.nIt = (g.K + pl->kt - 1) / pl->kt;
+            else a.nIt = (npix + pl->kt - 1) / pl->kt;
+        }
     }
     const int BM = 64 * pl->wm, BN = 64 * pl->wn;
     a.tilesM = (a.M + BM - 1) / BM;
@@ -958,12 +1008,16 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
 template <int MODE, int WM, int WN, int KT>
 static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0 && a.prec == 1)
-        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, MODE != MODE_FWD_C3 ? 1 : 0>), dim3(grid), dim3(256), 0, st, a);
-    else if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
+    if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
         hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, 0>), dim3(grid), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false, 0>), dim3(grid), dim3(256), 0, st, a);
+}
+// bf16 operand tiles (PREC 1): buffer-descriptor kernels only
+template <int MODE, int WM, int WN, int KT>
+static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
+    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1>), dim3(grid), dim3(256), 0, st, a);
 }
 
 static long long* g_stamp_buf = nullptr;
@@ -987,8 +1041,14 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         a.part = (float*)ws;
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
-    const int key = pl.mode * 100 + pl.wm * 10 + (pl.kt == 32 ? 1 : 0);
+    const int key = a.prec == 1 ? 1000 + pl.mode * 100 + pl.wm * 10 + (pl.kt == 64 ? 1 : 0)
+                                : pl.mode * 100 + pl.wm * 10 + (pl.kt == 32 ? 1 : 0);
     switch (key) {
+        case 1000 + MODE_FWD * 100 + 21: launch_igemm_bf16<MODE_FWD, 2, 2, 64>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_S2 * 100 + 21: launch_igemm_bf16<MODE_DGRAD_S2, 2, 2, 64>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_S2 * 100 + 40: launch_igemm_bf16<MODE_DGRAD_S2, 4, 1, 32>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_PLAIN * 100 + 21: launch_igemm_bf16<MODE_DGRAD_PLAIN, 2, 2, 64>(a, zmul, st); break;
+        case 1000 + MODE_WGRAD * 100 + 21: launch_igemm_bf16<MODE_WGRAD, 2, 2, 64>(a, zmul, st); break;
         case MODE_FWD * 100 + 21: launch_igemm<MODE_FWD, 2, 2, 32>(a, zmul, st); break;
         case MODE_FWD * 100 + 20: launch_igemm<MODE_FWD, 2, 2, 16>(a, zmul, st); break;
         case MODE_DGRAD_S2 * 100 + 21: launch_igemm<MODE_DGRAD_S2, 2, 2, 32>(a, zmul, st); break;

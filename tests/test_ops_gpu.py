@@ -87,7 +87,8 @@ def test_conv_s2_options(kt, splitk):
         _lib.set_option("splitk", 0)
 
 
-@pytest.mark.parametrize("N,C,K,H", [(2, 128, 256, 8), (3, 64, 128, 16), (4, 256, 64, 16), (2, 512, 512, 4)])
+@pytest.mark.parametrize("N,C,K,H", [(2, 128, 256, 8), (3, 64, 128, 16), (4, 256, 64, 16), (2, 512, 512, 4), (5, 64, 128, 64),
+                                     (2, 1024, 2048, 8)])
 def test_conv_bf16_operands(N, C, K, H):
     """Option "bf16": operands rounded to bf16 (RNE), bf16 MFMA, fp32 accumulate.  bf16 x bf16 products are exact in
     fp32, so the result must equal the fp32 op on the ROUNDED operands up to summation order (tolerance as fp32)."""
@@ -105,6 +106,24 @@ def test_conv_bf16_operands(N, C, K, H):
         # and it is NOT the fp32 result (the rounding is really applied)
         yf = TF.conv2d(x, w, stride=2, padding=1)
         assert (ops.conv_fwd(xg, wg, 2, 1).cpu() - yf).abs().max() > 1e-4 * yf.abs().max()
+    finally:
+        _lib.set_option("bf16", 0)
+
+
+@pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100), (3, 128, 100)])
+def test_conv_head_bf16_operands(N, C, K):
+    """The 4x4 heads (plain GEMMs: FWD / DGRAD_PLAIN / WGRAD with ragged K = 100) on the bf16 tile kernels."""
+    r = lambda t_: t_.bfloat16().float()
+    x, w, dy = rnd(N, C, 4, 4, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, 1, 1, seed=3)
+    xr, wr = r(x).double().requires_grad_(True), r(w).double().requires_grad_(True)
+    yr = TF.conv2d(xr, wr)
+    yr.backward(r(dy).double())
+    _lib.set_option("bf16", 1)
+    try:
+        xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+        close(ops.conv_fwd(xg, wg, 1, 0), yr.float(), what="bf16 head fwd")
+        close(ops.conv_dgrad(dyg, wg, (4, 4), 1, 0), xr.grad.float(), rtol=2e-4, what="bf16 head dgrad")
+        close(ops.conv_wgrad(dyg, xg, 1, 0), wr.grad.float(), rtol=2e-4, what="bf16 head wgrad")
     finally:
         _lib.set_option("bf16", 0)
 
