@@ -55,8 +55,9 @@ def parse(argv=None):
     ap.add_argument("--no_extra", action="store_true", help="headline + roofline only")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
-    ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16"],
-                    help="bf16 = BASELINE configs[4] arithmetic for the MAIN run (the JSON then says dtype bf16); default f32")
+    ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16", "f32x3"],
+                    help="arithmetic of the MAIN run (the JSON's dtype follows it). f32: exact fp32 MFMA (default); bf16: BASELINE "
+                         "configs[4] arithmetic; f32x3: fp32-accurate products from three bf16 planes per operand")
     ap.add_argument("--comm", default="auto", choices=["auto", "capi", "c10d"], help="data-parallel transport (dp.ExchangeGroup)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="data-parallel exchange overlapped with compute (eager dispatch) or behind a replayed hipGraph")
@@ -255,11 +256,15 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
     if roofline:
         flops, ms, nlaunch, by, hbm, it = roofline_pass(tr, A, B, it)
         bf = tr.mfma_dtype == "bf16"
-        peak = MFMA_BF16_PEAK_TFLOPS if bf else MFMA_F32_PEAK_TFLOPS
+        x3 = tr.mfma_dtype == "f32x3"
+        # f32x3 issues SIX bf16 MFMAs per algorithmic product block: its ceiling in algorithmic FLOPs is bf16 peak / 6
+        peak = MFMA_BF16_PEAK_TFLOPS if bf else (round(MFMA_BF16_PEAK_TFLOPS / 6, 1) if x3 else MFMA_F32_PEAK_TFLOPS)
         ach = flops / (ms * 1e-3) / 1e12
         res["roofline"] = dict(
             bound="mfma",
             kernel=("igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv family)" if bf else
+                    "igemm_kernel<*,PREC=2> (fp32 operands as three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product block; "
+                    "peak = dense bf16 peak / 6; the exact-fp32 MFMA peak is 157.3)" if x3 else
                     "igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)"),
             achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
             launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
@@ -358,11 +363,13 @@ def main():
             extra[label] = r
             log(f"{label}: {r['images_per_sec']:.1f} img/s ({time.time() - t0:.0f} s)")
 
-        other = "bf16" if a.mfma_dtype == "f32" else "f32"
-        side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True)
+        for other in ("f32", "bf16", "f32x3"):
+            if other != a.mfma_dtype:
+                side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True)
         if S == 512:
             side("64px_bs256_f32", 64, 256, 30, 9, mfma_dtype="f32", roofline=True)
             side("64px_bs256_bf16_mfma", 64, 256, 30, 9, mfma_dtype="bf16")
+            side("64px_bs256_f32x3_mfma", 64, 256, 30, 9, mfma_dtype="f32x3")
         else:
             side("512px_bs32_f32", 512, 32, 12, 6, mfma_dtype="f32", roofline=True)
         # configs[2]'s per-GPU shape in the two data-parallel dispatch modes (world 1, 1-rank RCCL communicator):
@@ -372,7 +379,10 @@ def main():
         extra["note_dp_modes"] = ("64 px / 64 per GPU (BASELINE configs[2] per-GPU shape) on ONE GPU with a 1-rank RCCL communicator: "
                                   "the exchange path runs for real, the collectives move nothing. Eager dispatch is host-bound at this "
                                   "size, so data parallelism below 256 px defaults to graph replay + exchange behind it.")
-        extra["note_side"] = "side measurements, NOT the headline value; bf16 = conv operands on bf16 MFMA, fp32 accumulate/BatchNorm/weights/Adam (configs[4] arithmetic)"
+        extra["note_side"] = ("side measurements, NOT the headline value; bf16 = conv operands rounded to bf16 on the bf16 MFMA path, fp32 "
+                              "accumulate/BatchNorm/weights/Adam (configs[4] arithmetic); f32x3 = fp32-ACCURATE conv products on the bf16 "
+                              "MFMA path: each fp32 operand split into three bf16 planes (24 significand bits), six MFMAs per block, fp32 "
+                              "accumulate -- measured closer to fp64 than the exact-fp32 MFMA chain (tests/test_ops_gpu.py::test_conv_f32x3_is_fp32_accurate)")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

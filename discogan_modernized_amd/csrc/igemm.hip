@@ -104,11 +104,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // PREC 1 (bf16 LDS images, element = 2 bytes): k-contiguous [row][KT+8] (row stride 144 / 80 B: the 16 lanes of a
     // ds_read_b128 group land on 16 different 16-B slots), k-major [kk][cols+32] (row stride = 64 mod 256 B: the four
     // rows of a ds_read_b64_tr_b16 block land on four different 64-B bank segments) -- both conflict-free.
+    // PREC 2 ("f32x3"): every fp32 operand value is split into THREE bf16 planes hi + mid + lo (24 significand bits in
+    // all), K-tile 16, and each 32x32x16 product block is six bf16 MFMAs (see body_h).
+    constexpr int NP = PREC == 2 ? 3 : 1;
     constexpr int LDAH = A_KM ? (BM + 32) : (KT + 8);
     constexpr int LDBH = B_KM ? (BN + 32) : (KT + 8);
-    constexpr int AH_BYTES = A_ROWS * LDAH * 2, BH_BYTES = B_ROWS * LDBH * 2;
+    constexpr int APL_BYTES = A_ROWS * LDAH * 2, BPL_BYTES = B_ROWS * LDBH * 2;     // one plane
+    constexpr int AH_BYTES = NP * APL_BYTES, BH_BYTES = NP * BPL_BYTES;
     constexpr int STAGEH_FLOATS = (AH_BYTES + BH_BYTES) / 4;
-    constexpr int MAIN_FLOATS = PREC == 1 ? 2 * STAGEH_FLOATS : 2 * STAGE;
+    constexpr int MAIN_FLOATS = PREC >= 1 ? 2 * STAGEH_FLOATS : 2 * STAGE;
     __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS];
 
     const int tid = threadIdx.x;
@@ -530,12 +534,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
     char* const smb = (char*)smem;
-    auto sth_A = [&](char* stage, int i) {
-        *(bf16x4*)(stage + ((arow0 + i * A_RSTEP) * LDAH + acq * 4) * 2) = __builtin_convertvector(ra[0][i], bf16x4);
+    // fp32 -> bf16 planes.  PREC 1: one RNE rounding.  PREC 2: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
+    // both subtractions are exact in fp32, so hi + mid + lo carries 24 significand bits of v.
+    auto split_store = [&](char* dst, int plane_bytes, const f32x4& v) {
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        *(bf16x4*)dst = h;
+        if constexpr (PREC == 2) {
+            const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+            const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+            *(bf16x4*)(dst + plane_bytes) = m;
+            const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+            *(bf16x4*)(dst + 2 * plane_bytes) = __builtin_convertvector(r2, bf16x4);
+        }
     };
-    auto sth_B = [&](char* stage, int i) {
-        *(bf16x4*)(stage + AH_BYTES + ((brow0 + i * B_RSTEP) * LDBH + bcq * 4) * 2) = __builtin_convertvector(rb[0][i], bf16x4);
-    };
+    auto sth_A = [&](char* stage, int i) { split_store(stage + ((arow0 + i * A_RSTEP) * LDAH + acq * 4) * 2, APL_BYTES, ra[0][i]); };
+    auto sth_B = [&](char* stage, int i) { split_store(stage + AH_BYTES + ((brow0 + i * B_RSTEP) * LDBH + bcq * 4) * 2, BPL_BYTES, rb[0][i]); };
     // transposed fragment read: lane l = 16g + 4q + p supplies row (k0 + q), columns c0 + 16*(g&1) + 4p .. +3 and
     // receives column c0 + (l & 31), rows k0 .. k0+3 (k0 already includes the lane half's 8*(l>>5))
     const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
@@ -564,23 +577,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         advance(it + 3 < it_end ? 1 : 0);
 #pragma unroll
         for (int s16 = 0; s16 < KT / 16; ++s16) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[NP][2], b[NP][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
-                if (!A_KM) a[i] = *(const bf16x8*)(As + ((row + l31) * LDAH + s16 * 16 + 8 * lh) * 2);
-                else a[i] = frag_km(As, LDAH, s16 * 16 + 8 * lh, row);
-                if (!B_KM) b[i] = *(const bf16x8*)(Bs + ((col + l31) * LDBH + s16 * 16 + 8 * lh) * 2);
-                else b[i] = frag_km(Bs, LDBH, s16 * 16 + 8 * lh, col);
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
+                    const char* Ap = As + pl * APL_BYTES;
+                    const char* Bp = Bs + pl * BPL_BYTES;
+                    if (!A_KM) a[pl][i] = *(const bf16x8*)(Ap + ((row + l31) * LDAH + s16 * 16 + 8 * lh) * 2);
+                    else a[pl][i] = frag_km(Ap, LDAH, s16 * 16 + 8 * lh, row);
+                    if (!B_KM) b[pl][i] = *(const bf16x8*)(Bp + ((col + l31) * LDBH + s16 * 16 + 8 * lh) * 2);
+                    else b[pl][i] = frag_km(Bp, LDBH, s16 * 16 + 8 * lh, col);
+                }
+            if constexpr (PREC == 2) {
+                // a*b = sum_{p,q} a_p*b_q over the 3x3 plane pairs; the three pairs dropped (mid*lo, lo*mid, lo*lo) are
+                // <= 2^-23 of |a*b| together.  bf16 x bf16 products are exact in fp32; smallest terms are added first.
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][jn], acc[i][jn], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][jn], acc[i][jn], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jn], acc[i][jn], 0, 0, 0);
         }
         __syncthreads();
     };
-    if constexpr (PREC == 1) {
+    if constexpr (PREC >= 1) {
         static_assert(KT % 16 == 0 && (LDAH * 2) % 16 == 0 && (LDBH * 2) % 16 == 0 && AH_BYTES % 16 == 0, "bf16 LDS image alignment");
         if (it_begin < it_end) {
 #pragma unroll
@@ -947,10 +977,13 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     pl->wm = 2; pl->wn = 2; pl->kt = (kt_opt == 16) ? 16 : 32;
     // bf16 MFMA operands (option "bf16"): bf16 LDS tiles, K-tile 64 (32 with the 256x64 tile, whose LDS would
     // otherwise allow one workgroup per CU only); needs the buffer-descriptor kernels and whole K-tiles per tap
-    bool want_bf16 = dg_get_option(DG_OPT_BF16) == 1;
+    const int popt = dg_get_option(DG_OPT_BF16);      // 0 exact fp32 MFMA, 1 bf16 operands, 2 fp32 as three bf16 planes
+    bool want_bf16 = popt == 1;
+    const bool want_x3 = popt == 2;
     if (want_bf16 && op == 0 && g.C % 64 != 0) want_bf16 = false;
     if (want_bf16 && op == 1 && g.stride == 2 && g.K % 64 != 0) want_bf16 = false;
     if (want_bf16) pl->kt = 64;
+    if (want_x3) pl->kt = 16;
     int zmul = 1;
     if (op == 0) {
         pl->mode = MODE_FWD;
@@ -979,8 +1012,8 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
-        a.prec = (fits && want_bf16) ? 1 : 0;
-        if (want_bf16 && !fits) {            // >= 2 GiB operands: fp32 pointer kernels with their own K-tile
+        a.prec = !fits ? 0 : (want_bf16 ? 1 : (want_x3 ? 2 : 0));
+        if ((want_bf16 || want_x3) && !fits) {            // >= 2 GiB operands: fp32 pointer kernels with their own K-tile
             pl->kt = (pl->mode == MODE_DGRAD_S2 && pl->wm == 4) ? 16 : 32;
             if (pl->mode == MODE_FWD) a.nIt = 16 * g.C / pl->kt;
             else if (pl->mode == MODE_DGRAD_S2) a.nIt = 4 * g.K / pl->kt;
@@ -1013,11 +1046,11 @@ static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
     else
         hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false, 0>), dim3(grid), dim3(256), 0, st, a);
 }
-// bf16 operand tiles (PREC 1): buffer-descriptor kernels only
-template <int MODE, int WM, int WN, int KT>
+// bf16 operand tiles (PREC 1) / fp32 as three bf16 planes (PREC 2): buffer-descriptor kernels only
+template <int MODE, int WM, int WN, int KT, int PREC>
 static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), dim3(grid), dim3(256), 0, st, a);
 }
 
 static long long* g_stamp_buf = nullptr;
@@ -1042,13 +1075,19 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     const int key = a.prec == 1 ? 1000 + pl.mode * 100 + pl.wm * 10 + (pl.kt == 64 ? 1 : 0)
+                  : a.prec == 2 ? 2000 + pl.mode * 100 + pl.wm * 10
                                 : pl.mode * 100 + pl.wm * 10 + (pl.kt == 32 ? 1 : 0);
     switch (key) {
-        case 1000 + MODE_FWD * 100 + 21: launch_igemm_bf16<MODE_FWD, 2, 2, 64>(a, zmul, st); break;
-        case 1000 + MODE_DGRAD_S2 * 100 + 21: launch_igemm_bf16<MODE_DGRAD_S2, 2, 2, 64>(a, zmul, st); break;
-        case 1000 + MODE_DGRAD_S2 * 100 + 40: launch_igemm_bf16<MODE_DGRAD_S2, 4, 1, 32>(a, zmul, st); break;
-        case 1000 + MODE_DGRAD_PLAIN * 100 + 21: launch_igemm_bf16<MODE_DGRAD_PLAIN, 2, 2, 64>(a, zmul, st); break;
-        case 1000 + MODE_WGRAD * 100 + 21: launch_igemm_bf16<MODE_WGRAD, 2, 2, 64>(a, zmul, st); break;
+        case 1000 + MODE_FWD * 100 + 21: launch_igemm_bf16<MODE_FWD, 2, 2, 64, 1>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_S2 * 100 + 21: launch_igemm_bf16<MODE_DGRAD_S2, 2, 2, 64, 1>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_S2 * 100 + 40: launch_igemm_bf16<MODE_DGRAD_S2, 4, 1, 32, 1>(a, zmul, st); break;
+        case 1000 + MODE_DGRAD_PLAIN * 100 + 21: launch_igemm_bf16<MODE_DGRAD_PLAIN, 2, 2, 64, 1>(a, zmul, st); break;
+        case 1000 + MODE_WGRAD * 100 + 21: launch_igemm_bf16<MODE_WGRAD, 2, 2, 64, 1>(a, zmul, st); break;
+        case 2000 + MODE_FWD * 100 + 20: launch_igemm_bf16<MODE_FWD, 2, 2, 16, 2>(a, zmul, st); break;
+        case 2000 + MODE_DGRAD_S2 * 100 + 20: launch_igemm_bf16<MODE_DGRAD_S2, 2, 2, 16, 2>(a, zmul, st); break;
+        case 2000 + MODE_DGRAD_S2 * 100 + 40: launch_igemm_bf16<MODE_DGRAD_S2, 4, 1, 16, 2>(a, zmul, st); break;
+        case 2000 + MODE_DGRAD_PLAIN * 100 + 20: launch_igemm_bf16<MODE_DGRAD_PLAIN, 2, 2, 16, 2>(a, zmul, st); break;
+        case 2000 + MODE_WGRAD * 100 + 20: launch_igemm_bf16<MODE_WGRAD, 2, 2, 16, 2>(a, zmul, st); break;
         case MODE_FWD * 100 + 21: launch_igemm<MODE_FWD, 2, 2, 32>(a, zmul, st); break;
         case MODE_FWD * 100 + 20: launch_igemm<MODE_FWD, 2, 2, 16>(a, zmul, st); break;
         case MODE_DGRAD_S2 * 100 + 21: launch_igemm<MODE_DGRAD_S2, 2, 2, 32>(a, zmul, st); break;

@@ -77,8 +77,9 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
                         "log). Same weights; the generators' BatchNorm running statistics then differ from the reference's")
     p.add_argument("--comm", type=str, default="auto", choices=["auto", "capi", "c10d"],
                    help="data-parallel transport: the library's own RCCL communicator (capi) or torch.distributed (c10d)")
-    p.add_argument("--mfma_dtype", type=str, default="f32", choices=["f32", "bf16"],
-                   help="bf16: conv operands rounded to bf16 on the matrix cores, fp32 accumulate/BatchNorm/weights/Adam")
+    p.add_argument("--mfma_dtype", type=str, default="f32", choices=["f32", "bf16", "f32x3"],
+                   help="bf16: conv operands rounded to bf16 on the matrix cores, fp32 accumulate/BatchNorm/weights/Adam; "
+                        "f32x3: fp32-accurate products from three bf16 planes per operand (six bf16 MFMAs per block)")
     return p
 
 

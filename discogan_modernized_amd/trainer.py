@@ -107,9 +107,11 @@ class DiscoGANTrainer:
         self.skew_steps = int(skew_steps)
         # mfma_dtype "bf16": the interior conv GEMMs round their operands to bf16 and run on the bf16 matrix path
         # with fp32 accumulation (BASELINE configs[4]); tensors, BatchNorm, losses, master weights, Adam stay fp32.
+        # "f32x3": fp32-accurate products on the bf16 matrix path -- every operand is split into three bf16 planes
+        # (24 significand bits), six MFMAs per product block, fp32 accumulation (csrc/igemm.hip PREC 2).
         # Process-global library option, set for the lifetime of this trainer's calls.
-        if mfma_dtype not in ("f32", "bf16"):
-            raise ValueError("mfma_dtype must be 'f32' or 'bf16'")
+        if mfma_dtype not in ("f32", "bf16", "f32x3"):
+            raise ValueError("mfma_dtype must be 'f32', 'bf16' or 'f32x3'")
         self.mfma_dtype = mfma_dtype
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
@@ -340,16 +342,16 @@ class DiscoGANTrainer:
         _F.WGRAD_STREAM = self.wgrad_stream
         _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
         from . import _lib as _l
-        if self.mfma_dtype == "bf16":
-            _l.set_option("bf16", 1)
+        if self.mfma_dtype != "f32":
+            _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 2)
         try:
             out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
-            if self.mfma_dtype == "bf16":
-                _l.set_option("bf16", 0)          # the library default stays fp32 for everyone else
+            if self.mfma_dtype != "f32":
+                _l.set_option("bf16", 0)          # the library default stays exact fp32 for everyone else
         if self.skip_dead_work and not dstep:
             for p in self.optim_dis.params:               # a G-step froze the D parameters: give them back
                 p.requires_grad_(True)

@@ -307,12 +307,12 @@ def test_config3_full_batch_vs_reference_golden_512_n32(kind):
     torch.cuda.empty_cache()
 
 
-def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, need_noise=True):
+def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, need_noise=True, mfma_dtype="f32"):
     """Every iteration starts from the ORACLE's current weights/buffers; gradients are compared with an fp64 run of
     the oracle that differentiates the SAME activation sign pattern the implementation used (tests/kink_probe.py),
     so no kink term is left and the bound is max(1e-4, 4 x the reference's own fp32 error)."""
     st = st or O.build_state(image_size=S, seed=1234)
-    tr = tr or DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234)
+    tr = tr or DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234, mfma_dtype=mfma_dtype)
     A, B = O.synthetic_batch(N, S, seed=0)
     Ag, Bg = A.to(DEV), B.to(DEV)
     table = []
@@ -374,6 +374,14 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
     """Losses, D outputs, per-tensor gradients, BN buffers and the Adam update op-wise on the oracle's gradients,
     through the saturated-discriminator regime (iterations 1-3)."""
     _teacher_forced(S, N, 4)
+
+
+@pytest.mark.parametrize("S,N", [(64, 4), (128, 2)])
+def test_teacher_forced_iterations_f32x3(S, N):
+    """mfma_dtype="f32x3" (fp32 operands as three bf16 planes on the bf16 matrix path) is held to EXACTLY the fp32
+    bounds of test_teacher_forced_iterations_vs_oracle: losses 2e-4, D outputs 2e-3, every gradient tensor within
+    max(1e-4, 4 x the reference's own fp32 error) of the fp64 oracle on the same activation pattern, BN buffers, Adam."""
+    _teacher_forced(S, N, 4, mfma_dtype="f32x3")
 
 
 def test_masked_fp64_gradient_parity_512():

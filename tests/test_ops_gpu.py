@@ -128,6 +128,55 @@ def test_conv_head_bf16_operands(N, C, K):
         _lib.set_option("bf16", 0)
 
 
+def _rel(got, ref64):
+    got = got.detach().double().cpu()
+    return ((got - ref64).norm() / ref64.norm().clamp_min(1e-300)).item()
+
+
+@pytest.mark.parametrize("N,C,K,H", [(2, 64, 128, 8), (3, 64, 128, 16), (2, 128, 256, 8), (4, 256, 64, 16), (5, 64, 128, 64),
+                                     (2, 1024, 2048, 8), (1, 2048, 2048, 8)])
+def test_conv_f32x3_is_fp32_accurate(N, C, K, H):
+    """Option "bf16" = 2 ("f32x3"): every fp32 operand is split into three bf16 planes (hi + mid + lo = 24 significand
+    bits) and each product block is six bf16 MFMAs with fp32 accumulation (the dropped plane pairs are <= 2^-23 of a
+    product).  The claim is fp32 accuracy, so the yardstick is the exact-fp32 MFMA path of the same library: against an
+    fp64 reference the split path may be at most 2x as far as the fp32-FMA-chain path (it is usually closer: the
+    products are exact and only the accumulation rounds), and it passes the plain fp32 tolerance of every op test."""
+    x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    y64 = TF.conv2d(x.double(), w.double(), stride=2, padding=1)
+    dx64 = TF.conv_transpose2d(dy.double(), w.double(), stride=2, padding=1)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=2, padding=1)
+    xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+    e32 = (_rel(ops.conv_fwd(xg, wg, 2, 1), y64), _rel(ops.conv_dgrad(dyg, wg, (H, H), 2, 1), dx64), _rel(ops.conv_wgrad(dyg, xg, 2, 1), dw64))
+    _lib.set_option("bf16", 2)
+    try:
+        y, dx, dw = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
+    finally:
+        _lib.set_option("bf16", 0)
+    close(y, y64.float(), what="f32x3 conv fwd")
+    close(dx, dx64.float(), rtol=2e-4, what="f32x3 conv dgrad")
+    close(dw, dw64.float(), rtol=2e-4, what="f32x3 conv wgrad")
+    ex3 = (_rel(y, y64), _rel(dx, dx64), _rel(dw, dw64))
+    print(f"[{N},{C},{K},{H}] rel L2 error vs fp64: exact-fp32 MFMA {e32[0]:.2e}/{e32[1]:.2e}/{e32[2]:.2e}  f32x3 {ex3[0]:.2e}/{ex3[1]:.2e}/{ex3[2]:.2e}")
+    for a, b, what in zip(ex3, e32, ("fwd", "dgrad", "wgrad")):
+        assert a <= 2.0 * b + 2e-7, f"f32x3 {what}: {a:.2e} vs exact-fp32 path {b:.2e}"
+
+
+@pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100)])
+def test_conv_head_f32x3(N, C, K):
+    x, w, dy = rnd(N, C, 4, 4, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, 1, 1, seed=3)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = TF.conv2d(xr, wr)
+    yr.backward(dy.double())
+    _lib.set_option("bf16", 2)
+    try:
+        xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+        close(ops.conv_fwd(xg, wg, 1, 0), yr.float(), what="f32x3 head fwd")
+        close(ops.conv_dgrad(dyg, wg, (4, 4), 1, 0), xr.grad.float(), rtol=2e-4, what="f32x3 head dgrad")
+        close(ops.conv_wgrad(dyg, xg, 1, 0), wr.grad.float(), rtol=2e-4, what="f32x3 head wgrad")
+    finally:
+        _lib.set_option("bf16", 0)
+
+
 def test_pointer_path_kernels():
     """Tensors of 2 GiB and more use the 64-bit addressing instantiations (no buffer descriptors); force them
     on small shapes so that path stays covered."""
