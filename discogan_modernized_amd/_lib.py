@@ -27,6 +27,8 @@ SIGNATURES = {
     "dg_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_fwd_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
+    "dg_conv_dgrad_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "dg_conv_plan_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dg_conv_bnstats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dg_conv_fwd_bnstats": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),

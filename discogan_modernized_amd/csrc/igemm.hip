@@ -51,8 +51,10 @@ struct IgemmArgs {
     int nIt, itPerSplit, splits;
     int tilesM, tilesN;
     int accumulate;
-    int act;      // FWD_C3 only: fused activation on the output
+    int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
     float slope;
+    int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
+    const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
     // fused BatchNorm statistics (FWD / DGRAD_S2): per-tile partial rows [P][3*Ng + 4] =
     // {count, -, -, -, shift[Ng], sum(y - shift)[Ng], sum((y - shift)^2)[Ng]}; nullptr = off
     float* stat;
@@ -713,9 +715,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             }
             dst += ncol;
             if (!to_part && p.accumulate) v += *(const f32x4*)dst;
-            if (MODE == MODE_FWD_C3) {
+            if (!to_part) {
+                if (MODE != MODE_FWD_C3 && MODE != MODE_WGRAD && p.bias != nullptr)
+                    v += *(const f32x4*)(p.bias + (MODE == MODE_DGRAD_PLAIN ? ncol % Cc : ncol));
+                if (MODE != MODE_WGRAD && p.act != 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dg_apply_act(v[e], p.act, p.slope);
+                    for (int e = 0; e < 4; ++e) v[e] = dg_apply_act(v[e], p.act, p.slope);
+                }
             }
             *(f32x4*)dst = v;
         }
@@ -757,6 +763,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
             dst = p.C + row * p.Ng + c4 * 4;
         }
         if (p.accumulate) s += *(const f32x4*)dst;
+        if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
+        if (p.act != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
+        }
         *(f32x4*)dst = s;
     }
 }
@@ -786,6 +797,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const IgemmArg
         for (int j = 1; j < 16; ++j) s += red[j][tx];
         float* dst = p.C + row * p.Ng + c4 * 4;
         if (p.accumulate) s += *(const f32x4*)dst;
+        if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
+        if (p.act != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
+        }
         *(f32x4*)dst = s;
     }
 }
@@ -1194,6 +1210,36 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
     make_plan(2, g, &pl);
     pl.a.A = dy; pl.a.B = x; pl.a.C = dw; pl.a.accumulate = accumulate;
     return run_plan("dg_conv_wgrad", pl, ws, ws_bytes, st);
+}
+
+// ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------
+// Replaces [Conv2d | ConvTranspose2d] -> BatchNorm2d(eval) -> LeakyReLU/ReLU of inference.py:149,172-187 by ONE kernel:
+// the caller multiplies the weights by gamma*invstd per output channel and passes bias = beta - mean*gamma*invstd.
+static int conv_bias_act(int op, const float* a_in, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                         int stride, int pad, int act, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
+    const char* who = op == 0 ? "dg_conv_fwd_bias_act" : "dg_conv_dgrad_bias_act";
+    ConvGeom g;
+    int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(a_in && w && out, "%s: null pointer", who);
+    DG_CHECK_ARG(K > 1, "%s: K == 1 head has no folded form", who);
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "%s: bad act %d", who, act);
+    if (op == 0) DG_CHECK_ARG(C % 32 == 0, "%s: C=%d must be a multiple of 32", who, C);
+    if (op == 1 && stride == 2) DG_CHECK_ARG(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
+    Plan pl;
+    make_plan(op, g, &pl);
+    pl.a.A = a_in; pl.a.B = w; pl.a.C = out;
+    pl.a.bias = bias; pl.a.act = act; pl.a.slope = slope;
+    pl.a.bias_mod = (pl.mode == MODE_DGRAD_PLAIN) ? C : pl.a.Ng;
+    return run_plan(who, pl, ws, ws_bytes, st);
+}
+extern "C" int dg_conv_fwd_bias_act(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int K,
+                                    int stride, int pad, int act, float slope, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_bias_act(0, x, w, bias, y, N, H, W, C, K, stride, pad, act, slope, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_dgrad_bias_act(const float* dy, const float* w, const float* bias, float* dx, int N, int H, int W, int C, int K,
+                                      int stride, int pad, int act, float slope, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_bias_act(1, dy, w, bias, dx, N, H, W, C, K, stride, pad, act, slope, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---- conv + fused BatchNorm partial statistics -------------------------------------------------------

@@ -235,6 +235,36 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     return (dx, stat) if want_stats else dx
 
 
+def conv_fwd_bias_act(x, w, bias, stride, pad, act=ACT_NONE, slope=0.2):
+    """Inference: act(Conv2d(x; w) + bias) in one kernel (BatchNorm folded into w / bias by the caller)."""
+    _check_dev(x, w, bias)
+    x, w = as_nhwc(x), _krsc(w)
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    ho, wo = _out_hw(h, wd, stride, pad)
+    y = empty_nhwc(n, k, ho, wo, x.device)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
+    _lib.check(L.dg_conv_fwd_bias_act(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, h, wd, c, k, stride, pad, act, slope, _ptr(ws), wsb,
+                                      _stream()), "dg_conv_fwd_bias_act")
+    return y
+
+
+def conv_dgrad_bias_act(x, w, bias, out_hw, stride, pad, act=ACT_NONE, slope=0.0):
+    """Inference: act(ConvTranspose2d(x; w) + bias) in one kernel; w is the transposed conv's [Cin,Cout,4,4] (KRSC memory)."""
+    _check_dev(x, w, bias)
+    x, w = as_nhwc(x), _krsc(w)
+    n, k = x.shape[0], x.shape[1]
+    c = w.shape[1]
+    h, wd = out_hw
+    y = empty_nhwc(n, c, h, wd, x.device)
+    L = _lib.load()
+    ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), x.device)
+    _lib.check(L.dg_conv_dgrad_bias_act(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, h, wd, c, k, stride, pad, act, slope, _ptr(ws), wsb,
+                                        _stream()), "dg_conv_dgrad_bias_act")
+    return y
+
+
 def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     """Weight-gradient of that Conv2d: returns logical [K,C,4,4] (KRSC memory)."""
     _check_dev(dy, x)

@@ -76,6 +76,15 @@ int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int 
 int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 
+/* Inference path (inference.py:149,172-187: generator.eval() forward): [Conv2d | ConvTranspose2d] -> BatchNorm2d(eval)
+ * -> LeakyReLU/ReLU as ONE kernel.  The caller folds the BatchNorm scale into the weights (w * gamma*invstd per output
+ * channel) and passes the shift as bias[out channels] = beta - running_mean*gamma*invstd; y = act(conv(x, w) + bias).
+ * Same geometry / layouts as dg_conv_fwd / dg_conv_dgrad (dgrad = ConvTranspose2d forward); bias may be NULL. */
+int dg_conv_fwd_bias_act(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int K,
+                         int stride, int pad, int act, float slope, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad_bias_act(const float* dy, const float* w, const float* bias, float* dx, int N, int H, int W, int C, int K,
+                           int stride, int pad, int act, float slope, void* ws, size_t ws_bytes, dg_stream_t stream);
+
 /* Stride-2 conv forward / dgrad (= ConvTranspose2d forward) that ALSO emit BatchNorm partial statistics
  * of the output from the kernel epilogue (or from the split-K reduction), saving the separate read
  * pass of dg_bn_train_stats.  stat: [rows][3*cols + 4] floats with rows = dg_conv_bnstats_rows(op,...)

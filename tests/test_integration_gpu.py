@@ -139,6 +139,60 @@ def test_u8_ingest_matches_dataset_normalisation():
     assert (got == ref[:, ::-1]).all()
 
 
+@pytest.mark.parametrize("S,N", [(16, 5), (64, 3), (128, 1)])
+def test_folded_inference_generator_matches_oracle_eval(S, N):
+    """inference.py:149: generator.eval().  BatchNorm folded into the convolutions (scale into the weights, shift +
+    activation in the conv epilogue) against the oracle's eval-mode forward, with running statistics moved away from
+    their initial (0, 1) and non-trivial gamma / beta."""
+    from oracle import discogan_ref as O
+    from discogan_modernized_amd.inference import FoldedGenerator
+    torch.manual_seed(11)
+    og = O.Generator(True, image_size=S)
+    og.train()
+    with torch.no_grad():
+        for _ in range(3):
+            og(torch.rand(4, 3, S, S))
+        for m in og.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    og.eval()
+    mg = model.Generator(True, image_size=S).to(DEV)
+    mg.load_state_dict(og.state_dict())
+    mg.eval()
+    x = torch.rand(N, 3, S, S)
+    with torch.no_grad():
+        ref = og(x)
+        plain = mg(x.to(DEV))
+    folded = FoldedGenerator(mg)(x.to(DEV))
+    assert folded.shape == ref.shape
+    for got, what in ((plain, "eval modules"), (folded, "folded")):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item() + 1e-5, f"{what}: max err {err:.2e}"
+
+
+def test_inference_cli_roundtrip(tmp_path):
+    """`python -m discogan_modernized_amd.inference`: checkpoints written by the training CLI, AtoB uses gen_B_final.pth
+    and reconstructs with gen_A_final.pth (inference.py:127-136,171-187); uint8 image-row input."""
+    from discogan_modernized_amd import inference as inf
+    argv = ["--task_name", "edges2shoes", "--image_size", "16", "--batch_size", "4", "--synthetic_size", "8", "--epochs", "2",
+            "--results_dir", str(tmp_path / "r"), "--models_dir", str(tmp_path / "m")]
+    it_cli.main(argv)
+    _, mp = it_cli.train.last_paths
+    g = torch.Generator().manual_seed(4)
+    torch.save(torch.randint(0, 256, (3, 16, 16, 3), generator=g, dtype=torch.uint8), tmp_path / "imgs.pt")
+    res = inf.main(["--model_path", str(mp), "--input_path", str(tmp_path / "imgs.pt"), "--image_size", "16",
+                    "--output_dir", str(tmp_path / "out"), "--direction", "AtoB"])
+    stem, gen, rec = res[0]
+    assert gen.shape == (3, 3, 16, 16) and rec.shape == (3, 3, 16, 16) and float(gen.min()) > 0 and float(gen.max()) < 1
+    saved = torch.load(tmp_path / "out" / "imgs_result.pt")
+    assert torch.equal(saved["generated"], gen.cpu())
+    # the folded path == the training modules in eval mode
+    res2 = inf.main(["--model_path", str(mp), "--input_path", str(tmp_path / "imgs.pt"), "--image_size", "16",
+                     "--output_dir", str(tmp_path / "out2"), "--direction", "AtoB", "--no_fold"])
+    assert torch.allclose(res2[0][1], gen, rtol=1e-4, atol=1e-6) and torch.allclose(res2[0][2], rec, rtol=1e-4, atol=1e-6)
+
+
 def _cli(tmp, tag, extra):
     argv = ["--task_name", "edges2shoes", "--image_size", "16", "--batch_size", "4", "--synthetic_size", "16", "--epochs", "3",
             "--log_interval", "1", "--model_save_interval", "5", "--save_train_state",
