@@ -134,7 +134,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     int bid = blockIdx.x;
     int tn, tm, parity = 0, split;
-    if (p.xcd_group) {
+    if (p.xcd_group == 2) {
+        // Weight-dominated layers (deep stages: the B operand is tens to hundreds of MB, A a few MB): the row tiles
+        // that stream the SAME weight columns / K-slice are the ones that must share an L2 -- the G = tilesM row tiles
+        // of one (column tile, parity, split) get blockIdx values 8 apart (one XCD, one dispatch window).
+        const int G = p.tilesM;
+        tm = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = rest & 3;
+            rest >>= 2;
+        }
+        tn = rest % p.tilesN;
+        split = rest / p.tilesN;
+    } else if (p.xcd_group) {
         // Workgroups that read the same operand-A rows -- the N-tile columns of a row tile and, for the transposed
         // conv, its four output-parity classes -- should share an L2.  Workgroups are dealt to the 8 XCDs round
         // robin by blockIdx, so such a group of G workgroups gets blockIdx values 8 apart (same XCD, dispatched
@@ -1048,6 +1061,13 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     // the 256x64 tile 135 -> 104, input-grad with 128x128 tiles 64 -> 76 (worse: left in plain order)
     a.xcd_group = ((a.tilesM * a.splits) % 8 == 0 && dg_get_option(DG_OPT_RESERVED) == 0 &&
                    !(pl->mode == MODE_DGRAD_S2 && pl->wm != 4)) ? 1 : 0;   // option "no_xcd_group" switches it off
+    {   // weight-dominated layers: share the B operand instead (mode 2, see the kernel)
+        const long a_bytes = (long)a.M * (pl->mode == MODE_FWD ? 16L * g.C : (pl->mode == MODE_DGRAD_S2 ? 4L * g.K : g.K)) * 4;
+        const long b_bytes = (long)g.K * 16 * g.C * 4 / (pl->mode == MODE_DGRAD_S2 ? 4 : 1);
+        if ((pl->mode == MODE_FWD || pl->mode == MODE_DGRAD_S2) && dg_get_option(DG_OPT_RESERVED) == 0 && b_bytes > a_bytes &&
+            a.tilesM > 1 && a.tilesM <= 64 && (a.tilesN * zmul * a.splits) % 8 == 0)
+            a.xcd_group = 2;
+    }
     pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
     pl->stat_rows = 0;
     if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)

@@ -7,11 +7,12 @@ an upper bound on HBM bytes."""
 import collections, csv, json, sys
 
 
-def means(path, counter):
+def means(path, counter, by_grid=False):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            key = r["Kernel_Name"] + (f" grid={r.get('Grid_Size', '?')}" if by_grid else "")
+            acc[key].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
@@ -30,6 +31,12 @@ for k in sorted(set(fetch) & set(write)):
         continue
     out["kernels"][k] = {"launches": n, "FETCH_SIZE_KB_raw": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                          "hbm_MB_per_launch": round((2 * f + w) / 1024, 2)}
+# per-layer view of the implicit-GEMM family: the same kernel at different grid sizes = different layers of bench_ops.py
+fg, wg = means(sys.argv[1], "FETCH_SIZE", True), means(sys.argv[2], "WRITE_SIZE", True)
+out["igemm_by_grid"] = {}
+for k in sorted(set(fg) & set(wg)):
+    if "igemm_kernel" in k and fg[k][1] >= 3:
+        out["igemm_by_grid"][k] = {"launches": fg[k][1], "hbm_MB_per_launch": round((2 * fg[k][0] + wg[k][0]) / 1024, 2)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["kernels"].items():
     print(f"{k[:70]:70s} {v['hbm_MB_per_launch']:9.2f} MB/launch  (n={v['launches']})")
