@@ -109,8 +109,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // PREC 2 ("f32x3"): every fp32 operand value is split into THREE bf16 planes hi + mid + lo (24 significand bits in
     // all), K-tile 16, and each 32x32x16 product block is six bf16 MFMAs (see body_h).
     constexpr int NP = PREC == 2 ? 3 : 1;
-    constexpr int LDAH = A_KM ? (BM + 32) : (KT + 8);
-    constexpr int LDBH = B_KM ? (BN + 32) : (KT + 8);
+    // PREC 2 k-contiguous images: rows of exactly 16 bf16 = two 16-B chunks, no padding; the chunk index is XORed with
+    // bit 3 of the row, so the rows a ds_read_b128 lane group touches (r and r + 8k) land on different 16-B slots.
+    constexpr bool SWZ = PREC == 2;
+    constexpr int LDAH = A_KM ? (BM + 32) : (SWZ ? KT : KT + 8);
+    constexpr int LDBH = B_KM ? (BN + 32) : (SWZ ? KT : KT + 8);
     constexpr int APL_BYTES = A_ROWS * LDAH * 2, BPL_BYTES = B_ROWS * LDBH * 2;     // one plane
     constexpr int AH_BYTES = NP * APL_BYTES, BH_BYTES = NP * BPL_BYTES;
     constexpr int STAGEH_FLOATS = (AH_BYTES + BH_BYTES) / 4;
@@ -551,19 +554,39 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     char* const smb = (char*)smem;
     // fp32 -> bf16 planes.  PREC 1: one RNE rounding.  PREC 2: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
     // both subtractions are exact in fp32, so hi + mid + lo carries 24 significand bits of v.
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // two floats -> one dword of two RNE-rounded bf16 (ONE v_cvt_pk_bf16_f32); the fp32 value of each half is a shift / a mask
+    auto pk2 = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2)); };
+    auto lo_f = [](unsigned p) -> float { return __builtin_bit_cast(float, p << 16); };
+    auto hi_f = [](unsigned p) -> float { return __builtin_bit_cast(float, p & 0xffff0000u); };
     auto split_store = [&](char* dst, int plane_bytes, const f32x4& v) {
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        *(bf16x4*)dst = h;
-        if constexpr (PREC == 2) {
-            const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
-            const bf16x4 m = __builtin_convertvector(r1, bf16x4);
-            *(bf16x4*)(dst + plane_bytes) = m;
-            const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-            *(bf16x4*)(dst + 2 * plane_bytes) = __builtin_convertvector(r2, bf16x4);
+        const unsigned h0 = pk2(v[0], v[1]), h1 = pk2(v[2], v[3]);
+        *(u32x2*)dst = (u32x2){h0, h1};
+        if constexpr (PREC == 2) {      // 5.5 VALU per element: 1.5 packed converts, 2 unpacks, 2 exact subtractions
+            const float r0 = v[0] - lo_f(h0), r1 = v[1] - hi_f(h0), r2 = v[2] - lo_f(h1), r3 = v[3] - hi_f(h1);
+            const unsigned m0 = pk2(r0, r1), m1 = pk2(r2, r3);
+            *(u32x2*)(dst + plane_bytes) = (u32x2){m0, m1};
+            const unsigned l0 = pk2(r0 - lo_f(m0), r1 - hi_f(m0)), l1 = pk2(r2 - lo_f(m1), r3 - hi_f(m1));
+            *(u32x2*)(dst + 2 * plane_bytes) = (u32x2){l0, l1};
         }
     };
-    auto sth_A = [&](char* stage, int i) { split_store(stage + ((arow0 + i * A_RSTEP) * LDAH + acq * 4) * 2, APL_BYTES, ra[0][i]); };
-    auto sth_B = [&](char* stage, int i) { split_store(stage + AH_BYTES + ((brow0 + i * B_RSTEP) * LDBH + bcq * 4) * 2, BPL_BYTES, rb[0][i]); };
+    // NSR register sets: tile j waits in set (j - it_begin) % NSR between its global load and its LDS store, so loads are
+    // in flight for NSR K-tiles (a bf16 / f32x3 K-tile is only 512-768 MFMA cycles: one tile does not cover an HBM miss)
+    constexpr int NSR = 2;
+    auto kc_off = [&](int row, int ld, int k) -> int {     // byte offset of element (row, k) of a k-contiguous image
+        if (SWZ) return row * (KT * 2) + ((((k >> 3) ^ (row >> 3)) & 1) << 4) + (k & 7) * 2;
+        return (row * ld + k) * 2;
+    };
+    auto sth_A = [&](char* stage, int set, int i) {
+        const int row = arow0 + i * A_RSTEP;
+        split_store(stage + (A_KM ? (row * LDAH + acq * 4) * 2 : kc_off(row, LDAH, acq * 4)), APL_BYTES, ra[set][i]);
+    };
+    auto sth_B = [&](char* stage, int set, int i) {
+        const int row = brow0 + i * B_RSTEP;
+        split_store(stage + AH_BYTES + (B_KM ? (row * LDBH + bcq * 4) * 2 : kc_off(row, LDBH, bcq * 4)), BPL_BYTES, rb[set][i]);
+    };
     // transposed fragment read: lane l = 16g + 4q + p supplies row (k0 + q), columns c0 + 16*(g&1) + 4p .. +3 and
     // receives column c0 + (l & 31), rows k0 .. k0+3 (k0 already includes the lane half's 8*(l>>5))
     const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
@@ -573,59 +596,135 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * ld * 2));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+    // One K-tile, hand-interleaved (the compiler, left alone, emits the whole conversion / LDS-write block of tile it+1
+    // first and the MFMAs back to back behind it, so a wave's matrix phase and its VALU phase never overlap; its
+    // scheduler also ignored sched_group_barrier hints here).  The staging work of tile it+1 is cut into steps and
+    // one or two steps follow every MFMA, fenced with sched_barrier like the fp32 body:
+    //   PREC 1: per load item   {convert + LDS store, re-issue the item's global load for tile it+3}
+    //   PREC 2: per load item   {hi planes + store, residuals, mid planes + store, residuals, lo planes + store, re-load}
+    // MFMA q of the tile: PREC 1 k16 step q/4, accumulators (q/2)&1, q&1; PREC 2 plane pair q/4 of the six.
+    constexpr int NMF = (KT / 16) * 4 * (PREC == 2 ? 6 : 1);          // MFMAs per K-tile per wave
+    constexpr int SPI = PREC == 2 ? 6 : 2;                             // staging steps per load item
+    constexpr int NST = NLD * SPI;
+    constexpr int SPM = (NST + NMF - 1) / NMF;                         // staging steps behind each MFMA
+    // PREC 2 fragments live across tiles: set (tile parity) is multiplied while the next tile's set is fetched right
+    // behind the tile barrier, which sits 8 MFMAs before the end of the tile (as in the fp32 body): barrier skew and
+    // the LDS read latency are covered by the current tile's last MFMAs.
+    bf16x8 xa[2][NP][2], xb[2][NP][2];
+    auto frags_x = [&](const char* stage, int set) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
+                const char* Ap = stage + pl * APL_BYTES;
+                const char* Bp = stage + AH_BYTES + pl * BPL_BYTES;
+                if (!A_KM) xa[set][pl][i] = *(const bf16x8*)(Ap + kc_off(row + l31, LDAH, 8 * lh));
+                else xa[set][pl][i] = frag_km(Ap, LDAH, 8 * lh, row);
+                if (!B_KM) xb[set][pl][i] = *(const bf16x8*)(Bp + kc_off(col + l31, LDBH, 8 * lh));
+                else xb[set][pl][i] = frag_km(Bp, LDBH, 8 * lh, col);
+            }
+    };
+    constexpr int QB = NMF > 8 ? NMF - 8 : 1;                                         // the tile barrier comes before MFMA QB
+    constexpr int SPQ = (NST + QB - 1) / QB;                            // staging steps behind each of the first QB MFMAs
     auto body_h = [&](auto P, int it) {
+        constexpr int p_ = decltype(P)::value;
+        char* nxt = smb + (p_ ^ 1) * (AH_BYTES + BH_BYTES);
+        const int itn = min(it + 1 + NSR, it_last);  // tile it+3 -> the register set just emptied (re-loads the last tile at the end)
+        unsigned th0 = 0, th1 = 0, tm0 = 0, tm1 = 0;
+        float tr0 = 0.f, tr1 = 0.f, tr2 = 0.f, tr3 = 0.f;
+        auto stage_step = [&](int st) {
+            const int item = st / SPI, ph = st % SPI;
+            const bool isA = item < NVA;
+            const int ii = isA ? item : item - NVA;
+            const f32x4 v = isA ? ra[p_ ^ 1][ii] : rb[p_ ^ 1][ii];
+            char* dst;
+            int plane;
+            if (isA) {
+                const int row = arow0 + ii * A_RSTEP;
+                dst = nxt + (A_KM ? (row * LDAH + acq * 4) * 2 : kc_off(row, LDAH, acq * 4));
+                plane = APL_BYTES;
+            } else {
+                const int row = brow0 + ii * B_RSTEP;
+                dst = nxt + AH_BYTES + (B_KM ? (row * LDBH + bcq * 4) * 2 : kc_off(row, LDBH, bcq * 4));
+                plane = BPL_BYTES;
+            }
+            if (ph == 0) {
+                th0 = pk2(v[0], v[1]); th1 = pk2(v[2], v[3]);
+                *(u32x2*)dst = (u32x2){th0, th1};
+            } else if (ph == SPI - 1) {               // the item's registers are free: re-issue its load for tile it+3
+                if (isA) load_A(p_ ^ 1, ii, itn); else load_B(p_ ^ 1, ii, itn);
+            } else if (ph == 1) {
+                tr0 = v[0] - lo_f(th0); tr1 = v[1] - hi_f(th0); tr2 = v[2] - lo_f(th1); tr3 = v[3] - hi_f(th1);
+            } else if (ph == 2) {
+                tm0 = pk2(tr0, tr1); tm1 = pk2(tr2, tr3);
+                *(u32x2*)(dst + plane) = (u32x2){tm0, tm1};
+            } else if (ph == 3) {
+                tr0 -= lo_f(tm0); tr1 -= hi_f(tm0); tr2 -= lo_f(tm1); tr3 -= hi_f(tm1);
+            } else {
+                *(u32x2*)(dst + 2 * plane) = (u32x2){pk2(tr0, tr1), pk2(tr2, tr3)};
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == QB) {
+                // every wave's stores of tile it+1 are done (all staging steps sit behind MFMAs < QB) and every wave's
+                // fragment reads of tile it were issued before its first MFMA
+                __syncthreads();
+                frags_x(nxt, p_ ^ 1);
+            }
+            const int i = (q >> 1) & 1, jn = q & 1;
+            // a*b = sum over the 3x3 plane pairs; the three pairs dropped (mid*lo, lo*mid, lo*lo) are together
+            // <= 2^-23 of |a*b|.  bf16 x bf16 products are exact in fp32; smallest terms are added first.
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[p_][PA[q >> 2]][i], xb[p_][PB[q >> 2]][jn], acc[i][jn], 0, 0, 0);
+            if (q < QB) {
+#pragma unroll
+                for (int u = 0; u < SPQ; ++u)
+                    if (q * SPQ + u < NST) stage_step(q * SPQ + u);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        advance(it + 2 + NSR < it_end ? 1 : 0);
+    };
+    // PREC 1 keeps the compiler-scheduled form of the same K-tile: with 16 load items in two register sets the
+    // hand-interleaved body above needs double-buffered fragments on top and spills (measured 652 -> 485 TFLOP/s).
+    auto body_c = [&](auto P, int it) {
         constexpr int p_ = decltype(P)::value;
         const char* As = smb + p_ * (AH_BYTES + BH_BYTES);
         const char* Bs = As + AH_BYTES;
         char* nxt = smb + (p_ ^ 1) * (AH_BYTES + BH_BYTES);
-        if (it + 1 < it_end) {                       // tile it+1: registers -> bf16 -> the other LDS buffer
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) sth_A(nxt, i);
+        for (int i = 0; i < NVA; ++i) sth_A(nxt, p_ ^ 1, i);
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) sth_B(nxt, i);
-        }
-        const int itn = min(it + 2, it_last);        // tile it+2 -> registers (re-loads the last tile at the end)
+        for (int i = 0; i < NVB; ++i) sth_B(nxt, p_ ^ 1, i);
+        const int itn = min(it + 1 + NSR, it_last);
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) load_A(0, i, itn);
+        for (int i = 0; i < NVA; ++i) load_A(p_ ^ 1, i, itn);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) load_B(0, i, itn);
-        advance(it + 3 < it_end ? 1 : 0);
+        for (int i = 0; i < NVB; ++i) load_B(p_ ^ 1, i, itn);
+        advance(it + 2 + NSR < it_end ? 1 : 0);
 #pragma unroll
         for (int s16 = 0; s16 < KT / 16; ++s16) {
-            bf16x8 a[NP][2], b[NP][2];
+            bf16x8 a[2], b[2];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
-                    const char* Ap = As + pl * APL_BYTES;
-                    const char* Bp = Bs + pl * BPL_BYTES;
-                    if (!A_KM) a[pl][i] = *(const bf16x8*)(Ap + ((row + l31) * LDAH + s16 * 16 + 8 * lh) * 2);
-                    else a[pl][i] = frag_km(Ap, LDAH, s16 * 16 + 8 * lh, row);
-                    if (!B_KM) b[pl][i] = *(const bf16x8*)(Bp + ((col + l31) * LDBH + s16 * 16 + 8 * lh) * 2);
-                    else b[pl][i] = frag_km(Bp, LDBH, s16 * 16 + 8 * lh, col);
-                }
-            if constexpr (PREC == 2) {
-                // a*b = sum_{p,q} a_p*b_q over the 3x3 plane pairs; the three pairs dropped (mid*lo, lo*mid, lo*lo) are
-                // <= 2^-23 of |a*b| together.  bf16 x bf16 products are exact in fp32; smallest terms are added first.
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < 2; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][jn], acc[i][jn], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][jn], acc[i][jn], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
+                if (!A_KM) a[i] = *(const bf16x8*)(As + kc_off(row + l31, LDAH, s16 * 16 + 8 * lh));
+                else a[i] = frag_km(As, LDAH, s16 * 16 + 8 * lh, row);
+                if (!B_KM) b[i] = *(const bf16x8*)(Bs + kc_off(col + l31, LDBH, s16 * 16 + 8 * lh));
+                else b[i] = frag_km(Bs, LDBH, s16 * 16 + 8 * lh, col);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jn], acc[i][jn], 0, 0, 0);
         }
         __syncthreads();
     };
     if constexpr (PREC >= 1) {
+        static_assert(!SWZ || KT == 16, "the XOR swizzle is written for 16-element rows");
         static_assert(KT % 16 == 0 && (LDAH * 2) % 16 == 0 && (LDBH * 2) % 16 == 0 && AH_BYTES % 16 == 0, "bf16 LDS image alignment");
         if (it_begin < it_end) {
 #pragma unroll
@@ -634,21 +733,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             for (int i = 0; i < NVB; ++i) load_B(0, i, it_begin);
             advance(it_begin + 1 < it_end ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) sth_A(smb, i);
+            for (int i = 0; i < NVA; ++i) load_A(1, i, min(it_begin + 1, it_last));
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) sth_B(smb, i);
-#pragma unroll
-            for (int i = 0; i < NVA; ++i) load_A(0, i, min(it_begin + 1, it_last));
-#pragma unroll
-            for (int i = 0; i < NVB; ++i) load_B(0, i, min(it_begin + 1, it_last));
+            for (int i = 0; i < NVB; ++i) load_B(1, i, min(it_begin + 1, it_last));
             advance(it_begin + 2 < it_end ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) sth_A(smb, 0, i);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) sth_B(smb, 0, i);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) load_A(0, i, min(it_begin + 2, it_last));
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) load_B(0, i, min(it_begin + 2, it_last));
+            advance(it_begin + 3 < it_end ? 1 : 0);
         }
         __syncthreads();
         if (stp) stp[2] = clock64();
+        if constexpr (PREC == 2) frags_x(smb, 0);
         for (int it = it_begin; it < it_end; it += 2) {
-            body_h(std::integral_constant<int, 0>{}, it);
-            if (it + 1 < it_end) body_h(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (PREC == 2) {
+                body_h(std::integral_constant<int, 0>{}, it);
+                if (it + 1 < it_end) body_h(std::integral_constant<int, 1>{}, it + 1);
+            } else {
+                body_c(std::integral_constant<int, 0>{}, it);
+                if (it + 1 < it_end) body_c(std::integral_constant<int, 1>{}, it + 1);
+            }
         }
+        if constexpr (PREC == 2) __syncthreads();      // the last tile's fragment prefetch read LDS behind the tile barrier
     } else {
         for (int it = it_begin; it < it_end; it += 2) {
             body(std::integral_constant<int, 0>{}, it);
