@@ -235,12 +235,37 @@ def cpu_baseline(image_size, batch, budget_s, update_interval=3):
     return batch * n / dt, dt, n
 
 
+COMM_NOTE = []
+
+
 def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None):
     from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args
     ov = {"auto": None, "on": True, "off": False}[a.overlap] if overlap is None else overlap
-    return DiscoGANTrainer(default_args(), device=dev, image_size=image_size, seed=1234, process_group=pg,
-                           use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
-                           mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov, comm=comm or a.comm)
+    kw = dict(device=dev, image_size=image_size, seed=1234, process_group=pg,
+              use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
+              mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov)
+    want = comm or a.comm
+    if pg is None or want == "c10d":
+        return DiscoGANTrainer(default_args(), comm=want, **kw)
+    # Multi-rank run: the library's own RCCL communicator is the default transport.  Should its bootstrap fail on ANY rank
+    # (it has only been exercised with one rank on the builder's 1-GPU boxes), every rank falls back to torch.distributed's
+    # RCCL together and the JSON says so -- a benchmark harness decision, visible, never silent.
+    import torch
+    import torch.distributed as dist
+    tr, err = None, ""
+    try:
+        tr = DiscoGANTrainer(default_args(), comm=want, **kw)
+    except Exception as e:            # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if tr is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return tr
+    if tr is not None:
+        tr.close()
+    COMM_NOTE.append(f"capi transport unavailable on at least one rank ({err or 'another rank failed'}); all ranks use c10d")
+    log(COMM_NOTE[-1])
+    return DiscoGANTrainer(default_args(), comm="c10d", **kw)
 
 
 def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycles=0, image_size=None):
@@ -329,7 +354,8 @@ def main():
         comm = dict(transport=tr.xg.describe(), backend=backend, world_size=dist.get_world_size(), rccl_world_size=rccl_ws,
                     allreduce_ms_per_D_step=round(ms.get("D", 0.0), 3), allreduce_ms_per_G_step=None,
                     allreduce_overlap=bool(tr.overlap_comm), exchanges=tr.xg.calls,
-                    payload_MB=dict(D=round(tr.optim_dis.numel * 4 / 1e6, 1), G=round(tr.optim_gen.numel * 4 / 1e6, 1)))
+                    payload_MB=dict(D=round(tr.optim_dis.numel * 4 / 1e6, 1), G=round(tr.optim_gen.numel * 4 / 1e6, 1)),
+                    note=(COMM_NOTE[-1] if COMM_NOTE else None))
         if "G" in ms:
             comm["allreduce_ms_per_G_step"] = round(ms["G"], 3)
             comm["G_step_buckets"] = len(tr._buckets.buckets) if tr._buckets is not None else 1
