@@ -271,7 +271,11 @@ def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=No
 def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycles=0, image_size=None):
     """value + optional roofline leg + optional D/G split for one trainer; returns a dict."""
     ui = tr.args.update_interval
-    warmup = (warmup + ui - 1) // ui * ui                 # timed region starts on a D-step
+    # K a multiple of the cycle: start on a D-step (whole D,G,G cycles, exact).  Otherwise start right AFTER a D-step, so
+    # the partial cycle at the end holds G-steps only: the window then has the fewest cheap D-steps a K-step window can
+    # have (conservative by <= 1.5 %), never the most.
+    phase = 0 if steps % ui == 0 else 1
+    warmup = warmup + (phase - warmup) % ui
     dt, it = timed_run(tr, A, B, steps, warmup, world)
     res = dict(images_per_sec=round(batch * world * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=bool(tr.overlap_comm))
@@ -434,7 +438,10 @@ def main():
                                 image_size=S, global_batch=N * world, parallelism=f"dp{world}",
                                 hipgraph=head["hipgraph"], hip_streams=1 if a.single_stream else 2,
                                 allreduce_overlap=head["allreduce_overlap"],
-                                timed_region="starts on a D-step; " + ("whole D,G,G cycles" if a.steps % 3 == 0 else f"{a.steps} steps (not a multiple of the 3-step cycle)")),
+                                timed_region=("starts on a D-step: whole D,G,G cycles" if a.steps % 3 == 0 else
+                                              f"{a.steps} steps are not a multiple of the 3-step cycle: the window starts right after a D-step "
+                                              f"({a.steps // 3} D-steps + {a.steps - a.steps // 3} G-steps, the conservative mix); "
+                                              "extra.ms_per_step_whole_cycles is the balanced figure")),
                     roofline=roof, cpu_baseline=cpu, comm=comm, extra=extra)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

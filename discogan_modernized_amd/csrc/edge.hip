@@ -5,11 +5,12 @@
 //
 //   c3_fwd (K == 64): a wave owns groups of 32 consecutive output pixels; MFMA operands gathered straight from
 //       the NCHW image with range-checked buffer loads (no LDS, no barriers after the weights are staged).
-//   c3_dgrad (K == 64): out[n,c,2a+ph,2b+pw] for a 2x2 output quad is a [9 neighbours x 64 k] . [576 x 12]
-//       product: M = quads, N = 12 (c,ph,pw) padded to 16, K = 576, on v_mfma_f32_16x16x4_f32.  The
-//       [576][16] weight image is structurally 4/9 dense (each output parity uses 2x2 of the 3x3
-//       neighbours); it is built once per call into the workspace and copied to LDS by each workgroup;
-//       the next tile's dy rows are prefetched into registers under the current tile's MFMAs.
+//   c3_dgrad (K == 64), scatter form: P[pixel][48 = (c,r,s)] = dy[pixel][64] . W[64][48] is a DENSE GEMM on
+//       v_mfma_f32_16x16x4_f32 (M = 16 pixels, N = 3 x 16 columns, the [64][48] weights in 48 registers per lane, the
+//       dy rows loaded straight into MFMA registers); out[c][2a-1+r][2b-1+s] += P[a][b][c][r][s] is a 4-term
+//       overlap-add through LDS inside a tile of 6 x 14 pixels computed with a 1-pixel halo (8 x 16).  The
+//       gather form it replaces (9 neighbours x 64 k against a 1/3-dense [576][16] weight image) needed 144 MFMA
+//       column-steps per 16 pixels, this one 48 x (8*16)/(6*14) = 73.
 //   c3_wgrad: dw[64][48] = dy^T [64 x pixels] . im2col(x) [pixels x 48] on v_mfma_f32_32x32x2_f32; every wave
 //       streams its own pixel range with operands loaded straight into MFMA registers (no LDS, no
 //       barriers); per-wave partial slabs are summed by a fixed-order reduction kernel (deterministic).
@@ -181,6 +182,90 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
     }
 }
 
+// ---- scatter form, K == 64 -------------------------------------------------------------------------------
+#define CS_TR 6                 // pixel rows of dy whose outputs a tile completes
+#define CS_TC 14                // pixel columns
+#define CS_PR (CS_TR + 2)       // computed rows (halo 1)  = 8 = 2 per wave
+#define CS_PC 16                // computed columns (halo 1) = one MFMA M group
+#define CS_LDP 52               // floats per pixel of the P image (48 + 4: the four k-quarters of a wave store to disjoint banks)
+__global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                  float* __restrict__ dx, int N, int H, int W, int act,
+                                                                  int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
+    __shared__ __attribute__((aligned(16))) float Ps[CS_PR * CS_PC * CS_LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, kq = lane >> 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    // B operand: W[k][col], col = c*16 + r*4 + s (the weight tensor's own order).  MFMA step s multiplies the four k values
+    // 16*kq + s (kq = lane >> 4): the k order inside the GEMM is free as long as A uses the same one, and this one lets
+    // every lane fetch its 16 A values of a pixel as 64 contiguous bytes.
+    float breg[3][16];
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) breg[blk][s] = w[(16 * kq + s) * 48 + blk * 16 + p];
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dybytes, 0x00020000);
+    constexpr int OOR = (int)0x80000000;
+    f32x4 areg[2][2][4];            // [set][row group][4 x float4 = 16 k values]
+    auto fetch = [&](int t, int set) {
+        const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int a = tr * CS_TR - 1 + wave + 4 * g, b = tc * CS_TC - 1 + p;
+            const bool ok = t < ntiles && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
+            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + 16 * kq) * 4 : OOR;   // out of range reads 0 = zero padding
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 16 * j, 0, 0));
+        }
+    };
+    fetch(blockIdx.x, 0);
+    auto tile = [&](auto SB, int t) {
+        constexpr int S = decltype(SB)::value;
+        const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
+        const int a0 = tr * CS_TR, b0 = tc * CS_TC;
+        fetch(t + gridDim.x, S ^ 1);             // next tile's rows fly under this tile's MFMAs
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk) acc[g][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int blk = 0; blk < 3; ++blk)
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[S][g][s >> 2][s & 3], breg[blk][s], acc[g][blk], 0, 0, 0);
+        __syncthreads();                          // the previous tile's readers of Ps are done
+        // C/D layout 16x16: column = lane & 15, pixel = 4*(lane >> 4) + reg
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ps[((wave + 4 * g) * CS_PC + 4 * kq + j) * CS_LDP + blk * 16 + p] = acc[g][blk][j];
+        __syncthreads();
+        // overlap-add: output row y = 2a + ph takes (a, r = 1 + ph) and (a - 1 + 2 ph, r = 3 - 3 ph); columns likewise.
+        // Tile-local pixel (la, lb) = (a - a0 + 1, b - b0 + 1); out-of-image pixels were loaded as zeros.
+        for (int e = tid; e < 3 * 2 * CS_TR * 2 * CS_TC; e += 256) {
+            const int xx = e % (2 * CS_TC), yy = (e / (2 * CS_TC)) % (2 * CS_TR), c = e / (4 * CS_TR * CS_TC);
+            const int y = 2 * a0 + yy, x = 2 * b0 + xx;
+            const int ph = yy & 1, pw = xx & 1, la = (yy >> 1) + 1, lb = (xx >> 1) + 1;
+            const int ra2 = la - 1 + 2 * ph, rr1 = 1 + ph, rr2 = 3 - 3 * ph;
+            const int cb2 = lb - 1 + 2 * pw, ss1 = 1 + pw, ss2 = 3 - 3 * pw;
+            const float* pc = Ps + c * 16;
+            float v = pc[(la * CS_PC + lb) * CS_LDP + rr1 * 4 + ss1] + pc[(la * CS_PC + cb2) * CS_LDP + rr1 * 4 + ss2] +
+                      pc[(ra2 * CS_PC + lb) * CS_LDP + rr2 * 4 + ss1] + pc[(ra2 * CS_PC + cb2) * CS_LDP + rr2 * 4 + ss2];
+            if (act == DG_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            if (y < H && x < W) dx[((long)(n * 3 + c) * H + y) * W + x] = v;
+        }
+    };
+    for (int t = blockIdx.x; t < ntiles; t += 2 * gridDim.x) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + (int)gridDim.x < ntiles) tile(std::integral_constant<int, 1>{}, t + gridDim.x);
+    }
+}
+
 extern "C" size_t dg_c3_dgrad_workspace_bytes(int K) { return K == CD_K ? (size_t)CD_NK * 16 * sizeof(float) : 0; }
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
                                      int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
@@ -191,7 +276,17 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
     DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "dg_conv4x4s2_c3_dgrad: tensor too large");
     hipStream_t st = (hipStream_t)stream;
     const int Ho = H / 2, Wo = W / 2;
-    if (K == CD_K) {
+    if (K == CD_K && (long)N * Ho * Wo * CD_K * 4 < (1L << 31)) {
+        if (dg_get_option(DG_OPT_KT) != 16) {       // scatter form (dense GEMM + overlap-add); "kt" 16 keeps the gather form testable
+            const int tiles_r = (Ho + CS_TR - 1) / CS_TR, tiles_c = (Wo + CS_TC - 1) / CS_TC;
+            const long ntiles = (long)N * tiles_r * tiles_c;
+            DG_CHECK_ARG(ntiles < (1L << 30), "dg_conv4x4s2_c3_dgrad: too many tiles");
+            const int grid = (int)(ntiles < 512 ? ntiles : 512);
+            hipLaunchKernelGGL(c3_dgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                               tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
+            DG_CHECK_LAUNCH("c3_dgrad_scatter");
+            return DG_OK;
+        }
         const int tiles_r = (Ho + CD_TR - 1) / CD_TR, tiles_c = (Wo + CD_TC - 1) / CD_TC;
         const long ntiles = (long)N * tiles_r * tiles_c;
         DG_CHECK_ARG(ntiles < (1L << 31), "dg_conv4x4s2_c3_dgrad: too many tiles");

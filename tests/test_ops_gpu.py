@@ -177,6 +177,28 @@ def test_conv_head_f32x3(N, C, K):
         _lib.set_option("bf16", 0)
 
 
+@pytest.mark.parametrize("N,H", [(2, 8), (3, 16), (2, 64), (1, 256), (5, 32)])
+def test_c3_dgrad_scatter_and_gather_forms(N, H):
+    """Last ConvTranspose2d(64,3,4,2,1) + Sigmoid: the scatter form (dense [pixels x 64].[64 x 48] GEMM + overlap-add in
+    LDS; tiles of 6 x 14 pixels with halo, so ragged in both directions at every size here) and the older gather form
+    (option kt=16) against F.conv_transpose2d, and against each other."""
+    x = rnd(N, 64, H // 2, H // 2, seed=5)
+    w = rnd(64, 3, 4, 4, seed=6, scale=0.1)
+    ref = torch.sigmoid(TF.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)).float()
+    xg, wg = nhwc(x), w.to(DEV)
+    a = ops.c3_dgrad(xg, wg, ops.ACT_SIGMOID)
+    close(a, ref, rtol=1e-5, atol=1e-6, what="c3 dgrad scatter form")
+    raw = ops.c3_dgrad(xg, wg, ops.ACT_NONE)
+    close(raw, TF.conv_transpose2d(x.double(), w.double(), stride=2, padding=1).float(), what="c3 dgrad scatter form (no act)")
+    _lib.set_option("kt", 16)
+    try:
+        b = ops.c3_dgrad(xg, wg, ops.ACT_SIGMOID)
+    finally:
+        _lib.set_option("kt", 0)
+    close(b, ref, rtol=1e-5, atol=1e-6, what="c3 dgrad gather form")
+    assert torch.equal(ops.c3_dgrad(xg, wg, ops.ACT_SIGMOID), a), "not deterministic"
+
+
 def test_pointer_path_kernels():
     """Tensors of 2 GiB and more use the 64-bit addressing instantiations (no buffer descriptors); force them
     on small shapes so that path stays covered."""
