@@ -53,6 +53,7 @@ struct IgemmArgs {
     int accumulate;
     int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
     float slope;
+    int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
     int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
     const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
     // fused BatchNorm statistics (FWD / DGRAD_S2): per-tile partial rows [P][3*Ng + 4] =
@@ -250,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     // ---- BUF: per-row byte offsets and per-row tap-validity bits ----------------------------------------
     constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB tensor
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, BUF ? (int)p.abytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, BUF ? (int)p.bbytes : 0, 0x00020000);
+    // p.dbg_zero (timing experiments only, tools/bench_ops.py --dbg_zero): bit 0 / 1 give the A / B descriptor zero records, so
+    // every load through it is dropped by the range check while the instruction stream stays (guide, section 7)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, BUF ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, BUF ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
     int a_ob[NVA], a_inv[NVA], b_ob[NVB];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
@@ -1153,6 +1156,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
         a.prec = !fits ? 0 : (want_bf16 ? 1 : (want_x3 ? 2 : 0));
+        a.dbg_zero = dg_get_option(DG_OPT_DBG_ZERO);
         if ((want_bf16 || want_x3) && !fits) {            // >= 2 GiB operands: fp32 pointer kernels with their own K-tile
             pl->kt = (pl->mode == MODE_DGRAD_S2 && pl->wm == 4) ? 16 : 32;
             if (pl->mode == MODE_FWD) a.nIt = 16 * g.C / pl->kt;

@@ -42,10 +42,12 @@ def main():
     ap.add_argument("--target_wgs", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bf16", type=int, default=0)
+    ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
     a = ap.parse_args()
     global ITERS
     ITERS = a.iters
     _lib.set_option("bf16", a.bf16)
+    _lib.set_option("dbg_zero", a.dbg_zero)
     _lib.set_option("kt", a.kt)
     _lib.set_option("splitk", a.splitk)
     _lib.set_option("target_wgs", a.target_wgs)
