@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     // NSR register sets: tile j waits in set (j - it_begin) % NSR between its global load and its LDS store, so loads are
     // in flight for NSR K-tiles (a bf16 / f32x3 K-tile is only 512-768 MFMA cycles: one tile does not cover an HBM miss)
-    constexpr int NSR = 2;
+    constexpr int NSR = PREC == 2 ? 2 : 1;
     auto kc_off = [&](int row, int ld, int k) -> int {     // byte offset of element (row, k) of a k-contiguous image
         if (SWZ) return row * (KT * 2) + ((((k >> 3) ^ (row >> 3)) & 1) << 4) + (k & 7) * 2;
         return (row * ld + k) * 2;
@@ -691,39 +691,44 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         advance(it + 2 + NSR < it_end ? 1 : 0);
     };
-    // PREC 1 keeps the compiler-scheduled form of the same K-tile: with 16 load items in two register sets the
-    // hand-interleaved body above needs double-buffered fragments on top and spills (measured 652 -> 485 TFLOP/s).
-    auto body_c = [&](auto P, int it) {
+    // PREC 1, hand-interleaved like the PREC 2 body (the compiler otherwise emits all 16 conversions + LDS stores first, each
+    // behind its own vmcnt wait, and the MFMAs after them).  ONE register set: behind MFMA q the load item(s) q of tile it+1
+    // are converted and stored to the other LDS buffer and immediately re-loaded for tile it+2; fragments are double
+    // buffered over the four k16 steps of the tile; the tile barrier is at the end.
+    constexpr int IPM = (NLD + NMF - 1) / NMF;                          // load items behind each MFMA
+    auto body_i = [&](auto P, int it) {
         constexpr int p_ = decltype(P)::value;
         const char* As = smb + p_ * (AH_BYTES + BH_BYTES);
         const char* Bs = As + AH_BYTES;
         char* nxt = smb + (p_ ^ 1) * (AH_BYTES + BH_BYTES);
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) sth_A(nxt, p_ ^ 1, i);
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) sth_B(nxt, p_ ^ 1, i);
-        const int itn = min(it + 1 + NSR, it_last);
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) load_A(p_ ^ 1, i, itn);
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) load_B(p_ ^ 1, i, itn);
-        advance(it + 2 + NSR < it_end ? 1 : 0);
-#pragma unroll
-        for (int s16 = 0; s16 < KT / 16; ++s16) {
-            bf16x8 a[2], b[2];
+        const int itn = min(it + 2, it_last);
+        bf16x8 fa_[2][2], fb_[2][2];
+        auto frags = [&](int s16, int buf) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32, col = wn * 64 + i * 32;
-                if (!A_KM) a[i] = *(const bf16x8*)(As + kc_off(row + l31, LDAH, s16 * 16 + 8 * lh));
-                else a[i] = frag_km(As, LDAH, s16 * 16 + 8 * lh, row);
-                if (!B_KM) b[i] = *(const bf16x8*)(Bs + kc_off(col + l31, LDBH, s16 * 16 + 8 * lh));
-                else b[i] = frag_km(Bs, LDBH, s16 * 16 + 8 * lh, col);
+                if (!A_KM) fa_[buf][i] = *(const bf16x8*)(As + kc_off(row + l31, LDAH, s16 * 16 + 8 * lh));
+                else fa_[buf][i] = frag_km(As, LDAH, s16 * 16 + 8 * lh, row);
+                if (!B_KM) fb_[buf][i] = *(const bf16x8*)(Bs + kc_off(col + l31, LDBH, s16 * 16 + 8 * lh));
+                else fb_[buf][i] = frag_km(Bs, LDBH, s16 * 16 + 8 * lh, col);
             }
+        };
+        frags(0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int s16 = q >> 2, fbuf = s16 & 1;
+            if ((q & 3) == 1 && s16 + 1 < KT / 16) frags(s16 + 1, fbuf ^ 1);
+            acc[(q >> 1) & 1][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[fbuf][(q >> 1) & 1], fb_[fbuf][q & 1], acc[(q >> 1) & 1][q & 1], 0, 0, 0);
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jn], acc[i][jn], 0, 0, 0);
+            for (int u = 0; u < IPM; ++u) {
+                const int item = q * IPM + u;
+                if (item < NVA) { sth_A(nxt, 0, item); load_A(0, item, itn); }
+                else if (item < NLD) { sth_B(nxt, 0, item - NVA); load_B(0, item - NVA, itn); }
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        advance(it + 3 < it_end ? 1 : 0);
         __syncthreads();
     };
     if constexpr (PREC >= 1) {
@@ -735,20 +740,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) load_B(0, i, it_begin);
             advance(it_begin + 1 < it_end ? 1 : 0);
+            if constexpr (NSR == 2) {
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) load_A(1, i, min(it_begin + 1, it_last));
+                for (int i = 0; i < NVA; ++i) load_A(1, i, min(it_begin + 1, it_last));
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) load_B(1, i, min(it_begin + 1, it_last));
-            advance(it_begin + 2 < it_end ? 1 : 0);
+                for (int i = 0; i < NVB; ++i) load_B(1, i, min(it_begin + 1, it_last));
+                advance(it_begin + 2 < it_end ? 1 : 0);
+            }
 #pragma unroll
             for (int i = 0; i < NVA; ++i) sth_A(smb, 0, i);
 #pragma unroll
             for (int i = 0; i < NVB; ++i) sth_B(smb, 0, i);
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) load_A(0, i, min(it_begin + 2, it_last));
+            for (int i = 0; i < NVA; ++i) load_A(0, i, min(it_begin + NSR, it_last));
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) load_B(0, i, min(it_begin + 2, it_last));
-            advance(it_begin + 3 < it_end ? 1 : 0);
+            for (int i = 0; i < NVB; ++i) load_B(0, i, min(it_begin + NSR, it_last));
+            advance(it_begin + NSR + 1 < it_end ? 1 : 0);
         }
         __syncthreads();
         if (stp) stp[2] = clock64();
@@ -758,8 +765,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
                 body_h(std::integral_constant<int, 0>{}, it);
                 if (it + 1 < it_end) body_h(std::integral_constant<int, 1>{}, it + 1);
             } else {
-                body_c(std::integral_constant<int, 0>{}, it);
-                if (it + 1 < it_end) body_c(std::integral_constant<int, 1>{}, it + 1);
+                body_i(std::integral_constant<int, 0>{}, it);
+                if (it + 1 < it_end) body_i(std::integral_constant<int, 1>{}, it + 1);
             }
         }
         if constexpr (PREC == 2) __syncthreads();      // the last tile's fragment prefetch read LDS behind the tile barrier
