@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiscogan_hip.so")
+# DG_LIB (tuning aid): load another build of the same ABI, e.g. for same-box A/B timing of two library versions
+LIB_PATH = os.environ.get("DG_LIB") or os.path.join(_HERE, "libdiscogan_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int
