@@ -1,18 +1,24 @@
+"""Determinism / stability soak: N iterations at 64 px / batch 256 in every dispatch mode of one matrix path; all runs must end
+bitwise identical and finite.    python tools/soak.py [f32|bf16|f32x3] [iterations]"""
 import sys, torch, time
 sys.path.insert(0, ".")
 from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 450
 res = []
-for rep in range(2):
-    for graph in (True, False):
-        tr = DiscoGANTrainer(default_args(), device="cuda", image_size=64, seed=1234, use_graph=graph)
-        A, B = synthetic_batch(256, 64, 1000, "cuda")
-        t0 = time.time()
-        for it in range(450):
-            out = tr.train_iteration(A, B, it, need_losses=(it % 50 == 0))
-        tr.finish(); torch.cuda.synchronize()
-        f = tr.losses_to_floats(tr.train_iteration(A, B, 450))
-        cs = (tr.optim_gen.flat_p.double().sum().item(), tr.optim_dis.flat_p.double().sum().item(), tr.optim_gen.flat_p.abs().max().item())
-        print(f"rep {rep} graph {graph}: {time.time()-t0:.1f}s  checksums {cs}  gen_loss {f['gen_loss']:.6f} dis_loss {f['dis_loss']:.6f}", flush=True)
-        res.append(cs)
+modes = [dict(use_graph=True), dict(use_graph=False), dict(use_graph=False, two_streams=False),
+         dict(use_graph=False, overlap_comm=True, comm="capi", bucket_mb=4.0), dict(use_graph=True, overlap_comm=False, comm="capi")]
+for kw in modes:
+    tr = DiscoGANTrainer(default_args(), device="cuda", image_size=64, seed=1234, mfma_dtype=dtype, **kw)
+    A, B = synthetic_batch(256, 64, 1000, "cuda")
+    t0 = time.time()
+    for it in range(iters):
+        tr.train_iteration(A, B, it)
+    tr.finish(); torch.cuda.synchronize()
+    f = tr.losses_to_floats(tr.train_iteration(A, B, iters))
+    cs = (tr.optim_gen.flat_p.double().sum().item(), tr.optim_dis.flat_p.double().sum().item(), tr.optim_gen.flat_p.abs().max().item())
+    print(f"{dtype} {kw}: {time.time()-t0:.1f}s  checksums {cs}  gen_loss {f['gen_loss']:.6f} dis_loss {f['dis_loss']:.6f}", flush=True)
+    res.append(cs)
+    tr.close()
 assert all(r == res[0] for r in res), "non-deterministic!"
-print("450-iteration soak: all four runs bitwise identical, finite:", all(abs(v) < 1e30 for v in res[0]))
+print(f"{iters}-iteration soak ({dtype}): all {len(modes)} dispatch modes bitwise identical, finite:", all(abs(v) < 1e30 for v in res[0]))
