@@ -89,6 +89,14 @@ SIGNATURES = {
     "dg_dp_barrier": (_i, [_p, _p]),
     "dg_dp_destroy": (_i, []),
     "dg_u8hwc_to_f32chw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dg_adam_step_flat_bf16": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p, _p]),
+    "dg_f32_to_bf16": (_i, [_p, _p, _z, _p]),
+    "dg_bn_act_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
+    "dg_bn_act_bwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
+    "dg_conv_bf16_operands_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_wgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

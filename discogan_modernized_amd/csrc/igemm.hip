@@ -53,6 +53,7 @@ struct IgemmArgs {
     int accumulate;
     int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
     float slope;
+    int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element)
     int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
     int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
     const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
@@ -86,8 +87,14 @@ __device__ float dg_zero16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0
 // fp32 (BASELINE configs[4]: "bf16 MFMA + fp32 BatchNorm accum").  Products of two bf16 values are exact in
 // fp32, so the result equals an fp32 convolution of the rounded operands up to summation order.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int MODE, int WM, int WN, int KT, bool BUF, int PREC>
+// A16 / B16 (PREC 1 only): that operand already is bf16 in HBM (a shadow copy its producer wrote: the Adam kernel for
+// weights, bn_act_fwd / bn_bwd_apply / c3_fwd for activations and gradients) -- half the operand bytes, 8 elements per
+// 16-byte load, no conversion on the way into LDS.  Numerically identical to rounding the fp32 tensor here (same RNE).
+template <int MODE, int WM, int WN, int KT, bool BUF, int PREC, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
+    static_assert(!(A16 || B16) || (BUF && PREC == 1), "bf16 sources exist for the bf16 tile kernels only");
+    constexpr int AEG = A16 ? 8 : 4, BEG = B16 ? 8 : 4;     // elements per 16-byte load granule
+    constexpr int AEB = A16 ? 2 : 4, BEB = B16 ? 2 : 4;     // bytes per element in HBM
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr bool A_KM = (MODE == MODE_WGRAD);
     constexpr bool B_KM = (MODE != MODE_FWD && MODE != MODE_FWD_C3);
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int B_ROWS = B_KM ? KT : BN, B_COLS = B_KM ? BN : KT;
     constexpr int A_FLOATS = A_ROWS * LDA, B_FLOATS = B_ROWS * LDB;
     constexpr int STAGE = A_FLOATS + B_FLOATS;
-    constexpr int A_CQ = A_COLS / 4, B_CQ = B_COLS / 4;
+    constexpr int A_CQ = A_COLS / AEG, B_CQ = B_COLS / BEG;
     constexpr int NVA = A_ROWS * A_CQ / 256, NVB = B_ROWS * B_CQ / 256;
     constexpr int A_RSTEP = 256 / A_CQ, B_RSTEP = 256 / B_CQ;
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     int wg_r = 0, wg_s = 0, wg_c = 0;
     bool wg_colok = true;
     if (MODE == MODE_WGRAD) {
-        const int j = n0 + bcq * 4;
+        const int j = n0 + bcq * BEG;
         wg_colok = j < p.Ng;
         const int tap = wg_colok ? j / Cc : 0;
         wg_c = j - tap * Cc;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         a_ob[i] = 0;
         a_inv[i] = 0;
         if (BUF && MODE == MODE_FWD) {
-            a_ob[i] = (a_pix[i] * Cc + acq * 4) * 4;
+            a_ob[i] = (a_pix[i] * Cc + acq * AEG) * AEB;
             int colok = 0, okmask = 0;             // 4 column bits, replicated into every valid filter row
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(a_x[i] + sx) < (unsigned)W) ? (1 << sx) : 0;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(a_y[i] + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
             a_inv[i] = ~okmask & 0xFFFF;
         } else if (BUF && MODE == MODE_DGRAD_S2) {
-            a_ob[i] = (a_pix[i] * K + acq * 4) * 4;
+            a_ob[i] = (a_pix[i] * K + acq * AEG) * AEB;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ty = t >> 1, tx = t & 1;
@@ -279,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
                 a_inv[i] |= ok ? 0 : (1 << t);
             }
         } else if (BUF && MODE == MODE_WGRAD) {
-            const int kcol = m0 + acq * 4;
-            a_ob[i] = kcol < K ? ((arow0 + i * A_RSTEP) * K + kcol) * 4 : OOR;   // rows >= R run off the end: zeros
+            const int kcol = m0 + acq * AEG;
+            a_ob[i] = kcol < K ? ((arow0 + i * A_RSTEP) * K + kcol) * AEB : OOR;   // rows >= R run off the end: zeros
         }
     }
 #pragma unroll
@@ -288,10 +295,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         b_ob[i] = 0;
         if (BUF && MODE == MODE_FWD) {
             const int k = n0 + brow0 + i * B_RSTEP;
-            b_ob[i] = k < K ? (k * 16 * Cc + bcq * 4) * 4 : OOR;
+            b_ob[i] = k < K ? (k * 16 * Cc + bcq * BEG) * BEB : OOR;
         } else if (BUF && MODE == MODE_DGRAD_S2) {
-            const int col = n0 + bcq * 4;
-            b_ob[i] = col < Cc ? ((brow0 + i * B_RSTEP) * 16 * Cc + col) * 4 : OOR;
+            const int col = n0 + bcq * BEG;
+            b_ob[i] = col < Cc ? ((brow0 + i * B_RSTEP) * 16 * Cc + col) * BEB : OOR;
         }
     }
     auto ld4b = [&](const __amdgpu_buffer_rsrc_t& r, int byte_off) -> f32x4 {
@@ -329,19 +336,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     auto load_A = [&](int set, int i, int it) {
         if (BUF && MODE == MODE_FWD) {
             const int r = fwd_r(), sx = fwd_s();
-            const int soff = ((r * W + sx) * Cc + chunk * KT) * 4;                  // wave-uniform
+            const int soff = ((r * W + sx) * Cc + chunk * KT) * AEB;                // wave-uniform
             ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1));
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
             const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
-            const int soff = ((dyo * Wo + dxo) * K + chunk * KT) * 4;               // wave-uniform
+            const int soff = ((dyo * Wo + dxo) * K + chunk * KT) * AEB;             // wave-uniform
             ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1));
         } else if (BUF && MODE == MODE_DGRAD_PLAIN) {
-            const int kcol = it * KT + acq * 4;
-            ra[set][i] = ld4b(rA, (a_y[i] >= 0 && kcol < K) ? (a_pix[i] * K + kcol) * 4 : OOR);
+            const int kcol = it * KT + acq * AEG;
+            ra[set][i] = ld4b(rA, (a_y[i] >= 0 && kcol < K) ? (a_pix[i] * K + kcol) * AEB : OOR);
         } else if (BUF && MODE == MODE_WGRAD) {
-            ra[set][i] = ld4b(rA, a_ob[i] + it * (KT * 4) * K);
+            ra[set][i] = ld4b(rA, a_ob[i] + it * (KT * AEB) * K);
         } else if (MODE == MODE_FWD) {
             const int r = fwd_r(), s = fwd_s(), c0 = chunk * KT;
             const int iy = a_y[i] + r, ix = a_x[i] + s;
@@ -377,16 +384,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     auto load_B = [&](int set, int i, int it) {
         if (BUF && MODE == MODE_FWD) {
-            rb[set][i] = ld4b(rB, b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * 4);
+            rb[set][i] = ld4b(rB, b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * BEB);
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
             const int sx = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
-            rb[set][i] = ld4b(rB, b_ob[i] + ((chunk * KT * 16 + r * 4 + sx) * Cc) * 4);
+            rb[set][i] = ld4b(rB, b_ob[i] + ((chunk * KT * 16 + r * 4 + sx) * Cc) * BEB);
         } else if (BUF && MODE == MODE_DGRAD_PLAIN) {
-            const int col = n0 + bcq * 4;
+            const int col = n0 + bcq * BEG;
             const int k = it * KT + brow0 + i * B_RSTEP;
-            rb[set][i] = ld4b(rB, (k < K && col < p.Ng) ? (k * p.Ng + col) * 4 : OOR);
+            rb[set][i] = ld4b(rB, (k < K && col < p.Ng) ? (k * p.Ng + col) * BEB : OOR);
         } else if (BUF && MODE == MODE_WGRAD) {
             // reduction row = output pixel mrow = (n, oy, ox) packed (Ho, Wo powers of two).  k4 s2 p1 has
             // H = 2Ho, W = 2Wo, so the input pixel of tap (r, s) is 4*mrow - 2*ox + (r-1)*W + (s-1) and only
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             const int oxv = mrow & (Wo - 1), oyv = (mrow >> lgWo) & (Ho - 1);
             const int bad = (oyv == wg_ybad) | (oxv == wg_xbad) | (mrow >= p.R);
             const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst;
-            rb[set][i] = ld4b(rB, ((pix * Cc + wg_c) * 4) | wg_colbad | -bad);
+            rb[set][i] = ld4b(rB, ((pix * Cc + wg_c) * BEB) | wg_colbad | -bad);
         } else if (MODE == MODE_FWD) {
             const int k = n0 + brow0 + i * B_RSTEP;
             rb[set][i] = ld4(Bg, (long)k * 16 * Cc + (long)((fwd_r() * 4 + fwd_s()) * Cc + chunk * KT) + bcq * 4, k < K);
@@ -584,11 +591,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     auto sth_A = [&](char* stage, int set, int i) {
         const int row = arow0 + i * A_RSTEP;
-        split_store(stage + (A_KM ? (row * LDAH + acq * 4) * 2 : kc_off(row, LDAH, acq * 4)), APL_BYTES, ra[set][i]);
+        char* dst = stage + (A_KM ? (row * LDAH + acq * AEG) * 2 : kc_off(row, LDAH, acq * AEG));
+        if constexpr (A16) *(f32x4*)dst = ra[set][i];            // already bf16: 8 elements, one ds_write_b128
+        else split_store(dst, APL_BYTES, ra[set][i]);
     };
     auto sth_B = [&](char* stage, int set, int i) {
         const int row = brow0 + i * B_RSTEP;
-        split_store(stage + AH_BYTES + (B_KM ? (row * LDBH + bcq * 4) * 2 : kc_off(row, LDBH, bcq * 4)), BPL_BYTES, rb[set][i]);
+        char* dst = stage + AH_BYTES + (B_KM ? (row * LDBH + bcq * BEG) * 2 : kc_off(row, LDBH, bcq * BEG));
+        if constexpr (B16) *(f32x4*)dst = rb[set][i];
+        else split_store(dst, BPL_BYTES, rb[set][i]);
     };
     // transposed fragment read: lane l = 16g + 4q + p supplies row (k0 + q), columns c0 + 16*(g&1) + 4p .. +3 and
     // receives column c0 + (l & 31), rows k0 .. k0+3 (k0 already includes the lane half's 8*(l>>5))
@@ -1115,8 +1126,8 @@ static int choose_splits(int base_wgs, int nIt) {
     return s;
 }
 
-// op: 0 fwd, 1 dgrad, 2 wgrad
-static void make_plan(int op, const ConvGeom& g, Plan* pl) {
+// op: 0 fwd, 1 dgrad, 2 wgrad;  a16 / b16: that operand is a bf16 tensor (only honoured on the bf16 tile path)
+static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 = 0) {
     IgemmArgs& a = pl->a;
     a = IgemmArgs();
     a.N = g.N; a.H = g.H; a.W = g.W; a.Cc = g.C; a.K = g.K;
@@ -1158,10 +1169,11 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl) {
     }
     {   // operand sizes for the buffer-descriptor kernels; 0 = use the 64-bit pointer kernels
         const long xb = (long)g.N * g.H * g.W * g.C * 4, yb = (long)npix * g.K * 4, wb = (long)g.K * 16 * g.C * 4;
-        const long ab = op == 0 ? xb : yb, bb = op == 2 ? xb : wb;
+        const long ab = (op == 0 ? xb : yb) / (a16 ? 2 : 1), bb = (op == 2 ? xb : wb) / (b16 ? 2 : 1);
         const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
         a.bbytes = fits ? (unsigned)bb : 0u;
+        a.a16 = a16; a.b16 = b16;
         a.prec = !fits ? 0 : (want_bf16 ? 1 : (want_x3 ? 2 : 0));
         a.dbg_zero = dg_get_option(DG_OPT_DBG_ZERO);
         if ((want_bf16 || want_x3) && !fits) {            // >= 2 GiB operands: fp32 pointer kernels with their own K-tile
@@ -1208,6 +1220,12 @@ static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
 template <int MODE, int WM, int WN, int KT, int PREC>
 static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    if constexpr (PREC == 1) {
+        // bf16 shadow operands: weights (B of forward / input-grad) alone, or both operands
+        if (a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, true>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (!a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, false, true>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (a.a16 && !a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, false>), dim3(grid), dim3(256), 0, st, a); return; }
+    }
     hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), dim3(grid), dim3(256), 0, st, a);
 }
 
@@ -1352,6 +1370,51 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
     make_plan(2, g, &pl);
     pl.a.A = dy; pl.a.B = x; pl.a.C = dw; pl.a.accumulate = accumulate;
     return run_plan("dg_conv_wgrad", pl, ws, ws_bytes, st);
+}
+
+// ---- bf16 shadow operands (option "bf16" = 1 only) -------------------------------------------------------------------
+// The same three ops with either operand given as a bf16 tensor of the same logical layout.  Producers write the shadow
+// next to the fp32 tensor (dg_adam_step_flat_bf16 for weights, dg_bn_act_fwd_bf16 / dg_bn_act_bwd_bf16 / the c3 forward for
+// activations and gradients); the result is bit-identical to passing the fp32 tensors (same RNE rounding, same order).
+static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b16, float* out, int N, int H, int W, int C, int K,
+                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const char* who = op == 0 ? "dg_conv_fwd_mixed" : (op == 1 ? "dg_conv_dgrad_mixed" : "dg_conv_wgrad_mixed");
+    ConvGeom g;
+    int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(a_in && b_in && out, "%s: null pointer", who);
+    DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no bf16-operand form", who);
+    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 1 || (!a16 && !b16), "%s: bf16 operands need option bf16 = 1", who);
+    if (op == 0) DG_CHECK_ARG(C % 32 == 0, "%s: C=%d must be a multiple of 32", who, C);
+    if (op == 1 && stride == 2) DG_CHECK_ARG(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
+    // 8-element granules must not straddle a row end: the A operand of the plain GEMM forms has rows of K elements
+    if (a16 && op != 0 && K % 8 != 0) return dg_fail(DG_ERR_INVALID, "%s: a bf16 gradient operand needs K %% 8 == 0 (K=%d)", who, K);
+    Plan pl;
+    make_plan(op, g, &pl, a16, b16);
+    if (pl.a.prec != 1 && (a16 || b16)) return dg_fail(DG_ERR_INVALID, "%s: this shape has no bf16 tile kernel", who);
+    pl.a.A = (const float*)a_in; pl.a.B = (const float*)b_in; pl.a.C = out; pl.a.accumulate = accumulate;
+    return run_plan(who, pl, ws, ws_bytes, st);
+}
+extern "C" int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, float* y, int N, int H, int W, int C, int K,
+                                 int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_mixed(0, x, x_bf16, w, w_bf16, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, float* dx, int N, int H, int W, int C, int K,
+                                   int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_mixed(1, dy, dy_bf16, w, w_bf16, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
+                                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_mixed(2, dy, dy_bf16, x, x_bf16, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+// can this (op, shape) take bf16 operands at all?  (host planning aid: 1 = the bf16 tile kernel would be used)
+extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (check_geom("dg_conv_bf16_operands_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
+    if (dg_get_option(DG_OPT_BF16) != 1) return 0;
+    Plan pl;
+    make_plan(op, g, &pl, 1, 1);
+    return pl.a.prec == 1 ? 1 : 0;
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

@@ -195,10 +195,13 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
     }
 }
 
+typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
+// Z16: also write a bf16 (RNE) shadow of z for the bf16 matrix path (the next conv reads it instead of z)
+template <bool Z16>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, long total4,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope) {
+                                                         int act, float slope, __bf16* __restrict__ z16) {
     const int c4n = C >> 2;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % c4n) * 4;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
         *(f32x4*)(z + idx * 4) = o;
+        if (Z16) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector(o, bf16x4_n);
     }
 }
 
@@ -322,11 +326,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
 }
 
+template <bool D16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                            float* __restrict__ dy, long total4, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ coef,
-                                                           int act, float slope) {
+                                                           int act, float slope, __bf16* __restrict__ dy16) {
     const int c4n = C >> 2;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % c4n) * 4;
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o[j] = (float)((double)g[j] * (double)istd[j] * (gg - c1[j] - xhat * c2[j]));
         }
         *(f32x4*)(dy + idx * 4) = o;
+        if (D16) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector(o, bf16x4_n);
     }
 }
 
@@ -429,21 +435,34 @@ extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C,
     return DG_OK;
 }
 
-extern "C" int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
-                             const float* beta, int act, float slope, dg_stream_t stream) {
+static int bn_act_fwd_impl(const float* y, float* z, void* z16, int M, int C, const float* saved, const float* gamma,
+                           const float* beta, int act, float slope, dg_stream_t stream) {
     DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
     DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_fwd: C=%d must be a multiple of 4", C);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
     const long total4 = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
-                       saved, gamma, beta, act, slope);
+    if (z16)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
+                           saved, gamma, beta, act, slope, (__bf16*)z16);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
+                           saved, gamma, beta, act, slope, (__bf16*)nullptr);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
+extern "C" int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
+                             const float* beta, int act, float slope, dg_stream_t stream) {
+    return bn_act_fwd_impl(y, z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
+}
+extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M, int C, const float* saved, const float* gamma,
+                                  const float* beta, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(z_bf16, "dg_bn_act_fwd_bf16: null shadow pointer");
+    return bn_act_fwd_impl(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
+}
 
-extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
-                             const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
-                             int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+static int bn_act_bwd_impl(const float* dz, const float* y, float* dy, void* dy16, int M, int C, const float* saved,
+                           const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
     DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_bwd: C=%d must be a multiple of 4", C);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
@@ -460,10 +479,25 @@ extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, 
                        dgamma, dbeta, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long total4 = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
-                       beta, (const double*)coef, act, slope);
+    if (dy16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
+                           beta, (const double*)coef, act, slope, (__bf16*)dy16);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
+                           beta, (const double*)coef, act, slope, (__bf16*)nullptr);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
+}
+extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
+                             const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                             int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return bn_act_bwd_impl(dz, y, dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+}
+extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16, int M, int C, const float* saved,
+                                  const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                                  int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(dy_bf16, "dg_bn_act_bwd_bf16: null shadow pointer");
+    return bn_act_bwd_impl(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
 }
 
 extern "C" int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t stream) {

@@ -15,10 +15,13 @@ __global__ void adam_advance_kernel(double* state, double lr, double b1, double 
     state[2] = sqrt(1.0 - pow(b2, t));
 }
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// P16: also write a bf16 (RNE) shadow of the updated parameters for the bf16 matrix path (+2 B/param on 28)
+template <bool P16>
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long n,
                                                         const double* __restrict__ state, float b1, float b2, float eps,
-                                                        float wd, float gscale) {
+                                                        float wd, float gscale, __bf16* __restrict__ p16) {
     const float step_size = (float)state[1];
     const float bc2_sqrt = (float)state[2];
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
         *(f32x4*)(p + i * 4) = pp;
         *(f32x4*)(m + i * 4) = mm;
         *(f32x4*)(v + i * 4) = vv;
+        if (P16) *(bf16x4_t*)(p16 + i * 4) = __builtin_convertvector(pp, bf16x4_t);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (long e = n4 * 4; e < n; ++e) {
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
             v[e] = v[e] * b2 + omb2 * gr * gr;
             const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
             p[e] = p[e] - step_size * (m[e] / denom);
+            if (P16) p16[e] = (__bf16)p[e];
         }
     }
 }
@@ -64,8 +69,38 @@ extern "C" int dg_adam_step_flat(float* p, const float* g, float* m, float* v, s
     long grid = ((long)(n / 4) + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(adam_step_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
-                       beta1, beta2, eps, weight_decay, grad_scale);
+    hipLaunchKernelGGL(adam_step_kernel<false>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
+                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)nullptr);
     DG_CHECK_LAUNCH("adam_step");
+    return DG_OK;
+}
+extern "C" int dg_adam_step_flat_bf16(float* p, const float* g, float* m, float* v, size_t n, const double* state, float beta1,
+                                      float beta2, float eps, float weight_decay, float grad_scale, void* p16, dg_stream_t stream) {
+    DG_CHECK_ARG(p && g && m && v && state && p16, "dg_adam_step_flat_bf16: null pointer");
+    if (n == 0) return DG_OK;
+    long grid = ((long)(n / 4) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(adam_step_kernel<true>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
+                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)p16);
+    DG_CHECK_LAUNCH("adam_step_bf16");
+    return DG_OK;
+}
+// fp32 -> bf16 (RNE) copy: initial weight shadow / shadows of tensors that have no fused producer
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        *(bf16x4_t*)(y + i * 4) = __builtin_convertvector(*(const f32x4*)(x + i * 4), bf16x4_t);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long e = n4 * 4; e < n; ++e) y[e] = (__bf16)x[e];
+}
+extern "C" int dg_f32_to_bf16(const float* x, void* y, size_t n, dg_stream_t stream) {
+    DG_CHECK_ARG(x && y, "dg_f32_to_bf16: null pointer");
+    if (n == 0) return DG_OK;
+    long grid = ((long)(n / 4) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, (long)n);
+    DG_CHECK_LAUNCH("f32_to_bf16");
     return DG_OK;
 }

@@ -81,6 +81,7 @@ class ConvFn(Function):
     @staticmethod
     def backward(ctx, dy, dstat=None):
         x, w = ctx.saved_tensors
+        w = ctx.wref                                   # the Parameter object itself (carries the bf16 shadow attribute)
         stride, pad = ctx.sp
         dy = ops.as_nhwc(dy)
         dx = ops.conv_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
@@ -120,6 +121,7 @@ class ConvTransposeFn(Function):
     @staticmethod
     def backward(ctx, dy, dstat=None):
         x, w = ctx.saved_tensors
+        w = ctx.wref
         stride, pad = ctx.sp
         dy = ops.as_nhwc(dy)
         dx = ops.conv_fwd(dy, w, stride, pad) if ctx.needs_input_grad[0] else None

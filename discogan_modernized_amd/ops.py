@@ -176,6 +176,62 @@ def _ws(nbytes, device):
     return t, t.numel() * 4
 
 
+# ---- bf16 shadow operands (mfma_dtype="bf16") -------------------------------------------------------------------
+# A shadow is a bf16 (RNE) copy of an fp32 tensor in the same memory layout, written by the tensor's producer (Adam for
+# weights, the BatchNorm kernels / first conv for activations and gradients).  With SHADOW on, the conv wrappers hand the
+# shadows to dg_conv_*_mixed: half the operand bytes, no conversion in the conv kernel, bit-identical results.
+#   weights    : ``param._dg_bf16`` (a view of optim.Adam's flat bf16 buffer), valid while ``param._version`` is unchanged
+#   activations: side table keyed by the fp32 tensor's storage address; the entry holds the fp32 tensor, so the address
+#                cannot be recycled while the entry lives; the trainer clears the table every iteration.
+SHADOW = False
+_SHADOW_TAB = {}
+
+
+def shadow_clear():
+    _SHADOW_TAB.clear()
+
+
+def shadow_put(t, t16):
+    _SHADOW_TAB[t.data_ptr()] = (t, t16)
+
+
+def shadow_get(t):
+    if not SHADOW:
+        return None
+    e = _SHADOW_TAB.get(t.data_ptr())
+    if e is None or e[0].shape != t.shape or e[0].stride() != t.stride():
+        return None
+    return e[1]
+
+
+def weight_shadow(w):
+    """bf16 shadow of a conv weight Parameter (None when shadows are off or the parameter is not in a flat Adam group)."""
+    if not SHADOW:
+        return None
+    w16 = getattr(w, "_dg_bf16", None)
+    if w16 is None:
+        return None
+    if getattr(w, "_dg_bf16_ver", None) != w._version:          # e.g. load_state_dict wrote the fp32 weights
+        f32_to_bf16(w, w16)
+        w._dg_bf16_ver = w._version
+    return w16
+
+
+def f32_to_bf16(x, out):
+    """out (bf16, same memory layout / numel as x) <- RNE(x)."""
+    assert out.dtype == torch.bfloat16 and out.stride() == x.stride() and out.shape == x.shape
+    _lib.check(_lib.load().dg_f32_to_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "dg_f32_to_bf16")
+    return out
+
+
+def empty_nhwc_bf16(n, c, h, w, device):
+    return torch.empty((n, h, w, c), device=device, dtype=torch.bfloat16).permute(0, 3, 1, 2)
+
+
+def _bf16_ok(op, n, h, wd, c, k, stride, pad):
+    return SHADOW and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) == 1
+
+
 # ---- interior convolutions ------------------------------------------------------------------------------
 def _out_hw(h, w, stride, pad):
     return (h + 2 * pad - 4) // stride + 1, (w + 2 * pad - 4) // stride + 1
@@ -196,8 +252,16 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
+    w16 = x16 = None
+    if rows == 0 and k > 1 and _bf16_ok(0, n, h, wd, c, k, stride, pad):
+        w16, x16 = weight_shadow(w), shadow_get(x)
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
-        if rows > 0:
+        if w16 is not None or x16 is not None:
+            stat = None
+            _lib.check(L.dg_conv_fwd_mixed(_ptr(x16 if x16 is not None else x), int(x16 is not None),
+                                           _ptr(w16 if w16 is not None else w), int(w16 is not None), _ptr(y), n, h, wd, c, k,
+                                           stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_fwd_mixed")
+        elif rows > 0:
             stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
             _lib.check(L.dg_conv_fwd_bnstats(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, _ptr(stat), stat.numel(),
                                              _ptr(ws), wsb, _stream()), "dg_conv_fwd_bnstats")
@@ -223,8 +287,17 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0
+    w16 = dy16 = None
+    if rows == 0 and k > 1 and _bf16_ok(1, n, h, wd, c, k, stride, pad):
+        w16 = weight_shadow(w)
+        dy16 = shadow_get(dy) if k % 8 == 0 else None
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-        if rows > 0:
+        if w16 is not None or dy16 is not None:
+            stat = None
+            _lib.check(L.dg_conv_dgrad_mixed(_ptr(dy16 if dy16 is not None else dy), int(dy16 is not None),
+                                             _ptr(w16 if w16 is not None else w), int(w16 is not None), _ptr(dx), n, h, wd, c, k,
+                                             stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_dgrad_mixed")
+        elif rows > 0:
             stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)
             _lib.check(L.dg_conv_dgrad_bnstats(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, _ptr(stat), stat.numel(),
                                                _ptr(ws), wsb, _stream()), "dg_conv_dgrad_bnstats")
@@ -275,9 +348,18 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
+    dy16 = x16 = None
+    if k > 1 and _bf16_ok(2, n, h, wd, c, k, stride, pad):
+        x16 = shadow_get(x)
+        dy16 = shadow_get(dy) if k % 8 == 0 else None
     with _prof("conv_wgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-        _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
-                                   _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
+        if dy16 is not None or x16 is not None:
+            _lib.check(L.dg_conv_wgrad_mixed(_ptr(dy16 if dy16 is not None else dy), int(dy16 is not None),
+                                             _ptr(x16 if x16 is not None else x), int(x16 is not None), _ptr(dw), n, h, wd, c, k,
+                                             stride, pad, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv_wgrad_mixed")
+        else:
+            _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
+                                       _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
     return dw
 
 
@@ -294,6 +376,8 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
             _hbm("edge_c3_fwd", 4.0 * (x.numel() + y.numel())):
         _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
                    "dg_conv4x4s2_c3_fwd")
+    if SHADOW and k % 8 == 0:
+        shadow_put(y, f32_to_bf16(y, empty_nhwc_bf16(n, k, h // 2, wd // 2, x.device)))
     return y
 
 
@@ -365,6 +449,13 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     y = as_nhwc(y)
     n, c, h, w = y.shape
     z = empty_nhwc(n, c, h, w, y.device)
+    if SHADOW and c % 8 == 0:
+        z16 = empty_nhwc_bf16(n, c, h, w, y.device)
+        with _hbm("bn_apply", 10.0 * n * h * w * c):
+            _lib.check(_lib.load().dg_bn_act_fwd_bf16(_ptr(y), _ptr(z), _ptr(z16), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+                                                      act, slope, _stream()), "dg_bn_act_fwd_bf16")
+        shadow_put(z, z16)
+        return z
     with _hbm("bn_apply", 8.0 * n * h * w * c):
         _lib.check(_lib.load().dg_bn_act_fwd(_ptr(y), _ptr(z), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
                                              act, slope, _stream()), "dg_bn_act_fwd")
@@ -387,6 +478,13 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
         dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
+    if SHADOW and c % 8 == 0:
+        dy16 = empty_nhwc_bf16(n, c, h, w, y.device)
+        with _hbm("bn_backward", 22.0 * m * c):
+            _lib.check(L.dg_bn_act_bwd_bf16(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy16), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act,
+                                            slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_bf16")
+        shadow_put(dy, dy16)
+        return dy, dgamma, dbeta
     with _hbm("bn_backward", 20.0 * m * c):
         _lib.check(L.dg_bn_act_bwd(_ptr(dz), _ptr(y), _ptr(dy), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act, slope,
                                    _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd")
@@ -541,7 +639,12 @@ def adam_advance(state, lr, beta1, beta2):
     _lib.check(_lib.load().dg_adam_advance(_ptr(state), lr, beta1, beta2, _stream()), "dg_adam_advance")
 
 
-def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0, p16=None):
+    if p16 is not None:
+        with _hbm("adam", 30.0 * p.numel()):
+            _lib.check(_lib.load().dg_adam_step_flat_bf16(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2,
+                                                          eps, weight_decay, grad_scale, _ptr(p16), _stream()), "dg_adam_step_flat_bf16")
+        return
     with _hbm("adam", 28.0 * p.numel()):
         _lib.check(_lib.load().dg_adam_step_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1,
                                                  beta2,

@@ -48,6 +48,17 @@ class Adam:
                 p._dg_flat_grad = gview
                 p.grad = gview
 
+    def enable_bf16_shadow(self):
+        """Keep a bf16 (RNE) shadow of every parameter for the bf16 matrix path: one flat bf16 buffer, refreshed by the
+        Adam kernel itself (+2 B/param), exposed as ``param._dg_bf16`` views with the parameter's own memory layout."""
+        if getattr(self, "flat_p16", None) is not None:
+            return
+        self.flat_p16 = torch.empty(self.numel, device=self.flat_p.device, dtype=torch.bfloat16)
+        ops.f32_to_bf16(self.flat_p, self.flat_p16)
+        for p, off in zip(self.params, self.offsets):
+            p._dg_bf16 = self.flat_p16[off:off + p.numel()].as_strided(p.shape, p.stride())
+            p._dg_bf16_ver = p._version
+
     # -- torch.optim.Optimizer surface used by the reference loop ------------------------------------
     def zero_grad(self, set_to_none: bool = True):
         self.flat_g.zero_()
@@ -87,10 +98,11 @@ class Adam:
         g = self.param_groups[0]
         self._sync_foreign_grads()
         ops.adam_advance(self.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+        p16 = getattr(self, "flat_p16", None)
         for b, e in (active if active is not None else [(0, self.numel)]):
             ops.adam_step_flat(self.flat_p[b:e], self.flat_g[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], self.state,
                                float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                               float(grad_scale))
+                               float(grad_scale), p16=None if p16 is None else p16[b:e])
 
     def state_dict(self):
         return dict(step=self.state[0:1].clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

@@ -113,6 +113,11 @@ class DiscoGANTrainer:
         if mfma_dtype not in ("f32", "bf16", "f32x3"):
             raise ValueError("mfma_dtype must be 'f32', 'bf16' or 'f32x3'")
         self.mfma_dtype = mfma_dtype
+        # bf16 path: the conv kernels read bf16 SHADOWS of their operands written by the producers (ops.SHADOW)
+        self.bf16_shadow = mfma_dtype == "bf16"
+        if self.bf16_shadow:
+            self.optim_gen.enable_bf16_shadow()
+            self.optim_dis.enable_bf16_shadow()
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -344,12 +349,16 @@ class DiscoGANTrainer:
         from . import _lib as _l
         if self.mfma_dtype != "f32":
             _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 2)
+        _ops.SHADOW = self.bf16_shadow
+        _ops.shadow_clear()
         try:
             out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
+            _ops.SHADOW = False
+            _ops.shadow_clear()
             if self.mfma_dtype != "f32":
                 _l.set_option("bf16", 0)          # the library default stays exact fp32 for everyone else
         if self.skip_dead_work and not dstep:
@@ -591,9 +600,10 @@ class _GradBuckets:
             if active is None or any(lo <= b["begin"] and b["end"] <= hi for lo, hi in active):
                 g = opt.param_groups[0]
                 from . import ops
+                p16 = getattr(opt, "flat_p16", None)
                 ops.adam_step_flat(opt.flat_p[sl], opt.flat_g[sl], opt.exp_avg[sl], opt.exp_avg_sq[sl], opt.state,
                                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                   float(scale))
+                                   float(scale), p16=None if p16 is None else p16[sl])
         if early:
             self.launched += 1
 

@@ -253,6 +253,29 @@ int dg_dp_destroy(void);
  * bgr != 0 swaps the channel order (cv2.imread-style BGR sources).  H*W must be a multiple of 4. */
 int dg_u8hwc_to_f32chw(const uint8_t* src, float* dst, int N, int H, int W, int bgr, dg_stream_t s);
 
+/* ---- bf16 shadow operands for the bf16 matrix path (option "bf16" = 1; BASELINE configs[4]) ---------------------
+ * A shadow is a bf16 (RNE) copy of an fp32 tensor with the same logical layout, written by the tensor's PRODUCER so that
+ * the conv kernels read half the operand bytes and convert nothing: dg_adam_step_flat_bf16 (weights, +2 B/param),
+ * dg_bn_act_fwd_bf16 / dg_bn_act_bwd_bf16 (activations / gradients: +2 B/element on passes of 8 / 12 B/element),
+ * dg_f32_to_bf16 (initial weight shadow; the first layer's output).  The *_mixed convolutions take either operand as fp32 (flag 0) or bf16 (flag 1)
+ * and return bit-identical results; dg_conv_bf16_operands_ok tells whether a shape runs on the bf16 tile kernels at all. */
+int dg_adam_step_flat_bf16(float* p, const float* g, float* m, float* v, size_t n, const double* state,
+                           float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                           void* p_bf16, dg_stream_t s);
+int dg_f32_to_bf16(const float* x, void* y_bf16, size_t n, dg_stream_t s);
+int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M, int C, const float* saved, const float* gamma,
+                       const float* beta, int act, float slope, dg_stream_t stream);
+int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16, int M, int C, const float* saved,
+                       const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                       int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
+int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, float* y, int N, int H, int W, int C, int K,
+                      int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, float* dx, int N, int H, int W, int C, int K,
+                        int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
+                        int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+
 /* ---- layout helpers --------------------------------------------------------------------------- */
 int dg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);
 int dg_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);

@@ -646,3 +646,27 @@ def test_full_batch_iteration_is_finite_and_deterministic():
         assert all(v == v and abs(v) < 1e4 for v in o.values()), o
     assert vals[0][0] == vals[1][0]
     assert torch.equal(vals[0][1], vals[1][1])
+
+
+def test_bf16_shadow_operands_are_bitwise_neutral(monkeypatch):
+    """mfma_dtype="bf16": the conv kernels read bf16 SHADOWS written by the operands' producers (Adam: weights; BatchNorm /
+    first-conv kernels: activations and gradients) instead of rounding the fp32 tensors themselves.  Same RNE rounding of
+    the same values, same summation order: every loss and every weight must be BITWISE what the trainer gives with the
+    shadows switched off, eagerly and under hipGraph replay, also right after load_state_dict rewrote the fp32 weights."""
+    A, B = synthetic_batch(4, 64, 0, DEV)
+    res = []
+    for shadow in (False, True):
+        for graph in (False, True):
+            tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="bf16", use_graph=graph)
+            assert tr.bf16_shadow
+            if not shadow:
+                tr.bf16_shadow = False
+            vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4)]
+            sd = {k: v.clone() for k, v in tr.discriminator_A.state_dict().items()}
+            tr.discriminator_A.load_state_dict(sd)                  # bumps the fp32 weights' version: shadows must refresh
+            vals += [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4, 9)]
+            torch.cuda.synchronize()
+            res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    for r in res[1:]:
+        assert r[0] == res[0][0]
+        assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
