@@ -37,37 +37,7 @@
 #include "dg_common.h"
 #include <type_traits>
 
-enum { MODE_FWD = 0, MODE_DGRAD_S2 = 1, MODE_DGRAD_PLAIN = 2, MODE_WGRAD = 3, MODE_FWD_C3 = 4 };
-
-struct IgemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    float* part;  // split-K slabs (nullptr when splits == 1)
-    int N, H, W, Cc, K;  // conv geometry: x[N,H,W,Cc], K out channels
-    int Ho, Wo, lgHo, lgWo;
-    int stride, pad;
-    int M, Ng, R;  // GEMM rows, cols; R = reduction length in elements (WGRAD: pixels)
-    int nIt, itPerSplit, splits;
-    int tilesM, tilesN;
-    int accumulate;
-    int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
-    float slope;
-    int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element)
-    int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
-    int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
-    const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
-    // fused BatchNorm statistics (FWD / DGRAD_S2): per-tile partial rows [P][3*Ng + 4] =
-    // {count, -, -, -, shift[Ng], sum(y - shift)[Ng], sum((y - shift)^2)[Ng]}; nullptr = off
-    float* stat;
-    int stat_rs;
-    // profiling hook (tools/igemm_stamps.py): per workgroup {wall0, cyc0, cyc after prologue, cyc after K loop,
-    // cyc after the epilogue stores are issued, wall1, XCC/CU id}; nullptr = off
-    long long* stamps;
-    unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
-    int prec;                  // 1: bf16 MFMA operands (option "bf16"; BUF kernels only)
-    int xcd_group;             // workgroups sharing operand-A rows are placed on one XCD (needs tilesM * splits % 8 == 0)
-};
+#include "igemm_args.h"
 
 #define NEG_BIG (-(1 << 28))
 
@@ -1095,7 +1065,10 @@ struct Plan {
     IgemmArgs a;
     size_t ws_bytes;
     int stat_rows;   // partial rows the fused BatchNorm statistics would produce (0: not supported)
+    int dma;         // 1: igemm_dma.hip (both operands bf16 in HBM, LDS-DMA staging, 256 x 256 tile, 512 threads)
 };
+
+int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
     const int cch = (Ng + 127) / 128;
@@ -1107,10 +1080,10 @@ static int reduce_stats_rchunks(long R, int Ng) {
     return (int)rc;
 }
 
-static int choose_splits(int base_wgs, int nIt) {
+static int choose_splits(int base_wgs, int nIt, int dflt_target = 0) {
     int forced = dg_get_option(DG_OPT_SPLITK);
     int target = dg_get_option(DG_OPT_TARGET_WGS);
-    if (target <= 0) target = 512;
+    if (target <= 0) target = dflt_target > 0 ? dflt_target : 512;
     // Split K only when the tile grid cannot even give every CU one workgroup: at >= 256 workgroups the
     // split's extra slab traffic + reduction kernel cost more than the second co-resident workgroup buys
     // (measured on the 64 px layers: 0.157 ms unsplit vs 0.166 ms split-by-2 for M=16384, N=256, K=2048).
@@ -1184,11 +1157,18 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
             else a.nIt = (npix + pl->kt - 1) / pl->kt;
         }
     }
-    const int BM = 64 * pl->wm, BN = 64 * pl->wn;
+    // LDS-DMA kernel (igemm_dma.hip): both operands are bf16 tensors, the 256-wide tile is at least 3/4 used in both
+    // directions, whole 64-deep K-tiles per tap.  One 512-thread workgroup per CU: the split grid aims for 256 workgroups.
+    pl->dma = 0;
+    if (a.prec == 1 && a16 && b16 && dg_get_option(DG_OPT_NO_DMA) == 0 && pl->kt == 64 && a.Ng >= 192 && a.M >= 192 &&
+        g.C % 8 == 0 && g.K % 8 == 0 &&
+        ((pl->mode == MODE_FWD && g.C % 64 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 64 == 0) || pl->mode == MODE_WGRAD))
+        pl->dma = 1;
+    const int BM = pl->dma ? 256 : 64 * pl->wm, BN = pl->dma ? 256 : 64 * pl->wn;
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
     const int base = a.tilesM * a.tilesN * zmul;
-    a.splits = choose_splits(base, a.nIt);
+    a.splits = choose_splits(base, a.nIt, pl->dma ? 256 : 0);
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
     // measured (PMC, MB per launch beyond L2, 64 px layers): forward 83 -> 76, weight-grad 222 -> 90, input-grad with
@@ -1250,6 +1230,10 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         a.part = (float*)ws;
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
+    if (pl.dma) {
+        if (!dg_igemm_dma_launch(pl.mode, a, zmul, st)) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
+        DG_CHECK_LAUNCH(who);
+    } else {
     const int key = a.prec == 1 ? 1000 + pl.mode * 100 + pl.wm * 10 + (pl.kt == 64 ? 1 : 0)
                   : a.prec == 2 ? 2000 + pl.mode * 100 + pl.wm * 10
                                 : pl.mode * 100 + pl.wm * 10 + (pl.kt == 32 ? 1 : 0);
@@ -1276,6 +1260,7 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         default: return dg_fail(DG_ERR_INVALID, "%s: no kernel for mode %d wm %d kt %d", who, pl.mode, pl.wm, pl.kt);
     }
     DG_CHECK_LAUNCH(who);
+    }
     if (a.splits > 1 && a.stat != nullptr) {
         const int rc = pl.stat_rows;
         dim3 grid((a.Ng + 127) / 128, rc);
@@ -1306,7 +1291,14 @@ extern "C" size_t dg_conv_workspace_bytes(int op, int N, int H, int W, int C, in
     if (K == 1) return 0;
     Plan pl;
     make_plan(op, g, &pl);
-    return pl.ws_bytes;
+    size_t ws = pl.ws_bytes;
+    if (dg_get_option(DG_OPT_BF16) == 1) {      // the bf16-operand forms (dg_conv_*_mixed) may plan a different tile / split
+        for (int v = 1; v < 4; ++v) {
+            make_plan(op, g, &pl, v & 1, v >> 1);
+            if (pl.ws_bytes > ws) ws = pl.ws_bytes;
+        }
+    }
+    return ws;
 }
 
 extern "C" int dg_conv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
@@ -1407,14 +1399,15 @@ extern "C" int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, i
                                    int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     return conv_mixed(2, dy, dy_bf16, x, x_bf16, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
-// can this (op, shape) take bf16 operands at all?  (host planning aid: 1 = the bf16 tile kernel would be used)
+// can this (op, shape) take bf16 operands at all?  (host planning aid: 0 = no, 1 = the register-staged bf16 tile kernel,
+// 2 = with BOTH operands bf16 the LDS-DMA kernel of igemm_dma.hip runs)
 extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_bf16_operands_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
     if (dg_get_option(DG_OPT_BF16) != 1) return 0;
     Plan pl;
     make_plan(op, g, &pl, 1, 1);
-    return pl.a.prec == 1 ? 1 : 0;
+    return pl.a.prec == 1 ? (pl.dma ? 2 : 1) : 0;
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

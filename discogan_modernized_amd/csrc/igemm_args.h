@@ -1,0 +1,37 @@
+// Arguments shared by the implicit-GEMM conv kernels (igemm.hip: register-staged fp32 / bf16 / f32x3 tiles;
+// igemm_dma.hip: bf16 operands staged by LDS-DMA).  Internal; the public ABI is include/discogan_hip.h.
+#pragma once
+#include "dg_common.h"
+
+enum { MODE_FWD = 0, MODE_DGRAD_S2 = 1, MODE_DGRAD_PLAIN = 2, MODE_WGRAD = 3, MODE_FWD_C3 = 4 };
+
+struct IgemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    float* part;  // split-K slabs (nullptr when splits == 1)
+    int N, H, W, Cc, K;  // conv geometry: x[N,H,W,Cc], K out channels
+    int Ho, Wo, lgHo, lgWo;
+    int stride, pad;
+    int M, Ng, R;  // GEMM rows, cols; R = reduction length in elements (WGRAD: pixels)
+    int nIt, itPerSplit, splits;
+    int tilesM, tilesN;
+    int accumulate;
+    int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
+    float slope;
+    int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element)
+    int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
+    int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
+    const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
+    // fused BatchNorm statistics (FWD / DGRAD_S2): per-tile partial rows [P][3*Ng + 4] =
+    // {count, -, -, -, shift[Ng], sum(y - shift)[Ng], sum((y - shift)^2)[Ng]}; nullptr = off
+    float* stat;
+    int stat_rs;
+    // profiling hook (tools/igemm_stamps.py): per workgroup {wall0, cyc0, cyc after prologue, cyc after K loop,
+    // cyc after the epilogue stores are issued, wall1, XCC/CU id}; nullptr = off
+    long long* stamps;
+    unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
+    int prec;                  // 1: bf16 MFMA operands (option "bf16"; BUF kernels only)
+    int xcd_group;             // workgroups sharing operand-A rows are placed on one XCD (needs tilesM * splits % 8 == 0)
+};
+

@@ -1,0 +1,429 @@
+// Implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 with BOTH operands staged by LDS-DMA (gfx950).
+//
+// Replaces (reference file:line) the same ops as igemm.hip -- nn.Conv2d(k4,s2,p1) forward / input-grad / weight-grad
+// (model.py:11-31,83-103 via autograd) and nn.ConvTranspose2d(k4,s2,p1) (model.py:118-140) -- for the bf16 matrix path
+// (BASELINE configs[4]) when both operands exist as bf16 tensors in HBM (the shadows their producers write: Adam for
+// weights, the BatchNorm kernels / first conv for activations and gradients).
+//
+// Why a second kernel: the register-staged bf16 tiles of igemm.hip (128x128 block, 64x64 per wave, global -> VGPR ->
+// ds_write) move 1 KB of LDS reads + 0.5 KB of LDS writes per MFMA and 64 B/clk/CU through the vector memory path, and the
+// VGPR -> LDS store path (~80 B/clk/CU) plus the staging instructions bound the loop at ~0.7 PFLOP/s.  Here
+//   * a workgroup is 8 waves (2 x 4) on a 256 x 256 output tile, 128 x 64 per wave (4 x 2 accumulators of 32x32 = 128
+//     registers): 0.75 KB of LDS reads and 0.25 KB of global -> LDS traffic per MFMA;
+//   * operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (one 1-KiB piece per wave-instruction, no VGPRs, no
+//     ds_write, no conversions); the LDS image is lane-linear per piece, so the bank-conflict-free layouts are XOR
+//     swizzles applied to the per-lane SOURCE address and again in the fragment reads:
+//       k-contiguous images [row][64 k] (128-B rows): 16-B granule g of row r sits in slot g ^ ((r >> 1) & 7)
+//           -> the 16 lanes of a ds_read_b128 group hit 16 different 16-B slots of the 256-B bank row;
+//       reduction-major images [64 k][cols] (rows of 256 or 512 B): granule gc of row k sits in slot gc ^ ((k & 3) << 2)
+//           -> the four rows of a ds_read_b64_tr_b16 block hit four different 64-B bank segments;
+//   * padding / ragged rows are out-of-range buffer offsets (the DMA then writes zeros), exactly as in igemm.hip;
+//   * two LDS stages (2 x 64 KB), one workgroup per CU, ONE barrier per K-tile placed 8 MFMAs before the end of the tile
+//     (igemm.hip's pipeline): behind it the first fragments of tile t+1 are fetched and the DMA of tile t+2 starts into
+//     the stage tile t just vacated, so a tile's DMA has a whole K-tile (32 MFMAs per wave, two waves per SIMD) to land;
+//     the only vmcnt wait is the one in front of that barrier.
+// Epilogue, split-K slabs and the blockIdx -> tile orders are those of igemm.hip.
+#include "igemm_args.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+#define DG_NEG_BIG (-(1 << 28))
+
+template <int MODE, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_kernel(const IgemmArgs p) {
+    static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
+    constexpr int NW = WM * WN;
+    constexpr int FM = 4, FN = 2;                       // 32x32 accumulator blocks per wave: 128 x 64
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN, KT = 64;
+    constexpr bool A_KM = MODE == MODE_WGRAD;           // operand image is reduction-major ([k][rows])
+    constexpr bool B_KM = MODE != MODE_FWD;
+    constexpr int A_BYTES = BM * KT * 2, B_BYTES = BN * KT * 2;
+    constexpr int NPA = A_BYTES / 1024 / NW, NPB = B_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave and tile
+    static_assert(NPA * NW * 1024 == A_BYTES && NPB * NW * 1024 == B_BYTES, "pieces must divide over the waves");
+    constexpr int NPC = NPA + NPB;
+    constexpr int NTAIL = NPC / 2, NHEAD = NPC - NTAIL;  // pieces issued behind the tile barrier / at the head of the next tile
+    constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);   // [A stage 0][A stage 1][B stage 0][B stage 1]
+    constexpr int EPI_BYTES = NW * 32 * 68 * 4;
+    static_assert(EPI_BYTES <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long* const stp = (p.stamps != nullptr && tid == 0) ? p.stamps + (long)blockIdx.x * 8 : nullptr;
+    if (stp) {
+        stp[0] = wall_clock64();
+        stp[1] = clock64();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stp[6] = ((long long)xcc << 32) | hwid;
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- blockIdx -> (tile, parity, split): the three orders of igemm.hip -------------------------------------
+    int bid = blockIdx.x;
+    int tn, tm, parity = 0, split;
+    if (p.xcd_group == 2) {
+        const int G = p.tilesM;
+        tm = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = rest & 3;
+            rest >>= 2;
+        }
+        tn = rest % p.tilesN;
+        split = rest / p.tilesN;
+    } else if (p.xcd_group) {
+        const int G = p.tilesN * (MODE == MODE_DGRAD_S2 ? 4 : 1);
+        int inner = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = inner & 3;
+            inner >>= 2;
+        }
+        tn = inner;
+        tm = rest % p.tilesM;
+        split = rest / p.tilesM;
+    } else {
+        tn = bid % p.tilesN;
+        bid /= p.tilesN;
+        tm = bid % p.tilesM;
+        bid /= p.tilesM;
+        split = bid;
+        if (MODE == MODE_DGRAD_S2) {
+            parity = bid & 3;
+            split = bid >> 2;
+        }
+    }
+    const int ph = parity >> 1, pw = parity & 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int it_begin = split * p.itPerSplit;
+    const int it_end = min(p.nIt, it_begin + p.itPerSplit);
+    const int it_last = it_end - 1;
+
+    const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
+    const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
+
+    constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB tensor: the DMA writes zeros
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (p.dbg_zero & 1) ? 0 : (int)p.abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_zero & 2) ? 0 : (int)p.bbytes, 0x00020000);
+
+    // ---- per-lane source descriptors of this wave's DMA pieces (fixed over the K loop) --------------------------
+    // k-contiguous image: piece pq covers rows 8 pq .. 8 pq + 7; lane L lands in (row 8 pq + L / 8, slot L % 8) and fetches
+    // granule slot ^ swizzle(row).  Reduction-major image of NC columns: GR = NC / 8 granules per row, piece pq covers
+    // k rows RP pq .. RP pq + RP - 1 (RP = 64 / GR); lane L lands in (k row RP pq + L / GR, slot L % GR).
+    int a_ob[NPA], a_inv[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int pq = wave * NPA + i;
+        a_ob[i] = 0;
+        a_inv[i] = 0;
+        if (!A_KM) {
+            const int row = pq * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            if (MODE == MODE_FWD) {
+                a_inv[i] = 0xFFFF;
+                if (m < p.M) {
+                    const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                    const int ay = oy * p.stride - p.pad, ax = ox * p.stride - p.pad;
+                    a_ob[i] = (((n * H + ay) * W + ax) * Cc + g * 8) * 2;
+                    int colok = 0, okmask = 0;
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(ax + sx) < (unsigned)W) ? (1 << sx) : 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(ay + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
+                    a_inv[i] = ~okmask & 0xFFFF;
+                }
+            } else {   // DGRAD_S2
+                a_inv[i] = 0xF;
+                if (m < p.M) {
+                    const int bx = m & (Wo - 1), ay = (m >> lgWo) & (Ho - 1);
+                    a_ob[i] = (m * K + g * 8) * 2;
+                    a_inv[i] = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int ty = t >> 1, tx = t & 1;
+                        const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+                        const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+                        const bool ok = (unsigned)(ay + dyo) < (unsigned)Ho && (unsigned)(bx + dxo) < (unsigned)Wo;
+                        a_inv[i] |= ok ? 0 : (1 << t);
+                    }
+                }
+            }
+        } else {       // WGRAD: rows = reduction pixels, columns = out channels m0 .. m0 + BM - 1 of dy[pixel][K]
+            constexpr int GR = BM / 8, RP = 64 / GR;
+            const int krow = pq * RP + lane / GR;
+            const int gc = (lane % GR) ^ ((krow & 3) << 2);
+            const int col = m0 + gc * 8;
+            a_ob[i] = col < K ? (krow * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the tensor: zeros
+        }
+    }
+    int b_ob[NPB];
+    // WGRAD: the columns of B are (tap, c) of im2col(x); everything about the column is fixed per lane and piece
+    int wg_c[NPB], wg_cst[NPB], wg_ybad[NPB], wg_xbad[NPB], wg_colbad[NPB], wg_krow[NPB];
+    const bool wg_s2 = p.stride == 2;
+    const int wg_lpm = wg_s2 ? 2 : 4, wg_pxm = wg_s2 ? -1 : 0;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int pq = wave * NPB + i;
+        b_ob[i] = 0;
+        wg_c[i] = wg_cst[i] = wg_colbad[i] = wg_krow[i] = 0;
+        wg_ybad[i] = wg_xbad[i] = -1;
+        if (MODE == MODE_FWD) {
+            const int row = pq * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const int k = n0 + row;
+            b_ob[i] = k < K ? (k * 16 * Cc + g * 8) * 2 : OOR;
+        } else {
+            constexpr int GR = BN / 8, RP = 64 / GR;
+            const int krow = pq * RP + lane / GR;
+            const int gc = (lane % GR) ^ ((krow & 3) << 2);
+            const int col = n0 + gc * 8;
+            if (MODE == MODE_DGRAD_S2) {
+                b_ob[i] = col < Cc ? (krow * 16 * Cc + col) * 2 : OOR;
+            } else {
+                const bool colok = col < p.Ng;
+                const int tap = colok ? col / Cc : 0;
+                const int r = tap >> 2, s = tap & 3;
+                wg_c[i] = col - tap * Cc;
+                wg_cst[i] = wg_s2 ? (r - 1) * W + (s - 1) : r * 4 + s;
+                wg_ybad[i] = !wg_s2 ? -1 : (r == 0 ? 0 : (r == 3 ? Ho - 1 : -1));
+                wg_xbad[i] = !wg_s2 ? -1 : (s == 0 ? 0 : (s == 3 ? Wo - 1 : -1));
+                wg_colbad[i] = colok ? 0 : -1;
+                wg_krow[i] = krow;
+            }
+        }
+    }
+
+    // ---- DMA-side K-iteration state (wave-uniform): the tile the NEXT piece belongs to ----------------------------
+    // FWD walks the reduction channel-chunk major with the 16 taps inner in the order r, s in (0, 2, 1, 3) (igemm.hip);
+    // DGRAD_S2 chunk major with the 2x2 taps of the parity class inner; WGRAD walks pixel tiles.
+    int dt = it_begin, tap = 0, chunk = 0;
+    if (MODE == MODE_FWD) {
+        chunk = it_begin >> 4;
+        tap = it_begin & 15;
+    } else if (MODE == MODE_DGRAD_S2) {
+        chunk = it_begin >> 2;
+        tap = it_begin & 3;
+    }
+    auto advance = [&]() {                       // next tile, clamped to the last one (re-loaded, never used)
+        const int go = dt + 1 < it_end ? 1 : 0;
+        dt += go;
+        if (MODE == MODE_FWD) {
+            tap += go;
+            const int wrap = (tap == 16) ? 1 : 0;
+            tap = wrap ? 0 : tap;
+            chunk += wrap;
+        } else if (MODE == MODE_DGRAD_S2) {
+            tap += go;
+            const int wrap = (tap == 4) ? 1 : 0;
+            tap = wrap ? 0 : tap;
+            chunk += wrap;
+        }
+    };
+    auto fwd_r = [&]() { const int a = tap >> 2; return ((a & 1) << 1) | (a >> 1); };
+    auto fwd_s = [&]() { const int b = tap & 3; return ((b & 1) << 1) | (b >> 1); };
+
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int lds_off, int voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)(smem + lds_off), 16, voff, 0, 0, 0);
+    };
+    // piece k (0 .. NPC-1: A pieces first) of tile `dt` into LDS stage `stage`
+    auto issue = [&](int stage, int k) {
+        if (k < NPA) {
+            const int i = k;
+            const int lds_off = stage * A_BYTES + (wave * NPA + i) * 1024;
+            int voff;
+            if (MODE == MODE_FWD) {
+                const int r = fwd_r(), sx = fwd_s();
+                const int soff = ((r * W + sx) * Cc + chunk * KT) * 2;                 // wave-uniform
+                voff = (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1);
+            } else if (MODE == MODE_DGRAD_S2) {
+                const int ty = tap >> 1, tx = tap & 1;
+                const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+                const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+                const int soff = ((dyo * Wo + dxo) * K + chunk * KT) * 2;
+                voff = (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1);
+            } else {
+                voff = a_ob[i] + dt * (KT * 2) * K;
+            }
+            dma(rA, lds_off, voff);
+        } else {
+            const int i = k - NPA;
+            const int lds_off = 2 * A_BYTES + stage * B_BYTES + (wave * NPB + i) * 1024;
+            int voff;
+            if (MODE == MODE_FWD) {
+                voff = b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * 2;
+            } else if (MODE == MODE_DGRAD_S2) {
+                const int ty = tap >> 1, tx = tap & 1;
+                const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+                const int sx = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+                voff = b_ob[i] + ((chunk * KT * 16 + r * 4 + sx) * Cc) * 2;
+            } else {
+                // reduction row = output pixel mrow = (n, oy, ox) packed; see igemm.hip load_B (WGRAD)
+                const int mrow = dt * KT + wg_krow[i];
+                const int oxv = mrow & (Wo - 1), oyv = (mrow >> lgWo) & (Ho - 1);
+                const int bad = (oyv == wg_ybad[i]) | (oxv == wg_xbad[i]) | (mrow >= p.R);
+                const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst[i];
+                voff = ((pix * Cc + wg_c[i]) * 2) | wg_colbad[i] | -bad;
+            }
+            dma(rB, lds_off, voff);
+        }
+    };
+
+    // ---- fragment reads -------------------------------------------------------------------------------------------
+    const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    auto frag_kc = [&](const char* img, int row, int g) -> bf16x8 {
+        return *(const bf16x8*)(img + row * 128 + ((g ^ ((row >> 1) & 7)) << 4));
+    };
+    // transposed read (igemm.hip frag_km) from the swizzled reduction-major image; rowb = bytes per k row
+    auto frag_km = [&](const char* img, int rowb, int k0, int c0) -> bf16x8 {
+        const int kr = k0 + tr_q, col = c0 + tr_c;
+        const char* p0 = img + kr * rowb + ((((col >> 3) ^ ((kr & 3) << 2))) << 4) + (col & 7) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * rowb));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 fa[2][FM], fb[2][FN];
+    auto fetch = [&](int stage, int s, int set) {        // the fragments of k16 step s of the tile in `stage`
+        const char* As = smem + stage * A_BYTES;
+        const char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = wm * (32 * FM) + i * 32;
+            if (!A_KM) fa[set][i] = frag_kc(As, row + l31, 2 * s + lh);
+            else fa[set][i] = frag_km(As, BM * 2, s * 16 + 8 * lh, row);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int col = wn * (32 * FN) + j * 32;
+            if (!B_KM) fb[set][j] = frag_kc(Bs, col + l31, 2 * s + lh);
+            else fb[set][j] = frag_km(Bs, BN * 2, s * 16 + 8 * lh, col);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: tile 0 entirely, the first half of tile 1 --------------------------------------------------------
+    if (it_begin < it_end) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) issue(0, k);
+        advance();
+#pragma unroll
+        for (int k = 0; k < NTAIL; ++k) issue(1, k);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTAIL) : "memory");      // tile 0 has landed (this wave's pieces)
+    }
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[2] = clock64();
+    fetch(0, 0, 0);
+
+    // ---- one K-tile (32 MFMAs per wave): ST = LDS stage of the current tile ------------------------------------------
+    constexpr int NMF = 4 * FM * FN;                       // 4 k16 steps x 8 accumulator blocks
+    constexpr int PER = FM * FN;
+    constexpr int QB = NMF - PER;                          // the tile barrier comes before MFMA QB (the last k16 step)
+    auto body = [&](auto ST_) {
+        constexpr int ST = decltype(ST_)::value;
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            const int s = q / PER, w = q % PER;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == QB) {
+                // this wave's DMA pieces of tile t+1 have landed and its fragment reads of tile t are complete; behind
+                // the barrier that holds for every wave: tile t+1 may be read, tile t's stage may be overwritten
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fetch(ST ^ 1, 0, 0);
+            }
+            if (w == 1 && s + 1 < 4) fetch(ST, s + 1, (s + 1) & 1);
+            acc[w / FN][w % FN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][w / FN], fb[s & 1][w % FN], acc[w / FN][w % FN], 0, 0, 0);
+            // DMA pieces: the second half of tile t+1 behind the first PER MFMAs, the first half of tile t+2 behind the
+            // last PER (after the barrier: into the stage tile t is leaving)
+            if (q < PER) {
+#pragma unroll
+                for (int k = 0; k < NHEAD; ++k)
+                    if (k * PER / NHEAD == q) issue(ST ^ 1, NTAIL + k);
+                if (q == (NHEAD - 1) * PER / NHEAD) advance();
+            }
+            if (q >= QB) {
+#pragma unroll
+                for (int k = 0; k < NTAIL; ++k)
+                    if (QB + k * PER / NTAIL == q) issue(ST, k);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int it = it_begin; it < it_end; it += 2) {
+        body(std::integral_constant<int, 0>{});
+        if (it + 1 < it_end) body(std::integral_constant<int, 1>{});
+    }
+    // the clamped re-loads of the last tile and the fragment prefetch behind the last barrier still touch LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[3] = clock64();
+
+    // ---- epilogue (igemm.hip): acc[i][jn][r] = row (r&3)+8*(r>>2)+4*lh, col jn*32+l31 of the wave's 32x64 block i,
+    // transposed through a private [32][68] LDS region per wave, float4 stores with 16 lanes per 256-B row segment
+    const bool to_part = p.part != nullptr;
+    float* const eps = (float*)smem + wave * (32 * 68);
+    const int erow = lane >> 4, ec4 = (lane & 15) * 4;
+    const int ncol = n0 + wn * (32 * FN) + ec4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            eps[lr * 68 + l31] = acc[i][0][r];
+            eps[lr * 68 + 32 + l31] = acc[i][1][r];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + erow;
+            f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
+            const int m = m0 + wm * (32 * FM) + i * 32 + row;
+            if (m >= p.M || ncol >= p.Ng) continue;
+            float* dst;
+            if (to_part) {
+                const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m : (long)split * p.M + m;
+                dst = p.part + srow * p.Ng;
+            } else if (MODE == MODE_DGRAD_S2) {
+                const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                dst = p.C + (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc;
+            } else {
+                dst = p.C + (long)m * p.Ng;
+            }
+            dst += ncol;
+            if (!to_part && p.accumulate) v += *(const f32x4*)dst;
+            *(f32x4*)dst = v;
+        }
+    }
+    if (stp) {
+        stp[4] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[5] = wall_clock64();
+        stp[7] = clock64();
+    }
+}
+
+// host: launch the LDS-DMA kernel for a plan made by igemm.hip (mode, args); returns 0 when there is no instantiation
+int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st) {
+    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    switch (mode) {
+        case MODE_FWD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_FWD, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_kernel<MODE_DGRAD_S2, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_WGRAD, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
+        default: return 0;
+    }
+}

@@ -229,7 +229,7 @@ def empty_nhwc_bf16(n, c, h, w, device):
 
 
 def _bf16_ok(op, n, h, wd, c, k, stride, pad):
-    return SHADOW and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) == 1
+    return SHADOW and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) >= 1
 
 
 # ---- interior convolutions ------------------------------------------------------------------------------

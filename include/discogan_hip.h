@@ -258,7 +258,11 @@ int dg_u8hwc_to_f32chw(const uint8_t* src, float* dst, int N, int H, int W, int 
  * the conv kernels read half the operand bytes and convert nothing: dg_adam_step_flat_bf16 (weights, +2 B/param),
  * dg_bn_act_fwd_bf16 / dg_bn_act_bwd_bf16 (activations / gradients: +2 B/element on passes of 8 / 12 B/element),
  * dg_f32_to_bf16 (initial weight shadow; the first layer's output).  The *_mixed convolutions take either operand as fp32 (flag 0) or bf16 (flag 1)
- * and return bit-identical results; dg_conv_bf16_operands_ok tells whether a shape runs on the bf16 tile kernels at all. */
+ * and return the fp32 convolution of the RNE-rounded operands (same summation order per output element whichever operand
+ * form is passed).  With BOTH operands bf16 and a GEMM of at least 192 rows and columns the work goes to the LDS-DMA kernel
+ * (csrc/igemm_dma.hip: 256x256 tile, operand tiles global -> LDS by `buffer_load ... lds`; option "no_dma" 1 keeps the
+ * register-staged tiles).  dg_conv_bf16_operands_ok: 0 = the shape has no bf16 kernel, 1 = register-staged bf16 tiles,
+ * 2 = the LDS-DMA kernel when both operands are bf16. */
 int dg_adam_step_flat_bf16(float* p, const float* g, float* m, float* v, size_t n, const double* state,
                            float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                            void* p_bf16, dg_stream_t s);

@@ -653,20 +653,66 @@ def test_bf16_shadow_operands_are_bitwise_neutral(monkeypatch):
     first-conv kernels: activations and gradients) instead of rounding the fp32 tensors themselves.  Same RNE rounding of
     the same values, same summation order: every loss and every weight must be BITWISE what the trainer gives with the
     shadows switched off, eagerly and under hipGraph replay, also right after load_state_dict rewrote the fp32 weights."""
+    from discogan_modernized_amd import _lib
     A, B = synthetic_batch(4, 64, 0, DEV)
     res = []
-    for shadow in (False, True):
-        for graph in (False, True):
-            tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="bf16", use_graph=graph)
-            assert tr.bf16_shadow
-            if not shadow:
-                tr.bf16_shadow = False
-            vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4)]
-            sd = {k: v.clone() for k, v in tr.discriminator_A.state_dict().items()}
-            tr.discriminator_A.load_state_dict(sd)                  # bumps the fp32 weights' version: shadows must refresh
-            vals += [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4, 9)]
-            torch.cuda.synchronize()
-            res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    # the LDS-DMA kernel (both operands shadowed, big layers) sums in another order: keep every conv on the register-staged
+    # tiles for the bitwise comparison; test_bf16_lds_dma_step_matches_register_staged covers the other kernel
+    _lib.set_option("no_dma", 1)
+    try:
+        for shadow in (False, True):
+            for graph in (False, True):
+                tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="bf16", use_graph=graph)
+                assert tr.bf16_shadow
+                if not shadow:
+                    tr.bf16_shadow = False
+                vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4)]
+                sd = {k: v.clone() for k, v in tr.discriminator_A.state_dict().items()}
+                tr.discriminator_A.load_state_dict(sd)                  # bumps the fp32 weights' version: shadows must refresh
+                vals += [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(4, 9)]
+                torch.cuda.synchronize()
+                res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))
+    finally:
+        _lib.set_option("no_dma", 0)
     for r in res[1:]:
         assert r[0] == res[0][0]
         assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+
+
+def test_bf16_lds_dma_step_matches_register_staged():
+    """Same bf16 arithmetic, two kernels: with the LDS-DMA conv kernel (default for the big layers) the first iteration's
+    losses and every gradient of the stepped side must agree with the register-staged bf16 tiles at fp32 summation-order
+    tolerance (both multiply exactly the same rounded operands), eagerly and under hipGraph replay."""
+    from discogan_modernized_amd import _lib
+    A, B = synthetic_batch(16, 64, 0, DEV)
+    out = {}
+    for no_dma in (1, 0):
+        _lib.set_option("no_dma", no_dma)
+        try:
+            tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="bf16", use_graph=False)
+            l0 = tr.losses_to_floats(tr.train_iteration(A, B, 0, do_step=False))
+            gd = tr.optim_dis.flat_g.clone()
+            l1 = tr.losses_to_floats(tr.train_iteration(A, B, 1, do_step=False))
+            gg = tr.optim_gen.flat_g.clone()
+            torch.cuda.synchronize()
+            out[no_dma] = (l0, gd, l1, gg)
+        finally:
+            _lib.set_option("no_dma", 0)
+    a, b = out[1], out[0]
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-5 * abs(a[0][k]) + 1e-6, (k, a[0][k], b[0][k])
+        assert abs(a[2][k] - b[2][k]) <= 1e-4 * abs(a[2][k]) + 1e-6, (k, a[2][k], b[2][k])
+    for ga, gb, what in ((a[1], b[1], "D grads"), (a[3], b[3], "G grads")):
+        rel = ((ga - gb).norm() / ga.norm()).item()
+        assert rel < 2e-5, (what, rel)
+    # (the two kernels reduce every output element over the same K-tiles in the same order, so the bits may even be equal:
+    #  what proves that the LDS-DMA kernel ran is the plan, not a difference)
+    _lib.set_option("bf16", 1)
+    try:
+        L = _lib.load()
+        assert L.dg_conv_bf16_operands_ok(0, 16, 16, 16, 128, 256, 2, 1) == 2      # D/G conv 128->256 forward
+        assert L.dg_conv_bf16_operands_ok(1, 16, 8, 8, 256, 512, 2, 1) == 2        # conv 256->512 input-grad
+        assert L.dg_conv_bf16_operands_ok(2, 16, 8, 8, 256, 512, 2, 1) == 2        # ... weight-grad
+        assert L.dg_conv_bf16_operands_ok(0, 16, 32, 32, 64, 128, 2, 1) == 1       # 128 output columns: register-staged tiles
+    finally:
+        _lib.set_option("bf16", 0)

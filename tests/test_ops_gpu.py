@@ -110,6 +110,65 @@ def test_conv_bf16_operands(N, C, K, H):
         _lib.set_option("bf16", 0)
 
 
+def _with_shadow(t):
+    """Register a bf16 (RNE) shadow of t the way the producers do (ops.shadow_put / the Adam-owned weight shadow)."""
+    t16 = torch.empty_like(t, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+    ops.f32_to_bf16(t, t16)
+    ops.shadow_put(t, t16)
+    t._dg_bf16, t._dg_bf16_ver = t16, t._version
+    return t
+
+
+# (N, C, K, H): shapes that reach the LDS-DMA kernel (igemm_dma.hip: both operands bf16 in HBM, GEMM rows and columns >= 192)
+DMA_SHAPES = [
+    (4, 128, 256, 16),     # fwd: one 256x256 tile, split-K 8; wgrad: 8 column tiles
+    (3, 256, 320, 16),     # ragged column tile (320 = 256 + 64), ragged row tile (192); dgrad 4 parity classes, K = 5 chunks
+    (13, 256, 256, 8),     # ragged rows (208) and a ragged reduction in the weight gradient (208 pixels = 3 K-tiles + 16)
+    (2, 512, 512, 32),     # two row tiles, two column tiles
+    (1, 1024, 1024, 32),   # long reduction (256 K-tiles), split-K
+    (9, 192, 448, 16),     # C = 3 chunks of 64 (fwd), K = 7 chunks (dgrad), 576 rows = 2.25 tiles
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", DMA_SHAPES)
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk):
+    """bf16 shadow operands -> igemm_dma.hip (LDS-DMA staging, XOR-swizzled LDS images, 256x256 tile).  bf16 x bf16 products
+    are exact in fp32, so the result must equal the fp64 convolution of the ROUNDED operands at fp32 tolerance -- and agree
+    with the register-staged bf16 tiles (option no_dma) to the same bound."""
+    r = lambda t_: t_.bfloat16().float()
+    x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    yr = TF.conv2d(r(x).double(), r(w).double(), stride=2, padding=1).float()
+    dxr = TF.conv_transpose2d(r(dy).double(), r(w).double(), stride=2, padding=1).float()
+    dwr = torch.nn.grad.conv2d_weight(r(x).double(), w.shape, r(dy).double(), stride=2, padding=1).float()
+    L = _lib.load()
+    _lib.set_option("bf16", 1)
+    _lib.set_option("splitk", splitk)
+    ops.SHADOW = True
+    try:
+        xg, wg, dyg = _with_shadow(nhwc(x)), _with_shadow(krsc(w)), _with_shadow(nhwc(dy))
+        assert L.dg_conv_bf16_operands_ok(0, N, H, H, C, K, 2, 1) == 2 and L.dg_conv_bf16_operands_ok(2, N, H, H, C, K, 2, 1) == 2
+        y = ops.conv_fwd(xg, wg, 2, 1)
+        dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        dw = ops.conv_wgrad(dyg, xg, 2, 1)
+        close(y, yr, what="dma conv fwd")
+        close(dx, dxr, rtol=2e-4, what="dma conv dgrad")
+        close(dw, dwr, rtol=2e-4, what="dma conv wgrad")
+        dw2 = ops.conv_wgrad(dyg, xg, 2, 1, out=dw.clone(), accumulate=True)
+        close(dw2, 2 * dwr, rtol=2e-4, what="dma conv wgrad accumulate")
+        torch.cuda.synchronize()
+        _lib.set_option("no_dma", 1)
+        close(ops.conv_fwd(xg, wg, 2, 1), y, what="register-staged vs dma fwd")
+        close(ops.conv_dgrad(dyg, wg, (H, H), 2, 1), dx, rtol=2e-4, what="register-staged vs dma dgrad")
+        close(ops.conv_wgrad(dyg, xg, 2, 1), dw, rtol=2e-4, what="register-staged vs dma wgrad")
+    finally:
+        ops.SHADOW = False
+        ops.shadow_clear()
+        _lib.set_option("no_dma", 0)
+        _lib.set_option("splitk", 0)
+        _lib.set_option("bf16", 0)
+
+
 @pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100), (3, 128, 100)])
 def test_conv_head_bf16_operands(N, C, K):
     """The 4x4 heads (plain GEMMs: FWD / DGRAD_PLAIN / WGRAD with ragged K = 100) on the bf16 tile kernels."""

@@ -42,12 +42,26 @@ def main():
     ap.add_argument("--target_wgs", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bf16", type=int, default=0)
+    ap.add_argument("--shadow", type=int, default=0, help="with --bf16 1: hand the conv kernels bf16 shadow operands (what the trainer does)")
+    ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
+    ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
     a = ap.parse_args()
     global ITERS
     ITERS = a.iters
     _lib.set_option("bf16", a.bf16)
     _lib.set_option("dbg_zero", a.dbg_zero)
+    _lib.set_option("no_dma", a.no_dma)
+    ops.SHADOW = bool(a.shadow)
+    only = {int(v) for v in a.layers.split(",") if v}
+
+    def shadowed(t):
+        if a.shadow:
+            t16 = torch.empty_like(t, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+            ops.f32_to_bf16(t, t16)
+            ops.shadow_put(t, t16)
+            t._dg_bf16, t._dg_bf16_ver = t16, t._version
+        return t
     _lib.set_option("kt", a.kt)
     _lib.set_option("splitk", a.splitk)
     _lib.set_option("target_wgs", a.target_wgs)
@@ -61,9 +75,12 @@ def main():
     h = S // 2
     for i in range(1, len(ch)):
         C, K, H = ch[i - 1], ch[i], h
-        x = ops.empty_nhwc(N, C, H, H, dev).normal_()
-        w = ops.empty_krsc(K, C, dev).normal_()
-        dy = ops.empty_nhwc(N, K, H // 2, H // 2, dev).normal_()
+        if only and i not in only:
+            h //= 2
+            continue
+        x = shadowed(ops.empty_nhwc(N, C, H, H, dev).normal_())
+        w = shadowed(ops.empty_krsc(K, C, dev).normal_())
+        dy = shadowed(ops.empty_nhwc(N, K, H // 2, H // 2, dev).normal_())
         gf = 2.0 * N * (H // 2) ** 2 * K * C * 16 / 1e9
         t1 = timeit(lambda: ops.conv_fwd(x, w, 2, 1))
         t2 = timeit(lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1))
@@ -72,6 +89,10 @@ def main():
         print(f"conv s2 {C:4d}->{K:4d} @{H:3d} [{amb:7.1f} MB] {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
         tot["fwd"] += t1; tot["dgrad"] += t2; tot["wgrad"] += t3; totf += gf
         h //= 2
+    if only:
+        print(f"interior totals: {totf:.1f} GFLOP each dir | fwd {tot['fwd']:.3f} ms ({totf / max(tot['fwd'], 1e-9):.1f} TF/s) dgrad {tot['dgrad']:.3f} ms ({totf / max(tot['dgrad'], 1e-9):.1f}) wgrad {tot['wgrad']:.3f} ms ({totf / max(tot['wgrad'], 1e-9):.1f})")
+        return
+    ops.SHADOW = False
     # heads
     C = ch[-1]
     for K in (100, 1):
