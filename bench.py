@@ -58,6 +58,8 @@ def parse(argv=None):
     ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="arithmetic of the MAIN run (the JSON's dtype follows it). f32: exact fp32 MFMA (default); bf16: BASELINE "
                          "configs[4] arithmetic; f32x3: fp32-accurate products from three bf16 planes per operand")
+    ap.add_argument("--act_dtype", default="f32", choices=["f32", "bf16"],
+                    help="with --mfma_dtype bf16: feature maps and their gradients STORED in bf16 (fp32 BatchNorm statistics / arithmetic)")
     ap.add_argument("--comm", default="auto", choices=["auto", "capi", "c10d"], help="data-parallel transport (dp.ExchangeGroup)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="data-parallel exchange overlapped with compute (eager dispatch) or behind a replayed hipGraph")
@@ -238,12 +240,13 @@ def cpu_baseline(image_size, batch, budget_s, update_interval=3):
 COMM_NOTE = []
 
 
-def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None):
+def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None, act_dtype=None):
     from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args
     ov = {"auto": None, "on": True, "off": False}[a.overlap] if overlap is None else overlap
     kw = dict(device=dev, image_size=image_size, seed=1234, process_group=pg,
               use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
-              mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov)
+              mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov,
+              act_dtype=act_dtype or (a.act_dtype if (mfma_dtype or a.mfma_dtype) == "bf16" else "f32"))
     want = comm or a.comm
     if pg is None or want == "c10d":
         return DiscoGANTrainer(default_args(), comm=want, **kw)
@@ -380,7 +383,7 @@ def main():
     if world == 1 and not a.no_extra:
         def side(label, image_size, batch, steps, warmup, **kw):
             t0 = time.time()
-            t = make_trainer(a, dev, None, image_size, **{k: v for k, v in kw.items() if k in ("mfma_dtype", "graph", "overlap", "comm")})
+            t = make_trainer(a, dev, None, image_size, **{k: v for k, v in kw.items() if k in ("mfma_dtype", "graph", "overlap", "comm", "act_dtype")})
             x, y = synthetic_batch(batch, image_size, 1000, dev)
             r = measure(a, t, x, y, batch, 1, steps, warmup, roofline=kw.get("roofline", False), image_size=image_size)
             r.pop("_next_iter", None)
@@ -395,10 +398,13 @@ def main():
 
         for other in ("f32", "bf16", "f32x3"):
             if other != a.mfma_dtype:
-                side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True)
+                side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True, act_dtype="f32")
+        if not (a.mfma_dtype == "bf16" and a.act_dtype == "bf16"):
+            side(f"{S}px_bs{N}_bf16_mfma_bf16_activations", S, N, a.steps, a.warmup, mfma_dtype="bf16", act_dtype="bf16", roofline=True)
         if S == 512:
             side("64px_bs256_f32", 64, 256, 30, 9, mfma_dtype="f32", roofline=True)
-            side("64px_bs256_bf16_mfma", 64, 256, 30, 9, mfma_dtype="bf16")
+            side("64px_bs256_bf16_mfma", 64, 256, 30, 9, mfma_dtype="bf16", act_dtype="f32")
+            side("64px_bs256_bf16_mfma_bf16_activations", 64, 256, 30, 9, mfma_dtype="bf16", act_dtype="bf16")
             side("64px_bs256_f32x3_mfma", 64, 256, 30, 9, mfma_dtype="f32x3")
         else:
             side("512px_bs32_f32", 512, 32, 12, 6, mfma_dtype="f32", roofline=True)
@@ -434,7 +440,8 @@ def main():
                     n_gpus=world, steps=a.steps, warmup=head["warmup"], ms_per_step=head["ms_per_step"],
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.mfma_dtype, data="synthetic",
                     config=dict(workload=WORKLOADS[S].format(b=N) + "; D,G,G cycle, fwd+bwd+Adam, dead backward work skipped"
-                                + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)"),
+                                + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)")
+                                + ("; feature maps stored in bf16, fp32 BatchNorm statistics" if (a.mfma_dtype == "bf16" and a.act_dtype == "bf16") else ""),
                                 image_size=S, global_batch=N * world, parallelism=f"dp{world}",
                                 hipgraph=head["hipgraph"], hip_streams=1 if a.single_stream else 2,
                                 allreduce_overlap=head["allreduce_overlap"],

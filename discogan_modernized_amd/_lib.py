@@ -94,8 +94,17 @@ SIGNATURES = {
     "dg_bn_act_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "dg_bn_act_bwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
     "dg_conv_bf16_operands_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_bn_train_stats_t": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
+    "dg_bn_act_fwd_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _f, _p]),
+    "dg_bn_act_bwd_t": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
+    "dg_act_bwd_t": (_i, [_p, _p, _p, _i, _z, _i, _f, _p]),
+    "dg_conv4x4s2_c3_fwd_t": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "dg_conv4x4s2_c3_dgrad_t": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_c3_wgrad_t": (_i, [_p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_fm_fwd_t": (_i, [_p, _p, _i, _i, _z, _p, _p, _p, _z, _p]),
+    "dg_fm_bwd_t": (_i, [_p, _i, _z, _p, _p, _p, _i, _p]),
     "dg_conv_wgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dg_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),

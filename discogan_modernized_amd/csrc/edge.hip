@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
 #define CS_PR (CS_TR + 2)       // computed rows (halo 1)  = 8 = 2 per wave
 #define CS_PC 16                // computed columns (halo 1) = one MFMA M group
 #define CS_LDP 52               // floats per pixel of the P image (48 + 4: the four k-quarters of a wave store to disjoint banks)
+// IN16: dy is bf16 -- a lane's 16 k values of a pixel are 32 contiguous bytes (two 16-byte loads), expanded to fp32 by a
+// shift / a mask per value right in front of the MFMA that takes it
+template <bool IN16>
 __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                   float* __restrict__ dx, int N, int H, int W, int act,
                                                                   int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
         for (int g = 0; g < 2; ++g) {
             const int a = tr * CS_TR - 1 + wave + 4 * g, b = tc * CS_TC - 1 + p;
             const bool ok = t < ntiles && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
-            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + 16 * kq) * 4 : OOR;   // out of range reads 0 = zero padding
+            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + 16 * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < (IN16 ? 2 : 4); ++j)
                 areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 16 * j, 0, 0));
         }
     };
@@ -235,7 +238,17 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int blk = 0; blk < 3; ++blk)
-                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[S][g][s >> 2][s & 3], breg[blk][s], acc[g][blk], 0, 0, 0);
+                {
+                    float av;
+                    if constexpr (IN16) {     // value s of the lane's 16 = bf16 half (s & 1) of dword s / 2
+                        const float fv = areg[S][g][s >> 3][(s >> 1) & 3];     // (element first: a bit_cast applied directly to the vector-element expression read element 0)
+                        const unsigned wv = __float_as_uint(fv);
+                        av = __builtin_bit_cast(float, (s & 1) ? (wv & 0xffff0000u) : (wv << 16));
+                    } else {
+                        av = areg[S][g][s >> 2][s & 3];
+                    }
+                    acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[blk][s], acc[g][blk], 0, 0, 0);
+                }
         __syncthreads();                          // the previous tile's readers of Ps are done
         // C/D layout 16x16: column = lane & 15, pixel = 4*(lane >> 4) + reg
 #pragma unroll
@@ -267,9 +280,20 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
 }
 
 extern "C" size_t dg_c3_dgrad_workspace_bytes(int K) { return K == CD_K ? (size_t)CD_NK * 16 * sizeof(float) : 0; }
+static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                        int act, void* ws, size_t ws_bytes, dg_stream_t stream);
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
                                      int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return c3_dgrad_run(dy_nhwc, 0, w, dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
+}
+extern "C" int dg_conv4x4s2_c3_dgrad_t(const void* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                                       int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return c3_dgrad_run((const float*)dy_nhwc, dy_bf16, w, dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
+}
+static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                        int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_nhwc && w && dx_nchw, "dg_conv4x4s2_c3_dgrad: null pointer");
+    DG_CHECK_ARG(!dy_bf16 || (K == CD_K && dg_get_option(DG_OPT_KT) != 16), "dg_conv4x4s2_c3_dgrad_t: a bf16 dy needs K == 64 (scatter form)");
     DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_dgrad: bad N/K (%d,%d)", N, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_dgrad: H,W must be powers of two");
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_SIGMOID, "dg_conv4x4s2_c3_dgrad: bad act %d", act);
@@ -282,8 +306,12 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
             const long ntiles = (long)N * tiles_r * tiles_c;
             DG_CHECK_ARG(ntiles < (1L << 30), "dg_conv4x4s2_c3_dgrad: too many tiles");
             const int grid = (int)(ntiles < 512 ? ntiles : 512);
-            hipLaunchKernelGGL(c3_dgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
-                               tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
+            if (dy_bf16)
+                hipLaunchKernelGGL(c3_dgrad_scatter_kernel<true>, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
+            else
+                hipLaunchKernelGGL(c3_dgrad_scatter_kernel<false>, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
             DG_CHECK_LAUNCH("c3_dgrad_scatter");
             return DG_OK;
         }
@@ -317,7 +345,10 @@ extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float
 // consecutive channels of one pixel (128 B).
 #define CF_K 64
 #define CF_S 24            // GEMM-k steps of 2
-template <int ACT>
+// OUT16: y is bf16.  The two accumulator blocks then hold the EVEN and the ODD output channels (block nb, column p ->
+// channel 2p + nb), so a lane owns two adjacent channels of a pixel and stores them as one dword: one 128-B store per
+// pixel row instead of two, half the bytes.
+template <int ACT, bool OUT16>
 __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
                                                              long npix, int ngroups, float slope, int xbytes) {
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __rest
 #pragma unroll
         for (int s = 0; s < CF_S; ++s) {
             const int c = s >> 3, r = (s >> 1) & 3, q = 2 * (s & 1) + h;
-            wb[nb][s] = wS[(nb * 32 + p) * 49 + c * 16 + r * 4 + q];
+            wb[nb][s] = wS[(OUT16 ? 2 * p + nb : nb * 32 + p) * 49 + c * 16 + r * 4 + q];
         }
     float a[2][CF_S];
     // image gathers: raw buffer loads, 32-bit byte offsets; an invalid row / column / pixel pushes the offset
@@ -380,6 +411,20 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __rest
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[P][s], wb[1][s], acc1, 0, 0, 0);
         }
         const long pix0 = (long)gcur * 32;
+        if constexpr (OUT16) {
+            typedef __bf16 bf16x2_e __attribute__((ext_vector_type(2)));
+            typedef float f32x2_e __attribute__((ext_vector_type(2)));
+            unsigned* o16 = (unsigned*)((__bf16*)y + (pix0 + h * 4) * CF_K + 2 * p);
+            const bool whole = pix0 + 32 <= npix;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                const f32x2_e pr = {dg_apply_act(acc0[v], ACT, slope), dg_apply_act(acc1[v], ACT, slope)};
+                if (whole || pix0 + h * 4 + i < npix)
+                    o16[i * (CF_K / 2)] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_e));
+            }
+            return;
+        }
         float* o = y + (pix0 + h * 4) * CF_K + p;
         if (pix0 + 32 <= npix) {                  // whole group in range (wave-uniform): straight-line stores
 #pragma unroll
@@ -405,8 +450,9 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __rest
     }
 }
 
-extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int act,
+extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc_v, int y_bf16, int N, int H, int W, int act,
                                      float slope, hipStream_t st) {
+    float* y_nhwc = (float*)y_nhwc_v;
     const int Ho = H / 2, Wo = W / 2;
     const long npix = (long)N * Ho * Wo;
     const long ngroups = (npix + 31) / 32;
@@ -417,15 +463,21 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float*
     long wgs = (ngroups + 31) / 32;
     if (wgs > 4096) wgs = 4096;
     if (wgs < 1) wgs = 1;
-#define CF_LAUNCH(ACT)                                                                                              \
-    { static const hipError_t once = hipFuncSetAttribute((const void*)c3_fwd_mfma_kernel<ACT>,                         \
+#define CF_LAUNCH(ACT, O16)                                                                                          \
+    { static const hipError_t once = hipFuncSetAttribute((const void*)c3_fwd_mfma_kernel<ACT, O16>,                    \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      \
       (void)once; }                                                                                                     \
-    hipLaunchKernelGGL(c3_fwd_mfma_kernel<ACT>, dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W,     \
+    hipLaunchKernelGGL((c3_fwd_mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W, \
                        dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
-    if (act == DG_ACT_LEAKY) { CF_LAUNCH(DG_ACT_LEAKY); }
-    else if (act == DG_ACT_RELU) { CF_LAUNCH(DG_ACT_RELU); }
-    else { CF_LAUNCH(DG_ACT_NONE); }
+    if (y_bf16) {
+        if (act == DG_ACT_LEAKY) { CF_LAUNCH(DG_ACT_LEAKY, true); }
+        else if (act == DG_ACT_RELU) { CF_LAUNCH(DG_ACT_RELU, true); }
+        else { CF_LAUNCH(DG_ACT_NONE, true); }
+    } else {
+        if (act == DG_ACT_LEAKY) { CF_LAUNCH(DG_ACT_LEAKY, false); }
+        else if (act == DG_ACT_RELU) { CF_LAUNCH(DG_ACT_RELU, false); }
+        else { CF_LAUNCH(DG_ACT_NONE, false); }
+    }
 #undef CF_LAUNCH
     return DG_OK;
 }
@@ -440,7 +492,9 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float*
 // BUF: both tensors < 1 GiB -> raw buffer loads with 32-bit offsets, masked lanes read out of range (= 0).
 // FACT: the dy operand is taken through the backward of the layer's fused LeakyReLU/ReLU on the fly
 //       (dy * act'(act_out), act_out = the saved forward output), instead of a separate act_bwd pass.
-template <bool BUF, bool FACT>
+// IN16 (BUF only): dy and act_out are bf16.  A lane then loads ONE dword = channels (2 l31, 2 l31 + 1) of its pixel, so MFMA
+//       block i holds the channels of parity i: block i, row rho <-> channel 2 rho + i.
+template <bool BUF, bool FACT, bool IN16 = false>
 __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ part, int N, int H, int W, int K,
                                                                int lgHo, int lgWo, long npix, int pix_per_wave,
@@ -477,8 +531,9 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
 
     float fa[2][CW_B][2], fb[2][CW_B][2];
     constexpr int BIG = 0x40000000;
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, BUF ? (int)(npix * K * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, BUF ? (int)(npix * K * 4) : 0, 0x00020000);
+    static_assert(!IN16 || BUF, "bf16 operands: buffer path only");
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, BUF ? (int)(npix * K * (IN16 ? 2 : 4)) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, BUF ? (int)(npix * K * (IN16 ? 2 : 4)) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, BUF ? N * 3 * H * W * 4 : 0, 0x00020000);
     auto bload = [](const __amdgpu_buffer_rsrc_t& r, int off) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
@@ -492,12 +547,26 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
                 const int ox = pp & (Wo - 1), oy = (pp >> lgWo) & (Ho - 1), n = pp >> (lgWo + lgHo);
                 const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
                 const int xb = (n * 3 * H + iy0) * W + ix0;
+                float a0, a1;
+                if constexpr (IN16) {
+                    const int aoff = pok ? (pp * K + kg * 64 + 2 * l31) * 2 : BIG;
+                    const unsigned wv = __builtin_bit_cast(unsigned, bload(rdy, aoff));
+                    a0 = __builtin_bit_cast(float, wv << 16);
+                    a1 = __builtin_bit_cast(float, wv & 0xffff0000u);
+                    if constexpr (FACT) {
+                        const unsigned ov = __builtin_bit_cast(unsigned, bload(rao, aoff));
+                        a0 = __builtin_bit_cast(float, ov << 16) > 0.f ? a0 : a0 * slope;
+                        a1 = __builtin_bit_cast(float, ov & 0xffff0000u) > 0.f ? a1 : a1 * slope;
+                    }
+                } else {
                 const int aoff = pok ? (pp * K + kg * 64 + l31) * 4 : BIG;
-                float a0 = bload(rdy, aoff), a1 = bload(rdy, aoff + 128);
+                a0 = bload(rdy, aoff);
+                a1 = bload(rdy, aoff + 128);
                 if constexpr (FACT) {
                     const float o0 = bload(rao, aoff), o1 = bload(rao, aoff + 128);
                     a0 = o0 > 0.f ? a0 : a0 * slope;
                     a1 = o1 > 0.f ? a1 : a1 * slope;
+                }
                 }
                 fa[set][st][0] = a0;
                 fa[set][st][1] = a1;
@@ -554,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int k = IN16 ? 2 * rho + i : i * 32 + rho;
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
                 const int j = jn * 32 + l31;
@@ -602,7 +672,15 @@ extern "C" size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K) {
     return (size_t)nb * K * 48 * sizeof(float);
 }
 static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
-                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, int io_bf16 = 0);
+extern "C" int dg_conv4x4s2_c3_wgrad_t(const void* dy_nhwc, const void* act_out_nhwc, int io_bf16, int act, float slope,
+                                       const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
+                                       void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(act == DG_ACT_NONE || ((act == DG_ACT_LEAKY || act == DG_ACT_RELU) && act_out_nhwc),
+                 "dg_conv4x4s2_c3_wgrad_t: act %d needs the saved activation output (LeakyReLU / ReLU only)", act);
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_t", (const float*)dy_nhwc, act == DG_ACT_NONE ? nullptr : (const float*)act_out_nhwc, act,
+                        act == DG_ACT_RELU ? 0.f : slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream, io_bf16);
+}
 extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                                      int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     return c3_wgrad_run("dg_conv4x4s2_c3_wgrad", dy_nhwc, nullptr, DG_ACT_NONE, 0.f, x_nchw, dw, N, H, W, K, accumulate, ws,
@@ -617,7 +695,7 @@ extern "C" int dg_conv4x4s2_c3_wgrad_act(const float* dy_nhwc, const float* act_
                         act == DG_ACT_RELU ? 0.f : slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream);
 }
 static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
-                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, int io_bf16) {
     DG_CHECK_ARG(dy_nhwc && x_nchw && dw, "%s: null pointer", who);
     DG_CHECK_ARG(N >= 1 && K >= 64 && K % 64 == 0, "%s: K=%d must be a multiple of 64", who, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "%s: H,W must be powers of two", who);
@@ -633,7 +711,14 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
 #define CW_LAUNCH(B, F)                                                                                                  \
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
                        K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
-    if (buf && fact) CW_LAUNCH(true, true);
+    if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
+    if (io_bf16 && fact) {
+        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, true, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
+                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+    } else if (io_bf16) {
+        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, false, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
+                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+    } else if (buf && fact) CW_LAUNCH(true, true);
     else if (buf) CW_LAUNCH(true, false);
     else if (fact) CW_LAUNCH(false, true);
     else CW_LAUNCH(false, false);

@@ -818,18 +818,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             const int m = m0 + wm * 64 + i * 32 + row;
             if (m >= p.M || ncol >= p.Ng) continue;
             float* dst;
+            long eoff;              // element offset of the 4 outputs in the output tensor (C or the split-K slabs)
             if (to_part) {
                 const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m
                                                           : (long)split * p.M + m;
-                dst = p.part + srow * p.Ng;
+                dst = p.part;
+                eoff = srow * p.Ng + ncol;
             } else if (MODE == MODE_DGRAD_S2) {
                 const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
-                dst = p.C + (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc;
+                dst = p.C;
+                eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ncol;
             } else {
-                dst = p.C + (long)m * p.Ng;
+                dst = p.C;
+                eoff = (long)m * p.Ng + ncol;
             }
-            dst += ncol;
-            if (!to_part && p.accumulate) v += *(const f32x4*)dst;
+            if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
             if (!to_part) {
                 if (MODE != MODE_FWD_C3 && MODE != MODE_WGRAD && p.bias != nullptr)
                     v += *(const f32x4*)(p.bias + (MODE == MODE_DGRAD_PLAIN ? ncol % Cc : ncol));
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
                     for (int e = 0; e < 4; ++e) v[e] = dg_apply_act(v[e], p.act, p.slope);
                 }
             }
-            *(f32x4*)dst = v;
+            dg_store_out4(dst, eoff, v, (!to_part && MODE != MODE_WGRAD && MODE != MODE_FWD_C3) ? p.out16 : 0);
         }
     }
     if (stp) {
@@ -868,22 +871,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
             for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
-        float* dst;
+        long eoff;
         if (MODE == MODE_DGRAD_S2) {
             const int parity = (int)(row / p.M);
             const int m = (int)(row - (long)parity * p.M);
             const int b = m & (p.Wo - 1), a = (m >> p.lgWo) & (p.Ho - 1), n = m >> (p.lgWo + p.lgHo);
-            dst = p.C + (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c4 * 4;
+            eoff = (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c4 * 4;
         } else {
-            dst = p.C + row * p.Ng + c4 * 4;
+            eoff = row * p.Ng + c4 * 4;
         }
-        if (p.accumulate) s += *(const f32x4*)dst;
+        if (p.accumulate) s += *(const f32x4*)(p.C + eoff);
         if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
         if (p.act != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
         }
-        *(f32x4*)dst = s;
+        dg_store_out4(p.C, eoff, s, p.out16);
     }
 }
 
@@ -910,14 +913,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const IgemmArg
     if (ty == 0 && idx < total4) {
 #pragma unroll
         for (int j = 1; j < 16; ++j) s += red[j][tx];
-        float* dst = p.C + row * p.Ng + c4 * 4;
-        if (p.accumulate) s += *(const f32x4*)dst;
+        const long eoff = row * p.Ng + c4 * 4;
+        if (p.accumulate) s += *(const f32x4*)(p.C + eoff);
         if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
         if (p.act != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
         }
-        *(f32x4*)dst = s;
+        dg_store_out4(p.C, eoff, s, p.out16);
     }
 }
 
@@ -977,52 +980,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArg
 }
 
 // ---- K == 1 head (Discriminator conv8, model.py:35): plain reductions ---------------------------------
-__global__ __launch_bounds__(256) void head1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// XT = float or __bf16: the element type of the activation tensors x / dx (weights, dy and dw stay fp32)
+__device__ __forceinline__ f32x4 dg_ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 dg_ld4(const __bf16* p) { return __builtin_convertvector(*(const dg_bf16x4*)p, f32x4); }
+__device__ __forceinline__ void dg_st4(float* p, const f32x4& v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void dg_st4(__bf16* p, const f32x4& v) { *(dg_bf16x4*)p = __builtin_convertvector(v, dg_bf16x4); }
+template <typename XT>
+__global__ __launch_bounds__(256) void head1_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, int J) {
     __shared__ float red[4];
-    const float* xr = x + (long)blockIdx.x * J;
+    const XT* xr = x + (long)blockIdx.x * J;
     float s = 0.f;
     for (int j = threadIdx.x * 4; j < J; j += 1024) {
-        const f32x4 a = *(const f32x4*)(xr + j), b = *(const f32x4*)(w + j);
+        const f32x4 a = dg_ld4(xr + j), b = *(const f32x4*)(w + j);
         s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
     }
     s = dg_block_sum256(s, red);
     if (threadIdx.x == 0) y[blockIdx.x] = s;
 }
+template <typename XT>
 __global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                          float* __restrict__ dx, int N, int J) {
+                                                          XT* __restrict__ dx, int N, int J) {
     const long total4 = (long)N * (J >> 2);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         const int n = (int)(idx / (J >> 2));
         const int j4 = (int)(idx - (long)n * (J >> 2));
         const float g = dy[n];
         const f32x4 b = *(const f32x4*)(w + j4 * 4);
-        *(f32x4*)(dx + (long)n * J + j4 * 4) = b * g;
+        dg_st4(dx + (long)n * J + j4 * 4, b * g);
     }
 }
 // 16 float4 lanes along J x 16 batch lanes; each batch lane walks n = lane, lane+16, ... (4 loads in flight),
 // fixed-order tree over the batch lanes through LDS (deterministic).
-__global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename XT>
+__global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restrict__ dy, const XT* __restrict__ x,
                                                           float* __restrict__ dw, int N, int J, int accumulate) {
     __shared__ f32x4 red[256];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j4 = blockIdx.x * 16 + tx;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (j4 * 4 < J) {
-        const float* px = x + j4 * 4;
+        const XT* px = x + j4 * 4;
         int n = ty;
         for (; n + 48 < N; n += 64) {
             f32x4 v[4];
             float d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[u] = *(const f32x4*)(px + (long)(n + 16 * u) * J);
+                v[u] = dg_ld4(px + (long)(n + 16 * u) * J);
                 d[u] = dy[n + 16 * u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += v[u] * d[u];
         }
-        for (; n < N; n += 16) s += *(const f32x4*)(px + (long)n * J) * dy[n];
+        for (; n < N; n += 16) s += dg_ld4(px + (long)n * J) * dy[n];
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -1310,7 +1321,7 @@ extern "C" int dg_conv_fwd(const float* x, const float* w, float* y, int N, int 
     hipStream_t st = (hipStream_t)stream;
     if (K == 1) {
         DG_CHECK_ARG(stride == 1, "dg_conv_fwd: K==1 only for the 4x4 head");
-        hipLaunchKernelGGL(head1_fwd_kernel, dim3(N), dim3(256), 0, st, x, w, y, 16 * C);
+        hipLaunchKernelGGL(head1_fwd_kernel<float>, dim3(N), dim3(256), 0, st, x, w, y, 16 * C);
         DG_CHECK_LAUNCH("head1_fwd");
         return DG_OK;
     }
@@ -1333,7 +1344,7 @@ extern "C" int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, 
         const long total4 = (long)N * 4 * C;
         int grid = (int)((total4 + 255) / 256);
         if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(head1_dgrad_kernel, dim3(grid), dim3(256), 0, st, dy, w, dx, N, 16 * C);
+        hipLaunchKernelGGL(head1_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, dy, w, dx, N, 16 * C);
         DG_CHECK_LAUNCH("head1_dgrad");
         return DG_OK;
     }
@@ -1354,7 +1365,7 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
     if (K == 1) {
         DG_CHECK_ARG(stride == 1, "dg_conv_wgrad: K==1 only for the 4x4 head");
         const int J = 16 * C;
-        hipLaunchKernelGGL(head1_wgrad_kernel, dim3((J / 4 + 15) / 16), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
+        hipLaunchKernelGGL(head1_wgrad_kernel<float>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
         DG_CHECK_LAUNCH("head1_wgrad");
         return DG_OK;
     }
@@ -1368,36 +1379,61 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
 // The same three ops with either operand given as a bf16 tensor of the same logical layout.  Producers write the shadow
 // next to the fp32 tensor (dg_adam_step_flat_bf16 for weights, dg_bn_act_fwd_bf16 / dg_bn_act_bwd_bf16 / the c3 forward for
 // activations and gradients); the result is bit-identical to passing the fp32 tensors (same RNE rounding, same order).
-static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b16, float* out, int N, int H, int W, int C, int K,
+static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b16, void* out, int out16, int N, int H, int W, int C, int K,
                       int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     const char* who = op == 0 ? "dg_conv_fwd_mixed" : (op == 1 ? "dg_conv_dgrad_mixed" : "dg_conv_wgrad_mixed");
     ConvGeom g;
     int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
     if (rc) return rc;
     DG_CHECK_ARG(a_in && b_in && out, "%s: null pointer", who);
-    DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no bf16-operand form", who);
-    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 1 || (!a16 && !b16), "%s: bf16 operands need option bf16 = 1", who);
+    if (K == 1) {
+        // the discriminator's 4x4 head (plain reductions): only the ACTIVATION side may be bf16 (x of forward / weight-grad, dx of
+        // input-grad); the [N] vector and the weights are fp32
+        DG_CHECK_ARG(stride == 1, "%s: K==1 only for the 4x4 head", who);
+        const int J = 16 * C;
+        if (op == 0) {
+            DG_CHECK_ARG(!b16 && !out16, "%s: K == 1 head: weights and the [N] output are fp32", who);
+            if (a16) hipLaunchKernelGGL(head1_fwd_kernel<__bf16>, dim3(N), dim3(256), 0, st, (const __bf16*)a_in, (const float*)b_in, (float*)out, J);
+            else hipLaunchKernelGGL(head1_fwd_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, J);
+        } else if (op == 1) {
+            DG_CHECK_ARG(!a16 && !b16, "%s: K == 1 head: dy and the weights are fp32", who);
+            const long total4 = (long)N * 4 * C;
+            int grid = (int)((total4 + 255) / 256);
+            if (grid > 2048) grid = 2048;
+            if (out16) hipLaunchKernelGGL(head1_dgrad_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (__bf16*)out, N, J);
+            else hipLaunchKernelGGL(head1_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, N, J);
+        } else {
+            DG_CHECK_ARG(!a16, "%s: K == 1 head: dy is fp32", who);
+            if (b16) hipLaunchKernelGGL(head1_wgrad_kernel<__bf16>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, (const float*)a_in, (const __bf16*)b_in, (float*)out, N, J, accumulate);
+            else hipLaunchKernelGGL(head1_wgrad_kernel<float>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, N, J, accumulate);
+        }
+        DG_CHECK_LAUNCH(who);
+        return DG_OK;
+    }
+    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 1 || (!a16 && !b16 && !out16), "%s: bf16 operands / outputs need option bf16 = 1", who);
+    DG_CHECK_ARG(!(out16 && op == 2), "%s: the weight gradient is always fp32", who);
     if (op == 0) DG_CHECK_ARG(C % 32 == 0, "%s: C=%d must be a multiple of 32", who, C);
     if (op == 1 && stride == 2) DG_CHECK_ARG(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
     // 8-element granules must not straddle a row end: the A operand of the plain GEMM forms has rows of K elements
     if (a16 && op != 0 && K % 8 != 0) return dg_fail(DG_ERR_INVALID, "%s: a bf16 gradient operand needs K %% 8 == 0 (K=%d)", who, K);
     Plan pl;
     make_plan(op, g, &pl, a16, b16);
-    if (pl.a.prec != 1 && (a16 || b16)) return dg_fail(DG_ERR_INVALID, "%s: this shape has no bf16 tile kernel", who);
-    pl.a.A = (const float*)a_in; pl.a.B = (const float*)b_in; pl.a.C = out; pl.a.accumulate = accumulate;
+    if (pl.a.prec != 1 && (a16 || b16 || out16)) return dg_fail(DG_ERR_INVALID, "%s: this shape has no bf16 tile kernel", who);
+    pl.a.A = (const float*)a_in; pl.a.B = (const float*)b_in; pl.a.C = (float*)out; pl.a.accumulate = accumulate;
+    pl.a.out16 = out16;
     return run_plan(who, pl, ws, ws_bytes, st);
 }
-extern "C" int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, float* y, int N, int H, int W, int C, int K,
+extern "C" int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, void* y, int y_bf16, int N, int H, int W, int C, int K,
                                  int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_mixed(0, x, x_bf16, w, w_bf16, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+    return conv_mixed(0, x, x_bf16, w, w_bf16, y, y_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
 }
-extern "C" int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, float* dx, int N, int H, int W, int C, int K,
+extern "C" int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, int K,
                                    int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_mixed(1, dy, dy_bf16, w, w_bf16, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+    return conv_mixed(1, dy, dy_bf16, w, w_bf16, dx, dx_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
                                    int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_mixed(2, dy, dy_bf16, x, x_bf16, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return conv_mixed(2, dy, dy_bf16, x, x_bf16, dw, 0, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 // can this (op, shape) take bf16 operands at all?  (host planning aid: 0 = no, 1 = the register-staged bf16 tile kernel,
 // 2 = with BOTH operands bf16 the LDS-DMA kernel of igemm_dma.hip runs)
@@ -1533,11 +1569,21 @@ extern "C" int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw
     return dg_conv_wgrad(x, dy, dw, N, 4, 4, Cout, Cin, 1, 0, acc, ws, wsb, s);
 }
 
-extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int act,
+extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int act,
                                      float slope, hipStream_t st);   // edge.hip
+static int c3_fwd_run(const float* x_nchw, const float* w, float* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                      int act, float slope, dg_stream_t stream);
 // ---- 3-channel image side, forward direction (conv1 forward / last-convT input-grad) ----------------
 extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
                                    int act, float slope, dg_stream_t stream) {
+    return c3_fwd_run(x_nchw, w, y_nhwc, 0, N, H, W, K, act, slope, stream);
+}
+extern "C" int dg_conv4x4s2_c3_fwd_t(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                                     int act, float slope, dg_stream_t stream) {
+    return c3_fwd_run(x_nchw, w, (float*)y_nhwc, y_bf16, N, H, W, K, act, slope, stream);
+}
+static int c3_fwd_run(const float* x_nchw, const float* w, float* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                      int act, float slope, dg_stream_t stream) {
     DG_CHECK_ARG(x_nchw && w && y_nhwc, "dg_conv4x4s2_c3_fwd: null pointer");
     DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_fwd: bad N/K (%d,%d)", N, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd: H,W must be powers of two");
@@ -1545,11 +1591,12 @@ extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd: bad act %d", act);
     hipStream_t st = (hipStream_t)stream;
     if (K == 64 && dg_get_option(DG_OPT_KT) != 16 && (long)N * 3 * H * W * 4 < (1L << 30) && (long)N * (H / 2) * (W / 2) < (1L << 30)) {       // streaming per-wave kernel (edge.hip); kt=16 forces the tiled path
-        int rc = dg_c3_fwd_mfma_launch(x_nchw, w, y_nhwc, N, H, W, act, slope, st);
+        int rc = dg_c3_fwd_mfma_launch(x_nchw, w, y_nhwc, y_bf16, N, H, W, act, slope, st);
         if (rc != DG_OK) return rc;
         DG_CHECK_LAUNCH("dg_conv4x4s2_c3_fwd");
         return DG_OK;
     }
+    DG_CHECK_ARG(!y_bf16, "dg_conv4x4s2_c3_fwd_t: a bf16 output needs K == 64 and tensors < 1 GiB (the streaming kernel)");
     IgemmArgs a = IgemmArgs();
     a.A = x_nchw; a.B = w; a.C = y_nhwc;
     a.N = N; a.H = H; a.W = W; a.Cc = 3; a.K = K;

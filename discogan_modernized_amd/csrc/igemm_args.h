@@ -20,6 +20,7 @@ struct IgemmArgs {
     int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
     float slope;
     int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element)
+    int out16;           // the output tensor C is bf16 (RNE of the fp32 accumulators; FWD / DGRAD modes, never the weight gradient)
     int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
     int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)
     const float* bias;   // inference path (BatchNorm folded into the conv): per-output-channel bias added before act; nullptr = none
@@ -35,3 +36,10 @@ struct IgemmArgs {
     int xcd_group;             // workgroups sharing operand-A rows are placed on one XCD (needs tilesM * splits % 8 == 0)
 };
 
+
+typedef __bf16 dg_bf16x4 __attribute__((ext_vector_type(4)));
+// store 4 consecutive outputs: fp32 (16 B) or RNE-rounded bf16 (8 B); `elem` = element offset from the tensor base
+__device__ __forceinline__ void dg_store_out4(float* base, long elem, const f32x4& v, int out16) {
+    if (out16) *(dg_bf16x4*)((__bf16*)base + elem) = __builtin_convertvector(v, dg_bf16x4);
+    else *(f32x4*)(base + elem) = v;
+}

@@ -395,18 +395,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
             const int m = m0 + wm * (32 * FM) + i * 32 + row;
             if (m >= p.M || ncol >= p.Ng) continue;
             float* dst;
+            long eoff;
             if (to_part) {
                 const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m : (long)split * p.M + m;
-                dst = p.part + srow * p.Ng;
+                dst = p.part;
+                eoff = srow * p.Ng + ncol;
             } else if (MODE == MODE_DGRAD_S2) {
                 const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
-                dst = p.C + (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc;
+                dst = p.C;
+                eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ncol;
             } else {
-                dst = p.C + (long)m * p.Ng;
+                dst = p.C;
+                eoff = (long)m * p.Ng + ncol;
             }
-            dst += ncol;
-            if (!to_part && p.accumulate) v += *(const f32x4*)dst;
-            *(f32x4*)dst = v;
+            if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
+            dg_store_out4(dst, eoff, v, (!to_part && MODE != MODE_WGRAD) ? p.out16 : 0);
         }
     }
     if (stp) {

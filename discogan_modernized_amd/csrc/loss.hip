@@ -122,7 +122,14 @@ __global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* __restrict_
 // Feature matching, stage 1: batch-chunk partial sums.  grid = (J/4/256 blocks, nchunks); each thread
 // owns one float4 column and walks its chunk of the batch (coalesced 4 KB rows per block).
 // part layout: [2][nchunks][J]  (0: real, 1: fake)
-__global__ __launch_bounds__(256) void fm_partial_kernel(const float* __restrict__ real, const float* __restrict__ fake, int N,
+// T = float or __bf16: element type of the discriminator features (and of their gradients); sums stay fp32
+typedef __bf16 fm_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 fm_ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 fm_ld4(const __bf16* p) { return __builtin_convertvector(*(const fm_bf16x4*)p, f32x4); }
+__device__ __forceinline__ void fm_st4(float* p, const f32x4& v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void fm_st4(__bf16* p, const f32x4& v) { *(fm_bf16x4*)p = __builtin_convertvector(v, fm_bf16x4); }
+template <typename T>
+__global__ __launch_bounds__(256) void fm_partial_kernel(const T* __restrict__ real, const T* __restrict__ fake, int N,
                                                          long J, int nchunks, float* __restrict__ part) {
     const long j4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (j4 * 4 >= J) return;
@@ -130,8 +137,8 @@ __global__ __launch_bounds__(256) void fm_partial_kernel(const float* __restrict
     const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
     f32x4 sr = {0.f, 0.f, 0.f, 0.f}, sf = {0.f, 0.f, 0.f, 0.f};
     for (int n = n0; n < n1; ++n) {
-        sr += *(const f32x4*)(real + (long)n * J + j4 * 4);
-        sf += *(const f32x4*)(fake + (long)n * J + j4 * 4);
+        sr += fm_ld4(real + (long)n * J + j4 * 4);
+        sf += fm_ld4(fake + (long)n * J + j4 * 4);
     }
     *(f32x4*)(part + (long)blockIdx.y * J + j4 * 4) = sr;
     *(f32x4*)(part + ((long)nchunks + blockIdx.y) * J + j4 * 4) = sf;
@@ -154,8 +161,9 @@ __global__ __launch_bounds__(256) void fm_diff_kernel(const float* __restrict__ 
     }
     block_partial_store(s, dpart);
 }
+template <typename T>
 __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ diff, int N, long J, const float* __restrict__ gout,
-                                                     float* __restrict__ dreal, float* __restrict__ dfake) {
+                                                     T* __restrict__ dreal, T* __restrict__ dfake) {
     // d loss / d real[n][j] = 2*diff[j] / (N*J);  d/d fake = -that
     const float sc = 2.f * gout[0] / ((float)N * (float)J);
     const long j4n = J >> 2;
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ d
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long n = idx / j4n, j4 = idx - n * j4n;
         const f32x4 d = *(const f32x4*)(diff + j4 * 4) * sc;
-        if (dreal) *(f32x4*)(dreal + n * J + j4 * 4) = d;
-        if (dfake) *(f32x4*)(dfake + n * J + j4 * 4) = -d;
+        if (dreal) fm_st4(dreal + n * J + j4 * 4, d);
+        if (dfake) fm_st4(dfake + n * J + j4 * 4, -d);
     }
 }
 
@@ -302,15 +310,26 @@ static int fm_chunks(int N, size_t J) {
 extern "C" size_t dg_fm_workspace_bytes(int N, size_t J) {
     return dg_loss_workspace_bytes() + (size_t)2 * fm_chunks(N, J) * J * sizeof(float);
 }
+extern "C" int dg_fm_fwd_t(const void* real, const void* fake, int io_bf16, int N, size_t J, float* diff, float* loss, void* ws,
+                           size_t ws_bytes, dg_stream_t stream);
 extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss, void* ws,
                          size_t ws_bytes, dg_stream_t stream) {
+    return dg_fm_fwd_t(real, fake, 0, N, J, diff, loss, ws, ws_bytes, stream);
+}
+extern "C" int dg_fm_fwd_t(const void* real, const void* fake, int io_bf16, int N, size_t J, float* diff, float* loss, void* ws,
+                           size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(real && fake && diff && loss && N > 0 && J > 0 && J % 4 == 0, "dg_fm_fwd: bad argument");
     if (!ws || ws_bytes < dg_fm_workspace_bytes(N, J)) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
     const int nch = fm_chunks(N, J);
     double* dpart = (double*)ws;
     float* part = (float*)((char*)ws + dg_loss_workspace_bytes());
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fm_partial_kernel, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, real, fake, N, (long)J, nch, part);
+    if (io_bf16)
+        hipLaunchKernelGGL(fm_partial_kernel<__bf16>, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, (const __bf16*)real,
+                           (const __bf16*)fake, N, (long)J, nch, part);
+    else
+        hipLaunchKernelGGL(fm_partial_kernel<float>, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, (const float*)real,
+                           (const float*)fake, N, (long)J, nch, part);
     DG_CHECK_LAUNCH("fm_partial");
     const int g = loss_grid((long)(J / 4));
     hipLaunchKernelGGL(fm_diff_kernel, dim3(g), dim3(256), 0, st, (const float*)part, N, (long)J, nch, diff, dpart);
@@ -319,14 +338,20 @@ extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, 
     DG_CHECK_LAUNCH("fm_final");
     return DG_OK;
 }
-extern "C" int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t stream) {
+extern "C" int dg_fm_bwd_t(const float* diff, int N, size_t J, const float* gout, void* dreal, void* dfake, int io_bf16, dg_stream_t stream) {
     DG_CHECK_ARG(diff && gout && N > 0 && J > 0 && J % 4 == 0, "dg_fm_bwd: bad argument");
     const long total = (long)(J / 4) * N;
     long g = (total + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(fm_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, dreal, dfake);
+    if (io_bf16)
+        hipLaunchKernelGGL(fm_bwd_kernel<__bf16>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, (__bf16*)dreal, (__bf16*)dfake);
+    else
+        hipLaunchKernelGGL(fm_bwd_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, (float*)dreal, (float*)dfake);
     DG_CHECK_LAUNCH("fm_bwd");
     return DG_OK;
+}
+extern "C" int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t stream) {
+    return dg_fm_bwd_t(diff, N, J, gout, dreal, dfake, 0, stream);
 }
 
 extern "C" int dg_loss_mix_fwd(const float* lossvec, float* out8, int nfm, float rate, int arch, dg_stream_t stream) {

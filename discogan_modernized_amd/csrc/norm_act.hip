@@ -12,15 +12,49 @@
 
 #define BN_U 8     // independent row loads in flight per thread (same-box A/B of the whole iteration: U=2 13.46 ms, 4 13.17, 8 13.13)
 
+// Activation tensors are fp32 or bf16 (bf16 activation storage of the bf16 matrix path: statistics, normalisation and the
+// backward expression stay fp32 / fp64; only what is STORED is rounded, RNE).  Every thread moves 16 bytes per access:
+// V = 4 fp32 or 8 bf16 channels.
+typedef __bf16 bf16x8_n __attribute__((ext_vector_type(8)));
+typedef float f32x8_n __attribute__((ext_vector_type(8)));
+template <typename T> struct BnV;
+template <> struct BnV<float> { static constexpr int V = 4; };
+template <> struct BnV<__bf16> { static constexpr int V = 8; };
+__device__ __forceinline__ void bn_ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *(const f32x4*)p;
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void bn_ld(const __bf16* p, float (&v)[8]) {
+    const f32x8_n t = __builtin_convertvector(*(const bf16x8_n*)p, f32x8_n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = t[j];
+}
+// per-channel fp32 parameters (mean, invstd, gamma, beta): V consecutive channels as 16-byte loads
+template <int V>
+__device__ __forceinline__ void bn_ldp(const float* p, float (&v)[V]) {
+#pragma unroll
+    for (int h = 0; h < V / 4; ++h) {
+        const f32x4 t = *(const f32x4*)(p + 4 * h);
+        v[4 * h] = t[0]; v[4 * h + 1] = t[1]; v[4 * h + 2] = t[2]; v[4 * h + 3] = t[3];
+    }
+}
+__device__ __forceinline__ void bn_st(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void bn_st(__bf16* p, const float (&v)[8]) {
+    f32x8_n t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[j];
+    *(bf16x8_n*)p = __builtin_convertvector(t, bf16x8_n);
+}
+
 __device__ __forceinline__ float bn_norm(float y, float mean, float gs, float beta) { return fmaf(y - mean, gs, beta); }
 
 // Reduction-pass geometry: a 256-thread block is TX float4 lanes along channels x TY = 256/TX row lanes, with
 // TX = the power of two covering C/4 (capped at 64), so every thread is busy for C = 64 as for C = 512.
 // grid = (cchunks, rchunks); each block walks rows r0 + ty + k*TY of its row chunk.
 struct BnGrid { int tx, ty, cchunks, rchunks; };
-static BnGrid bn_grid(int M, int C) {
+static BnGrid bn_grid(int M, int C, int V = 4) {
     BnGrid g;
-    int q = C / 4, tx = 1;
+    int q = C / V, tx = 1;
     while (tx < q && tx < 64) tx <<= 1;
     g.tx = tx;
     g.ty = 256 / tx;
@@ -35,51 +69,72 @@ static BnGrid bn_grid(int M, int C) {
 }
 
 // part layout: [2][rchunks][C]  (0: sum of (y - shift), 1: sum of (y - shift)^2; shift = y[row 0])
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ y, float* __restrict__ part,
                                                                int M, int C, int rchunks, int TX) {
-    __shared__ f32x4 red[2][256];
+    constexpr int V = BnV<T>::V;
+    __shared__ float red[2][256][V];
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int c = (blockIdx.x * TX + tx) * 4;
+    const int c = (blockIdx.x * TX + tx) * V;
     const int rows_per = (M + rchunks - 1) / rchunks;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    float s[V], q[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
     if (c < C) {
         // shifted sums: d = y - y[row 0]; var = E[d^2] - E[d]^2 has no catastrophic cancellation
         // because the shift is itself a sample of the channel (|mean - shift| ~ std).
-        const f32x4 sh = *(const f32x4*)(y + c);
-        const float* p = y + c;
+        float sh[V];
+        bn_ld(y + c, sh);
+        const T* p = y + c;
         int r = r0 + ty;
         for (; r + (BN_U - 1) * TY < r1; r += BN_U * TY) {
-            f32x4 v[BN_U];
+            float v[BN_U][V];
 #pragma unroll
-            for (int u = 0; u < BN_U; ++u) v[u] = *(const f32x4*)(p + (long)(r + u * TY) * C);
+            for (int u = 0; u < BN_U; ++u) bn_ld(p + (long)(r + u * TY) * C, v[u]);
 #pragma unroll
-            for (int u = 0; u < BN_U; ++u) {
-                const f32x4 d = v[u] - sh;
-                s += d;
-                q += d * d;
-            }
+            for (int u = 0; u < BN_U; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = v[u][j] - sh[j];
+                    s[j] += d;
+                    q[j] += d * d;
+                }
         }
         for (; r < r1; r += TY) {
-            const f32x4 d = *(const f32x4*)(p + (long)r * C) - sh;
-            s += d;
-            q += d * d;
+            float v[V];
+            bn_ld(p + (long)r * C, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = v[j] - sh[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
         }
     }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = q;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][threadIdx.x][j] = s[j];
+        red[1][threadIdx.x][j] = q[j];
+    }
     __syncthreads();
     for (int h = TY >> 1; h > 0; h >>= 1) {     // fixed-order tree over the row lanes
         if (ty < h) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + h * TX];
-            red[1][threadIdx.x] += red[1][threadIdx.x + h * TX];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                red[0][threadIdx.x][j] += red[0][threadIdx.x + h * TX][j];
+                red[1][threadIdx.x][j] += red[1][threadIdx.x + h * TX][j];
+            }
         }
         __syncthreads();
     }
     if (ty == 0 && c < C) {
-        *(f32x4*)(part + (long)blockIdx.y * C + c) = red[0][tx];
-        *(f32x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = red[1][tx];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            part[(long)blockIdx.y * C + c + j] = red[0][tx][j];
+            part[((long)rchunks + blockIdx.y) * C + c + j] = red[1][tx][j];
+        }
     }
 }
 
@@ -125,7 +180,8 @@ __device__ __forceinline__ int bn_reduce_partials(const float* __restrict__ part
     return c;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ y, const float* __restrict__ part, int M, int C, int rchunks,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const T* __restrict__ y, const float* __restrict__ part, int M, int C, int rchunks,
                                                                 float eps, float momentum, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                                 float* __restrict__ saved) {
@@ -196,23 +252,27 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
 }
 
 typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
-// Z16: also write a bf16 (RNE) shadow of z for the bf16 matrix path (the next conv reads it instead of z)
-template <bool Z16>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, long total4,
+// TI / TO: element types of y and z.  Z16 (fp32 z only): also write a bf16 (RNE) shadow of z for the bf16 matrix path
+template <typename TI, typename TO, bool Z16>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ y, TO* __restrict__ z, long totalv,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, float slope, __bf16* __restrict__ z16) {
-    const int c4n = C >> 2;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % c4n) * 4;
-        const f32x4 v = *(const f32x4*)(y + idx * 4);
-        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
-        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        f32x4 o;
+    constexpr int V = BnV<TI>::V;
+    static_assert(BnV<TI>::V == BnV<TO>::V, "same storage type on both sides");
+    const int cvn = C / V;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cvn) * V;
+        float v[V], o[V], mean[V], istd[V], g[V], b[V];
+        bn_ld(y + idx * V, v);
+        bn_ldp<V>(saved + c, mean);
+        bn_ldp<V>(saved + C + c, istd);
+        bn_ldp<V>(gamma + c, g);
+        bn_ldp<V>(beta + c, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
-        *(f32x4*)(z + idx * 4) = o;
-        if (Z16) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector(o, bf16x4_n);
+        for (int j = 0; j < V; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
+        bn_st(z + idx * V, o);
+        if constexpr (Z16) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
     }
 }
 
@@ -229,58 +289,81 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
 // nearly constant within a channel (saturated discriminator), and fp32 there costs percents.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // part layout (fp64): [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                              double* __restrict__ part, int M, int C, int rchunks, int TX,
                                                              const float* __restrict__ saved, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope) {
-    __shared__ f64x4 red[2][256];
+    constexpr int V = BnV<T>::V;
+    __shared__ double red[2][256][V];
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int c = (blockIdx.x * TX + tx) * 4;
+    const int c = (blockIdx.x * TX + tx) * V;
     const int rows_per = (M + rchunks - 1) / rchunks;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    f64x4 s = {0., 0., 0., 0.}, q = {0., 0., 0., 0.};
-    if (c < C) {
-        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
-        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        const f32x4 gs = g * istd;
-        auto acc = [&](const f32x4& v, const f32x4& d) {
+    double s[V], q[V];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.;
+    if (c < C) {
+        float mean[V], istd[V], gs[V], b[V];
+        bn_ldp<V>(saved + c, mean);
+        bn_ldp<V>(saved + C + c, istd);
+        bn_ldp<V>(gamma + c, gs);
+        bn_ldp<V>(beta + c, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gs[j] *= istd[j];
+        auto acc = [&](const float (&v)[V], const float (&d)[V]) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
                 const float u = bn_norm(v[j], mean[j], gs[j], b[j]);
                 const double gg = (double)(d[j] * act_grad(u, act, slope));
                 s[j] += gg;
                 q[j] += gg * (((double)v[j] - (double)mean[j]) * (double)istd[j]);
             }
         };
-        const float* py = y + c;
-        const float* pd = dz + c;
+        const T* py = y + c;
+        const T* pd = dz + c;
+        constexpr int U = V == 4 ? BN_U : BN_U / 2;       // same bytes in flight per thread
         int r = r0 + ty;
-        for (; r + (BN_U - 1) * TY < r1; r += BN_U * TY) {
-            f32x4 v[BN_U], d[BN_U];
+        for (; r + (U - 1) * TY < r1; r += U * TY) {
+            float v[U][V], d[U][V];
 #pragma unroll
-            for (int u = 0; u < BN_U; ++u) {
-                v[u] = *(const f32x4*)(py + (long)(r + u * TY) * C);
-                d[u] = *(const f32x4*)(pd + (long)(r + u * TY) * C);
+            for (int u = 0; u < U; ++u) {
+                bn_ld(py + (long)(r + u * TY) * C, v[u]);
+                bn_ld(pd + (long)(r + u * TY) * C, d[u]);
             }
 #pragma unroll
-            for (int u = 0; u < BN_U; ++u) acc(v[u], d[u]);
+            for (int u = 0; u < U; ++u) acc(v[u], d[u]);
         }
-        for (; r < r1; r += TY) acc(*(const f32x4*)(py + (long)r * C), *(const f32x4*)(pd + (long)r * C));
+        for (; r < r1; r += TY) {
+            float v[V], d[V];
+            bn_ld(py + (long)r * C, v);
+            bn_ld(pd + (long)r * C, d);
+            acc(v, d);
+        }
     }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = q;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][threadIdx.x][j] = s[j];
+        red[1][threadIdx.x][j] = q[j];
+    }
     __syncthreads();
     for (int h = TY >> 1; h > 0; h >>= 1) {
         if (ty < h) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + h * TX];
-            red[1][threadIdx.x] += red[1][threadIdx.x + h * TX];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                red[0][threadIdx.x][j] += red[0][threadIdx.x + h * TX][j];
+                red[1][threadIdx.x][j] += red[1][threadIdx.x + h * TX][j];
+            }
         }
         __syncthreads();
     }
     if (ty == 0 && c < C) {
-        *(f64x4*)(part + (long)blockIdx.y * C + c) = red[0][tx];
-        *(f64x4*)(part + ((long)rchunks + blockIdx.y) * C + c) = red[1][tx];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            part[(long)blockIdx.y * C + c + j] = red[0][tx][j];
+            part[((long)rchunks + blockIdx.y) * C + c + j] = red[1][tx][j];
+        }
     }
 }
 
@@ -326,31 +409,34 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
 }
 
-template <bool D16>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                                                           float* __restrict__ dy, long total4, int C,
+// T: element type of dz / y / dy.  D16 (fp32 only): also write a bf16 shadow of dy
+template <typename T, bool D16>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                           T* __restrict__ dy, long totalv, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ coef,
                                                            int act, float slope, __bf16* __restrict__ dy16) {
-    const int c4n = C >> 2;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % c4n) * 4;
-        const f32x4 v = *(const f32x4*)(y + idx * 4);
-        const f32x4 d = *(const f32x4*)(dz + idx * 4);
-        const f32x4 mean = *(const f32x4*)(saved + c), istd = *(const f32x4*)(saved + C + c);
-        const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-        const f64x4 c1 = *(const f64x4*)(coef + c), c2 = *(const f64x4*)(coef + C + c);
-        f32x4 o;
+    constexpr int V = BnV<T>::V;
+    const int cvn = C / V;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cvn) * V;
+        float v[V], d[V], o[V], mean[V], istd[V], g[V], b[V];
+        bn_ld(y + idx * V, v);
+        bn_ld(dz + idx * V, d);
+        bn_ldp<V>(saved + c, mean);
+        bn_ldp<V>(saved + C + c, istd);
+        bn_ldp<V>(gamma + c, g);
+        bn_ldp<V>(beta + c, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
             const float gs = g[j] * istd[j];
             const float u = bn_norm(v[j], mean[j], gs, b[j]);
             const double gg = (double)(d[j] * act_grad(u, act, slope));
             const double xhat = ((double)v[j] - (double)mean[j]) * (double)istd[j];
-            o[j] = (float)((double)g[j] * (double)istd[j] * (gg - c1[j] - xhat * c2[j]));
+            o[j] = (float)((double)g[j] * (double)istd[j] * (gg - coef[c + j] - xhat * coef[C + c + j]));
         }
-        *(f32x4*)(dy + idx * 4) = o;
-        if (D16) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector(o, bf16x4_n);
+        bn_st(dy + idx * V, o);
+        if constexpr (D16) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
     }
 }
 
@@ -392,6 +478,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// bf16 in / bf16 out (n % 8 == 0): the first layer's fused LeakyReLU backward on the bf16-stored gradient
+__global__ __launch_bounds__(256) void act_bwd16_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ out,
+                                                        __bf16* __restrict__ dx, long total8, int act, float slope) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        float d[8], o[8], r[8];
+        bn_ld(dy + idx * 8, d);
+        bn_ld(out + idx * 8, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = act_bwd_one(d[j], o[j], act, slope);
+        bn_st(dx + idx * 8, r);
+    }
+}
+
 static int stream_grid(long total4) {
     long g = (total4 + 255) / 256;
     if (g > 2048) g = 2048;
@@ -400,27 +499,40 @@ static int stream_grid(long total4) {
 }
 
 extern "C" size_t dg_bn_workspace_bytes(int M, int C) {
-    const BnGrid g = bn_grid(M, C);
+    const BnGrid g = bn_grid(M, C);                                        // V = 4 needs the larger one (more channel lanes)
     return ((size_t)2 * g.rchunks * C + 2 * (size_t)C) * sizeof(double);   // fp64 partials in the backward
 }
 
-extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
-                                 float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
-                                 dg_stream_t stream) {
+// io_bf16: every activation tensor of the call (y / z / dz / dy) is bf16; statistics, parameters and their gradients stay fp32
+template <typename T>
+static int bn_train_stats_impl(const T* y, int M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                               int64_t* nbt, float* saved, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(y && saved, "dg_bn_train_stats: null pointer");
     DG_CHECK_ARG(M >= 2, "dg_bn_train_stats: Expected more than 1 value per channel when training (M=%d)", M);
-    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_train_stats: C=%d must be a multiple of 4", C);
+    DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_train_stats: C=%d must be a multiple of %d", C, V);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
         return dg_fail(DG_ERR_WORKSPACE, "dg_bn_train_stats: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
-    const BnGrid g = bn_grid(M, C);
+    const BnGrid g = bn_grid(M, C, V);
     const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc, g.tx);
+    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc, g.tx);
     DG_CHECK_LAUNCH("bn_stats_partial");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<T>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
                        momentum, running_mean, running_var, nbt, saved);
     DG_CHECK_LAUNCH("bn_stats_finalize");
     return DG_OK;
+}
+extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
+                                 float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
+                                 dg_stream_t stream) {
+    return bn_train_stats_impl<float>(y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
+}
+extern "C" int dg_bn_train_stats_t(const void* y, int io_bf16, int M, int C, float eps, float momentum, float* running_mean,
+                                   float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
+                                   dg_stream_t stream) {
+    if (io_bf16) return bn_train_stats_impl<__bf16>((const __bf16*)y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
+    return bn_train_stats_impl<float>((const float*)y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
 }
 
 extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C, float eps, float momentum,
@@ -435,69 +547,95 @@ extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C,
     return DG_OK;
 }
 
-static int bn_act_fwd_impl(const float* y, float* z, void* z16, int M, int C, const float* saved, const float* gamma,
+template <typename T>
+static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const float* saved, const float* gamma,
                            const float* beta, int act, float slope, dg_stream_t stream) {
+    constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
-    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_fwd: C=%d must be a multiple of 4", C);
+    DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
-    const long total4 = (long)M * C / 4;
-    if (z16)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
-                           saved, gamma, beta, act, slope, (__bf16*)z16);
-    else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, z, total4, C,
-                           saved, gamma, beta, act, slope, (__bf16*)nullptr);
+    const long totalv = (long)M * C / V;
+    if constexpr (V == 4) {
+        if (z16) {
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, true>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
+                               saved, gamma, beta, act, slope, (__bf16*)z16);
+            DG_CHECK_LAUNCH("bn_act_fwd");
+            return DG_OK;
+        }
+    }
+    hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, false>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
+                       saved, gamma, beta, act, slope, (__bf16*)nullptr);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
 extern "C" int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
                              const float* beta, int act, float slope, dg_stream_t stream) {
-    return bn_act_fwd_impl(y, z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
+    return bn_act_fwd_impl<float>(y, z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
 }
 extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M, int C, const float* saved, const float* gamma,
                                   const float* beta, int act, float slope, dg_stream_t stream) {
     DG_CHECK_ARG(z_bf16, "dg_bn_act_fwd_bf16: null shadow pointer");
-    return bn_act_fwd_impl(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
+    return bn_act_fwd_impl<float>(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
+}
+extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C, const float* saved, const float* gamma,
+                               const float* beta, int act, float slope, dg_stream_t stream) {
+    if (io_bf16) return bn_act_fwd_impl<__bf16>((const __bf16*)y, (__bf16*)z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
+    return bn_act_fwd_impl<float>((const float*)y, (float*)z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
 }
 
-static int bn_act_bwd_impl(const float* dz, const float* y, float* dy, void* dy16, int M, int C, const float* saved,
+template <typename T>
+static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, int C, const float* saved,
                            const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                            int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
-    DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_act_bwd: C=%d must be a multiple of 4", C);
+    DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
         return dg_fail(DG_ERR_WORKSPACE, "dg_bn_act_bwd: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
-    const BnGrid g = bn_grid(M, C);
+    const BnGrid g = bn_grid(M, C, V);
     const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
     double* coef = part + (size_t)2 * rc * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, g.tx, saved, gamma, beta, act, slope);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, g.tx, saved, gamma, beta, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_partial");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const double*)part, M, C, rc, coef,
                        dgamma, dbeta, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
-    const long total4 = (long)M * C / 4;
-    if (dy16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
-                           beta, (const double*)coef, act, slope, (__bf16*)dy16);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_grid(total4)), dim3(256), 0, st, dz, y, dy, total4, C, saved, gamma,
-                           beta, (const double*)coef, act, slope, (__bf16*)nullptr);
+    const long totalv = (long)M * C / V;
+    if constexpr (V == 4) {
+        if (dy16) {
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16);
+            DG_CHECK_LAUNCH("bn_bwd_apply");
+            return DG_OK;
+        }
+    }
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
+                       beta, (const double*)coef, act, slope, (__bf16*)nullptr);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
 }
 extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
                              const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                              int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return bn_act_bwd_impl(dz, y, dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+    return bn_act_bwd_impl<float>(dz, y, dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
 }
 extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16, int M, int C, const float* saved,
                                   const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                                   int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_bf16, "dg_bn_act_bwd_bf16: null shadow pointer");
-    return bn_act_bwd_impl(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+    return bn_act_bwd_impl<float>(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+}
+extern "C" int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_bf16, int M, int C, const float* saved,
+                               const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                               int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    if (io_bf16)
+        return bn_act_bwd_impl<__bf16>((const __bf16*)dz, (const __bf16*)y, (__bf16*)dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma,
+                                       dbeta, accumulate, ws, ws_bytes, stream);
+    return bn_act_bwd_impl<float>((const float*)dz, (const float*)y, (float*)dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta,
+                                  accumulate, ws, ws_bytes, stream);
 }
 
 extern "C" int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t stream) {
@@ -516,5 +654,17 @@ extern "C" int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n
     const long total4 = (long)((n + 3) / 4);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, total4, (long)n, act, slope);
     DG_CHECK_LAUNCH("act_bwd");
+    return DG_OK;
+}
+extern "C" int dg_act_bwd_t(const void* dy, const void* out, void* dx, int io_bf16, size_t n, int act, float slope, dg_stream_t stream) {
+    if (!io_bf16) return dg_act_bwd((const float*)dy, (const float*)out, (float*)dx, n, act, slope, stream);
+    DG_CHECK_ARG(dy && out && dx, "dg_act_bwd_t: null pointer");
+    DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_bwd_t: bad act %d", act);
+    DG_CHECK_ARG(n % 8 == 0, "dg_act_bwd_t: bf16 tensors need n %% 8 == 0 (n=%zu)", n);
+    if (n == 0) return DG_OK;
+    const long total8 = (long)(n / 8);
+    hipLaunchKernelGGL(act_bwd16_kernel, dim3(stream_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)out,
+                       (__bf16*)dx, total8, act, slope);
+    DG_CHECK_LAUNCH("act_bwd16");
     return DG_OK;
 }

@@ -103,14 +103,28 @@ def _check_dev(*ts):
         if not t.is_cuda:
             raise _lib.DiscoganHipError(
                 "discogan_modernized_amd ops need CUDA/HIP tensors (no CPU fallback exists); got a CPU tensor")
-        if t.dtype != torch.float32:
-            raise _lib.DiscoganHipError(f"fp32 tensors required, got {t.dtype}")
+        if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+            raise _lib.DiscoganHipError(f"fp32 (or, with bf16 activation storage, bf16) tensors required, got {t.dtype}")
 
 
 # ---- layout helpers -------------------------------------------------------------------------------------
-def empty_nhwc(n, c, h, w, device):
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
     """Logical [n,c,h,w] tensor backed by NHWC memory."""
-    return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+# bf16 ACTIVATION STORAGE (DiscoGANTrainer(mfma_dtype="bf16", act_dtype="bf16")): with ACT16 on, every feature map and
+# feature-map gradient an op produces is a bf16 tensor (channel counts that are multiples of 8; the [N,100] bottleneck and
+# everything image-shaped stay fp32), and the ops take bf16 tensors as they come -- there is no fp32 copy to shadow.
+ACT16 = False
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _act_dtype(channels):
+    return torch.bfloat16 if (ACT16 and channels % 8 == 0) else torch.float32
 
 
 def is_nhwc(x):
@@ -122,6 +136,8 @@ def as_nhwc(x):
     if is_nhwc(x):
         return x
     _check_dev(x)
+    if x.dtype != torch.float32:
+        raise _lib.DiscoganHipError("bf16 activations must already have NHWC memory")
     xc = x.contiguous()
     n, c, h, w = xc.shape
     y = empty_nhwc(n, c, h, w, x.device)
@@ -237,6 +253,14 @@ def _out_hw(h, w, stride, pad):
     return (h + 2 * pad - 4) // stride + 1, (w + 2 * pad - 4) // stride + 1
 
 
+def _mixed_operand(t, allow_shadow=True):
+    """(pointer tensor, is_bf16) of a conv operand: a bf16 tensor as it is, an fp32 tensor's shadow if it has one."""
+    if _is16(t):
+        return t, 1
+    t16 = shadow_get(t) if allow_shadow else None
+    return (t16, 1) if t16 is not None else (t, 0)
+
+
 def conv_fwd(x, w, stride, pad, want_stats=False):
     """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC.
     want_stats: also return the BatchNorm partial-statistics rows of y (None if the layer has no fused path)."""
@@ -246,20 +270,30 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     n, c, h, wd = x.shape
     k = w.shape[0]
     ho, wo = _out_hw(h, wd, stride, pad)
-    y = empty_nhwc(n, k, ho, wo, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
-    w16 = x16 = None
-    if rows == 0 and k > 1 and _bf16_ok(0, n, h, wd, c, k, stride, pad):
-        w16, x16 = weight_shadow(w), shadow_get(x)
+    mixed = False
+    xa, x16, wa, w16, o16 = x, 0, w, 0, 0
+    if k == 1:
+        mixed = _is16(x)
+        x16 = int(mixed)
+    elif rows == 0 and _bf16_ok(0, n, h, wd, c, k, stride, pad):
+        xa, x16 = _mixed_operand(x)
+        wsh = weight_shadow(w)
+        if wsh is not None:
+            wa, w16 = wsh, 1
+        o16 = int(_act_dtype(k) == torch.bfloat16)
+        mixed = bool(x16 or w16 or o16)
+    if _is16(x) and not mixed:
+        raise _lib.DiscoganHipError(f"conv_fwd: no bf16 kernel for a bf16 input of shape {tuple(x.shape)} -> {k} channels")
+    y = empty_nhwc(n, k, ho, wo, x.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
-        if w16 is not None or x16 is not None:
+        if mixed:
             stat = None
-            _lib.check(L.dg_conv_fwd_mixed(_ptr(x16 if x16 is not None else x), int(x16 is not None),
-                                           _ptr(w16 if w16 is not None else w), int(w16 is not None), _ptr(y), n, h, wd, c, k,
+            _lib.check(L.dg_conv_fwd_mixed(_ptr(xa), x16, _ptr(wa), w16, _ptr(y), o16, n, h, wd, c, k,
                                            stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_fwd_mixed")
         elif rows > 0:
             stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
@@ -281,21 +315,31 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     n, k = dy.shape[0], dy.shape[1]
     c = w.shape[1]
     h, wd = x_hw
-    dx = empty_nhwc(n, c, h, wd, dy.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
     rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0
-    w16 = dy16 = None
-    if rows == 0 and k > 1 and _bf16_ok(1, n, h, wd, c, k, stride, pad):
-        w16 = weight_shadow(w)
-        dy16 = shadow_get(dy) if k % 8 == 0 else None
+    mixed = False
+    da, d16, wa, w16, o16 = dy, 0, w, 0, 0
+    if k == 1:
+        o16 = int(_act_dtype(c) == torch.bfloat16)
+        mixed = bool(o16)
+    elif rows == 0 and _bf16_ok(1, n, h, wd, c, k, stride, pad):
+        if k % 8 == 0:
+            da, d16 = _mixed_operand(dy)
+        wsh = weight_shadow(w)
+        if wsh is not None:
+            wa, w16 = wsh, 1
+        o16 = int(_act_dtype(c) == torch.bfloat16)
+        mixed = bool(d16 or w16 or o16)
+    if _is16(dy) and not d16:
+        raise _lib.DiscoganHipError(f"conv_dgrad: no bf16 kernel for a bf16 gradient of shape {tuple(dy.shape)}")
+    dx = empty_nhwc(n, c, h, wd, dy.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-        if w16 is not None or dy16 is not None:
+        if mixed:
             stat = None
-            _lib.check(L.dg_conv_dgrad_mixed(_ptr(dy16 if dy16 is not None else dy), int(dy16 is not None),
-                                             _ptr(w16 if w16 is not None else w), int(w16 is not None), _ptr(dx), n, h, wd, c, k,
+            _lib.check(L.dg_conv_dgrad_mixed(_ptr(da), d16, _ptr(wa), w16, _ptr(dx), o16, n, h, wd, c, k,
                                              stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_dgrad_mixed")
         elif rows > 0:
             stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)
@@ -348,14 +392,18 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
-    dy16 = x16 = None
-    if k > 1 and _bf16_ok(2, n, h, wd, c, k, stride, pad):
-        x16 = shadow_get(x)
-        dy16 = shadow_get(dy) if k % 8 == 0 else None
+    da, d16, xa, x16 = dy, 0, x, 0
+    if k == 1:
+        x16 = int(_is16(x))
+    elif _bf16_ok(2, n, h, wd, c, k, stride, pad) or _is16(x) or _is16(dy):
+        xa, x16 = _mixed_operand(x)
+        if k % 8 == 0:
+            da, d16 = _mixed_operand(dy)
+    if (_is16(dy) and not d16) or (_is16(x) and not x16):
+        raise _lib.DiscoganHipError(f"conv_wgrad: no bf16 kernel for bf16 operands of shapes {tuple(dy.shape)}, {tuple(x.shape)}")
     with _prof("conv_wgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-        if dy16 is not None or x16 is not None:
-            _lib.check(L.dg_conv_wgrad_mixed(_ptr(dy16 if dy16 is not None else dy), int(dy16 is not None),
-                                             _ptr(x16 if x16 is not None else x), int(x16 is not None), _ptr(dw), n, h, wd, c, k,
+        if d16 or x16:
+            _lib.check(L.dg_conv_wgrad_mixed(_ptr(da), d16, _ptr(xa), x16, _ptr(dw), n, h, wd, c, k,
                                              stride, pad, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv_wgrad_mixed")
         else:
             _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
@@ -371,12 +419,17 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
     w = w.contiguous()
     n, _, h, wd = x.shape
     k = w.shape[0]
-    y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
+    o16 = ACT16 and k == 64 and x.numel() * 4 < (1 << 30)
+    y = empty_nhwc(n, k, h // 2, wd // 2, x.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), \
-            _hbm("edge_c3_fwd", 4.0 * (x.numel() + y.numel())):
-        _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
-                   "dg_conv4x4s2_c3_fwd")
-    if SHADOW and k % 8 == 0:
+            _hbm("edge_c3_fwd", 4.0 * x.numel() + y.numel() * y.element_size()):
+        if o16:
+            _lib.check(_lib.load().dg_conv4x4s2_c3_fwd_t(_ptr(x), _ptr(w), _ptr(y), 1, n, h, wd, k, act, slope, _stream()),
+                       "dg_conv4x4s2_c3_fwd_t")
+        else:
+            _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
+                       "dg_conv4x4s2_c3_fwd")
+    if SHADOW and not o16 and k % 8 == 0:
         shadow_put(y, f32_to_bf16(y, empty_nhwc_bf16(n, k, h // 2, wd // 2, x.device)))
     return y
 
@@ -390,9 +443,13 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     dx = torch.empty((n, 3, 2 * ho, 2 * wo), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_dgrad_workspace_bytes(k), dy.device)
-    with _hbm("edge_c3_dgrad", 4.0 * (dy.numel() + dx.numel())):
-        _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
-                                           _stream()), "dg_conv4x4s2_c3_dgrad")
+    with _hbm("edge_c3_dgrad", dy.numel() * dy.element_size() + 4.0 * dx.numel()):
+        if _is16(dy):
+            _lib.check(L.dg_conv4x4s2_c3_dgrad_t(_ptr(dy), 1, _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
+                                                 _stream()), "dg_conv4x4s2_c3_dgrad_t")
+        else:
+            _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
+                                               _stream()), "dg_conv4x4s2_c3_dgrad")
     return dx
 
 
@@ -407,9 +464,17 @@ def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE,
     dw = out if out is not None else torch.empty((k, 3, 4, 4), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_wgrad_workspace_bytes(n, h, wd, k), dy.device)
-    if act_out is not None and act != ACT_NONE:
+    fuse = act_out is not None and act != ACT_NONE
+    ao = None
+    if fuse:
         ao = as_nhwc(act_out)
-        assert ao.shape == dy.shape
+        assert ao.shape == dy.shape and ao.dtype == dy.dtype
+    if _is16(dy):
+        with _hbm("edge_c3_wgrad", 2.0 * ((2 if fuse else 1) * dy.numel()) + 4.0 * x.numel()):
+            _lib.check(L.dg_conv4x4s2_c3_wgrad_t(_ptr(dy), _ptr(ao), 1, act if fuse else ACT_NONE, float(slope), _ptr(x), _ptr(dw),
+                                                 n, h, wd, k, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_t")
+        return dw
+    if fuse:
         with _hbm("edge_c3_wgrad", 4.0 * (2 * dy.numel() + x.numel())):
             _lib.check(L.dg_conv4x4s2_c3_wgrad_act(_ptr(dy), _ptr(ao), act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k,
                                                    int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_act")
@@ -429,9 +494,9 @@ def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
     saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
-    with _hbm("bn_stats", 4.0 * m * c):
-        _lib.check(L.dg_bn_train_stats(_ptr(y), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
-                                       _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
+    with _hbm("bn_stats", float(y.element_size()) * m * c):
+        _lib.check(L.dg_bn_train_stats_t(_ptr(y), int(_is16(y)), m, c, eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                         _ptr(saved), _ptr(ws), wsb, _stream()), "dg_bn_train_stats")
     return saved
 
 
@@ -448,6 +513,12 @@ def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentu
 def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     y = as_nhwc(y)
     n, c, h, w = y.shape
+    if _is16(y):                      # bf16 activation storage: bf16 in, bf16 out, nothing else is written
+        z = empty_nhwc(n, c, h, w, y.device, torch.bfloat16)
+        with _hbm("bn_apply", 4.0 * n * h * w * c):
+            _lib.check(_lib.load().dg_bn_act_fwd_t(_ptr(y), _ptr(z), 1, n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+                                                   act, slope, _stream()), "dg_bn_act_fwd_t")
+        return z
     z = empty_nhwc(n, c, h, w, y.device)
     if SHADOW and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
@@ -468,7 +539,6 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
     y = as_nhwc(y)
     n, c, h, w = y.shape
     m = n * h * w
-    dy = empty_nhwc(n, c, h, w, y.device)
     acc = 0
     if out_grads is not None:
         dgamma, dbeta = out_grads
@@ -478,6 +548,15 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
         dbeta = torch.empty(c, device=y.device, dtype=torch.float32) if need_param_grads else None
     L = _lib.load()
     ws, wsb = _ws(L.dg_bn_workspace_bytes(m, c), y.device)
+    if _is16(y):
+        if not _is16(dz):
+            raise _lib.DiscoganHipError("bn_act_bwd: bf16 y needs a bf16 dz")
+        dy = empty_nhwc(n, c, h, w, y.device, torch.bfloat16)
+        with _hbm("bn_backward", 10.0 * m * c):
+            _lib.check(L.dg_bn_act_bwd_t(_ptr(dz), _ptr(y), _ptr(dy), 1, m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act,
+                                         slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_t")
+        return dy, dgamma, dbeta
+    dy = empty_nhwc(n, c, h, w, y.device)
     if SHADOW and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)
         with _hbm("bn_backward", 22.0 * m * c):
@@ -519,6 +598,11 @@ def act_bwd(dy, out, act, slope=0.2):
         dyl.copy_(dy)
         dy = dyl
     dx = _dense_like(out)
+    if _is16(out) or _is16(dy):
+        if dy.dtype != out.dtype:
+            raise _lib.DiscoganHipError("act_bwd: dy and out must have the same dtype")
+        _lib.check(_lib.load().dg_act_bwd_t(_ptr(dy), _ptr(out), _ptr(dx), 1, out.numel(), act, slope, _stream()), "dg_act_bwd_t")
+        return dx
     _lib.check(_lib.load().dg_act_bwd(_ptr(dy), _ptr(out), _ptr(dx), out.numel(), act, slope, _stream()), "dg_act_bwd")
     return dx
 
@@ -608,7 +692,9 @@ def fm_fwd(real, fake, out=None):
     diff = torch.empty(j, device=real.device, dtype=torch.float32)
     loss = out if out is not None else torch.empty((), device=real.device, dtype=torch.float32)
     ws, wsb = _ws(_lib.load().dg_fm_workspace_bytes(n, j), real.device)
-    _lib.check(_lib.load().dg_fm_fwd(_ptr(real), _ptr(fake), n, j, _ptr(diff), _ptr(loss), _ptr(ws), wsb, _stream()),
+    if real.dtype != fake.dtype:
+        raise _lib.DiscoganHipError("fm_fwd: real and fake features must have the same dtype")
+    _lib.check(_lib.load().dg_fm_fwd_t(_ptr(real), _ptr(fake), int(_is16(real)), n, j, _ptr(diff), _ptr(loss), _ptr(ws), wsb, _stream()),
                "dg_fm_fwd")
     return loss, diff, real, fake
 
@@ -618,7 +704,7 @@ def fm_bwd(diff, like_real, like_fake, gout, need_real, need_fake):
     j = diff.numel()
     dreal = _dense_like(like_real) if need_real else None
     dfake = _dense_like(like_fake) if need_fake else None
-    _lib.check(_lib.load().dg_fm_bwd(_ptr(diff), n, j, _ptr(gout), _ptr(dreal), _ptr(dfake), _stream()), "dg_fm_bwd")
+    _lib.check(_lib.load().dg_fm_bwd_t(_ptr(diff), n, j, _ptr(gout), _ptr(dreal), _ptr(dfake), int(_is16(like_fake)), _stream()), "dg_fm_bwd")
     return dreal, dfake
 
 

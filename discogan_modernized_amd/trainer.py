@@ -54,7 +54,7 @@ class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
                  cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
-                 bucket_mb=128.0):
+                 bucket_mb=128.0, act_dtype="f32"):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -115,6 +115,15 @@ class DiscoGANTrainer:
         self.mfma_dtype = mfma_dtype
         # bf16 path: the conv kernels read bf16 SHADOWS of their operands written by the producers (ops.SHADOW)
         self.bf16_shadow = mfma_dtype == "bf16"
+        # act_dtype "bf16" (needs mfma_dtype "bf16"): feature maps and their gradients are STORED in bf16 only -- the conv
+        # epilogues round the fp32 accumulators once, BatchNorm reads bf16 and keeps its statistics and arithmetic in
+        # fp32 / fp64 (BASELINE configs[4]: "bf16 MFMA + fp32 BatchNorm accum"); 8 / 10 bytes per element and pass instead
+        # of 18 / 22.  Images, weights, BatchNorm parameters and buffers, every parameter gradient, losses, Adam: fp32.
+        if act_dtype not in ("f32", "bf16"):
+            raise ValueError("act_dtype must be 'f32' or 'bf16'")
+        if act_dtype == "bf16" and mfma_dtype != "bf16":
+            raise ValueError("act_dtype='bf16' needs mfma_dtype='bf16'")
+        self.act_dtype = act_dtype
         if self.bf16_shadow:
             self.optim_gen.enable_bf16_shadow()
             self.optim_dis.enable_bf16_shadow()
@@ -350,6 +359,7 @@ class DiscoGANTrainer:
         if self.mfma_dtype != "f32":
             _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 2)
         _ops.SHADOW = self.bf16_shadow
+        _ops.ACT16 = self.act_dtype == "bf16"
         _ops.shadow_clear()
         try:
             out = self.forward_losses(A, B, iters, need_losses)
@@ -358,6 +368,7 @@ class DiscoGANTrainer:
             _F.WGRAD_STREAM = None
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
             _ops.SHADOW = False
+            _ops.ACT16 = False
             _ops.shadow_clear()
             if self.mfma_dtype != "f32":
                 _l.set_option("bf16", 0)          # the library default stays exact fp32 for everyone else

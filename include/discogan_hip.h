@@ -273,12 +273,42 @@ int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16
                        const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                        int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
-int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, float* y, int N, int H, int W, int C, int K,
+int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, void* y, int y_bf16, int N, int H, int W, int C, int K,
                       int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
-int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, float* dx, int N, int H, int W, int C, int K,
+int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, int K,
                         int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
                         int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+
+/* ---- bf16 ACTIVATION STORAGE (option "bf16" = 1; DiscoGANTrainer(mfma_dtype="bf16", act_dtype="bf16")) --------------------
+ * Feature maps and their gradients live in HBM as bf16 ONLY (no fp32 copy): the conv epilogues round the fp32
+ * accumulators once (y_bf16 / dx_bf16 of the *_mixed convolutions above; never the weight gradient), BatchNorm reads
+ * bf16, keeps statistics / normalisation / the backward expression in fp32 / fp64 exactly as the fp32 kernels do and
+ * rounds what it stores ("bf16 MFMA + fp32 BatchNorm accum", BASELINE configs[4]).  Per element: forward 8 B instead of
+ * 18 (fp32 + shadow), backward 10 B instead of 22.  `io_bf16` = every activation tensor of the call is bf16 (C % 8 == 0);
+ * 0 = the fp32 kernels.  The image side (NCHW, 3 channels), weights, BatchNorm parameters / statistics, every gradient
+ * of a parameter, losses and Adam stay fp32.  The K == 1 head takes a bf16 x / dx through the *_mixed entry points. */
+int dg_bn_train_stats_t(const void* y, int io_bf16, int M, int C, float eps, float momentum, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* saved, void* ws, size_t ws_bytes,
+                        dg_stream_t stream);
+int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C, const float* saved, const float* gamma,
+                    const float* beta, int act, float slope, dg_stream_t stream);
+int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_bf16, int M, int C, const float* saved,
+                    const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
+                    int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_act_bwd_t(const void* dy, const void* out, void* dx, int io_bf16, size_t n, int act, float slope, dg_stream_t stream);
+/* 3-channel edge layers with the 64-channel NHWC side in bf16 (K == 64 only; the NCHW image side stays fp32) */
+int dg_conv4x4s2_c3_fwd_t(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                          int act, float slope, dg_stream_t s);
+int dg_conv4x4s2_c3_dgrad_t(const void* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                            int act, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4s2_c3_wgrad_t(const void* dy_nhwc, const void* act_out_nhwc /* or NULL with act NONE */, int io_bf16, int act,
+                            float slope, const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
+                            void* ws, size_t ws_bytes, dg_stream_t s);
+/* feature matching on bf16 discriminator features (sums in fp32; dreal / dfake written as bf16) */
+int dg_fm_fwd_t(const void* real, const void* fake, int io_bf16, int N, size_t J, float* diff, float* loss, void* ws,
+                size_t ws_bytes, dg_stream_t stream);
+int dg_fm_bwd_t(const float* diff, int N, size_t J, const float* gout, void* dreal, void* dfake, int io_bf16, dg_stream_t stream);
 
 /* ---- layout helpers --------------------------------------------------------------------------- */
 int dg_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, dg_stream_t s);

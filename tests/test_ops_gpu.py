@@ -555,3 +555,154 @@ def test_errors_are_reported_not_fatal():
         ops.conv_fwd(nhwc(rnd(2, 64, 8, 8)), krsc(rnd(64, 64, 4, 4)), 1, 1)
     with pytest.raises(_lib.DiscoganHipError, match="CPU"):
         ops.conv_fwd(rnd(2, 64, 8, 8), rnd(64, 64, 4, 4), 2, 1)
+
+
+# ---- bf16 activation storage (the *_t entry points): bf16 in / bf16 out, fp32 arithmetic inside --------------------------
+BF16_ULP = 2.0 ** -8            # RNE to bf16: relative error <= 2^-9 per rounding; one rounding of the output is allowed
+
+
+def close16(got16, ref32, extra=0.0, what=""):
+    """got16 (bf16) must be ref32 rounded once: |got - ref| <= 2^-8 |ref| (+ extra * max|ref| for inputs' own effect)."""
+    g, r = got16.detach().float().cpu(), ref32.detach().float().cpu()
+    assert g.shape == r.shape, f"{what}: shape {tuple(g.shape)} vs {tuple(r.shape)}"
+    assert torch.isfinite(g).all(), f"{what}: non-finite"
+    bound = BF16_ULP * r.abs() + (extra + 1e-6) * r.abs().max()
+    bad = ((g - r).abs() > bound)
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, worst {((g - r).abs() - bound).max().item():.3e} over the bound"
+
+
+def nhwc16(t):
+    """CPU logical NCHW fp32 -> GPU bf16 tensor with NHWC memory."""
+    return t.to(DEV).bfloat16().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("N,C,H", [(4, 64, 32), (3, 128, 16), (2, 2048, 4), (5, 512, 8), (32, 64, 8)])
+@pytest.mark.parametrize("act", [ops.ACT_LEAKY, ops.ACT_RELU])
+def test_bn_bf16_storage_matches_fp32_kernels_on_rounded_input(N, C, H, act):
+    """bf16 y / dz in, bf16 z / dy out: the same fp32 / fp64 arithmetic as the fp32 kernels applied to the rounded tensors
+    -- statistics and parameter gradients equal at fp32 tolerance, z and dy equal after ONE rounding to bf16."""
+    y, dz = rnd(N, C, H, H, seed=5) * 2 + 0.3, rnd(N, C, H, H, seed=6)
+    gamma, beta = (rnd(C, seed=7) + 1.5).to(DEV), rnd(C, seed=8).to(DEV)
+    y16, dz16 = nhwc16(y), nhwc16(dz)
+    y32, dz32 = nhwc(y16.float().cpu()), nhwc(dz16.float().cpu())          # the SAME values in fp32 tensors
+    rm32, rv32, nb32 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    rm16, rv16, nb16 = rm32.clone(), rv32.clone(), nb32.clone()
+    s32 = ops.bn_train_stats(y32, rm32, rv32, nb32, 1e-5, 0.1)
+    s16 = ops.bn_train_stats(y16, rm16, rv16, nb16, 1e-5, 0.1)
+    close(s16, s32, rtol=2e-6, what="bf16-storage BN statistics")
+    close(rm16, rm32, rtol=2e-6, what="running_mean")
+    close(rv16, rv32, rtol=2e-6, what="running_var")
+    assert int(nb16) == 1
+    z32 = ops.bn_act_fwd(y32, s32, gamma, beta, act, 0.2)
+    z16 = ops.bn_act_fwd(y16, s32, gamma, beta, act, 0.2)
+    assert z16.dtype == torch.bfloat16 and ops.is_nhwc(z16)
+    close16(z16, z32, what="bf16-storage BN apply")
+    dy32, dg32, db32 = ops.bn_act_bwd(dz32, y32, s32, gamma, beta, act, 0.2)
+    dy16, dg16, db16 = ops.bn_act_bwd(dz16, y16, s32, gamma, beta, act, 0.2)
+    assert dy16.dtype == torch.bfloat16
+    close16(dy16, dy32, what="bf16-storage BN backward dy")
+    close(dg16, dg32, rtol=1e-5, what="dgamma")
+    close(db16, db32, rtol=1e-5, what="dbeta")
+
+
+@pytest.mark.parametrize("N,C,K,H", [(2, 128, 256, 8), (4, 128, 256, 16), (3, 256, 320, 16), (2, 64, 128, 32), (2, 128, 64, 16)])
+def test_conv_bf16_in_bf16_out(N, C, K, H):
+    """bf16 activations in, bf16 activations out (register-staged and LDS-DMA kernels, split-K reduction included): the
+    fp32 result of the same kernels, rounded once."""
+    x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    _lib.set_option("bf16", 1)
+    ops.SHADOW = True
+    try:
+        x16, dy16, wg = nhwc16(x), nhwc16(dy), _with_shadow(krsc(w))
+        x32, dy32 = _with_shadow(nhwc(x16.float().cpu())), _with_shadow(nhwc(dy16.float().cpu()))
+        y_ref, dx_ref, dw_ref = ops.conv_fwd(x32, wg, 2, 1), ops.conv_dgrad(dy32, wg, (H, H), 2, 1), ops.conv_wgrad(dy32, x32, 2, 1)
+        assert y_ref.dtype == torch.float32
+        ops.ACT16 = True
+        y, dx, dw = ops.conv_fwd(x16, wg, 2, 1), ops.conv_dgrad(dy16, wg, (H, H), 2, 1), ops.conv_wgrad(dy16, x16, 2, 1)
+        assert y.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and dw.dtype == torch.float32
+        close16(y, y_ref, what="conv fwd bf16 out")
+        close16(dx, dx_ref, what="conv dgrad bf16 out")
+        assert torch.equal(dw, dw_ref), "weight gradient from bf16 tensors must be bitwise the shadowed one"
+    finally:
+        ops.ACT16 = False
+        ops.SHADOW = False
+        ops.shadow_clear()
+        _lib.set_option("bf16", 0)
+
+
+def test_head_and_bottleneck_bf16_storage():
+    """The K == 1 discriminator head with a bf16 feature map (plain reductions), and the generators' 100-channel bottleneck:
+    bf16 map in -> fp32 [N,100] out -> bf16 map back (C = 100 is not a multiple of 8: that tensor stays fp32)."""
+    N, C = 6, 512
+    x, w1, dy1 = rnd(N, C, 4, 4, seed=1), rnd(1, C, 4, 4, seed=2, scale=0.02), rnd(N, 1, 1, 1, seed=3)
+    w100, dy100 = rnd(100, C, 4, 4, seed=4, scale=0.02), rnd(N, 100, 1, 1, seed=5)
+    _lib.set_option("bf16", 1)
+    ops.SHADOW = True
+    try:
+        x16 = nhwc16(x)
+        x32 = _with_shadow(nhwc(x16.float().cpu()))
+        wg1, wg100 = krsc(w1), _with_shadow(krsc(w100))
+        ref = (ops.conv_fwd(x32, wg1, 1, 0), ops.conv_dgrad(dy1.to(DEV), wg1, (4, 4), 1, 0), ops.conv_wgrad(dy1.to(DEV), x32, 1, 0),
+               ops.conv_fwd(x32, wg100, 1, 0), ops.conv_dgrad(dy100.to(DEV), wg100, (4, 4), 1, 0), ops.conv_wgrad(dy100.to(DEV), x32, 1, 0))
+        ops.ACT16 = True
+        got = (ops.conv_fwd(x16, wg1, 1, 0), ops.conv_dgrad(dy1.to(DEV), wg1, (4, 4), 1, 0), ops.conv_wgrad(dy1.to(DEV), x16, 1, 0),
+               ops.conv_fwd(x16, wg100, 1, 0), ops.conv_dgrad(dy100.to(DEV), wg100, (4, 4), 1, 0), ops.conv_wgrad(dy100.to(DEV), x16, 1, 0))
+        assert got[0].dtype == torch.float32 and got[3].dtype == torch.float32
+        assert got[1].dtype == torch.bfloat16 and got[4].dtype == torch.bfloat16
+        close(got[0], ref[0], rtol=1e-5, what="head1 fwd")
+        close16(got[1], ref[1], what="head1 dgrad")
+        close(got[2], ref[2], rtol=1e-5, what="head1 wgrad")
+        close(got[3], ref[3], rtol=1e-5, what="bottleneck fwd")
+        close16(got[4], ref[4], what="bottleneck dgrad")
+        close(got[5], ref[5], rtol=1e-5, what="bottleneck wgrad")
+    finally:
+        ops.ACT16 = False
+        ops.SHADOW = False
+        ops.shadow_clear()
+        _lib.set_option("bf16", 0)
+
+
+@pytest.mark.parametrize("N,S", [(2, 16), (3, 64), (1, 128)])
+def test_edge_kernels_bf16_storage(N, S):
+    """3-channel edge layers with the 64-channel side in bf16: forward output rounded once; input-grad / weight-grad equal
+    the fp32 kernels on the rounded tensors at fp32 tolerance (with and without the fused LeakyReLU backward)."""
+    x, w = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(1)), rnd(64, 3, 4, 4, seed=2, scale=0.2)
+    dy = rnd(N, 64, S // 2, S // 2, seed=3)
+    xg, wg = x.to(DEV), w.to(DEV)
+    y32 = ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2)
+    ops.ACT16 = True
+    try:
+        y16 = ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2)
+    finally:
+        ops.ACT16 = False
+    assert y16.dtype == torch.bfloat16 and ops.is_nhwc(y16)
+    close16(y16, y32, what="c3_fwd bf16 out")
+    dy16 = nhwc16(dy)
+    dy32 = nhwc(dy16.float().cpu())
+    yr32 = nhwc(y16.float().permute(0, 1, 2, 3).cpu())
+    close(ops.c3_dgrad(dy16, wg, ops.ACT_SIGMOID), ops.c3_dgrad(dy32, wg, ops.ACT_SIGMOID), rtol=2e-5, what="c3_dgrad bf16 in")
+    close(ops.c3_dgrad(dy16, wg, ops.ACT_NONE), ops.c3_dgrad(dy32, wg, ops.ACT_NONE), rtol=2e-5, what="c3_dgrad bf16 in (no act)")
+    close(ops.c3_wgrad(dy16, xg), ops.c3_wgrad(dy32, xg), rtol=2e-5, what="c3_wgrad bf16 in")
+    close(ops.c3_wgrad(dy16, xg, act_out=y16, act=ops.ACT_LEAKY, slope=0.2),
+          ops.c3_wgrad(dy32, xg, act_out=yr32, act=ops.ACT_LEAKY, slope=0.2), rtol=2e-5, what="c3_wgrad_act bf16 in")
+    g16 = ops.act_bwd(dy16, y16, ops.ACT_LEAKY, 0.2)
+    g32 = ops.act_bwd(dy32, yr32, ops.ACT_LEAKY, 0.2)
+    assert g16.dtype == torch.bfloat16
+    close16(g16, g32, what="act_bwd bf16")
+
+
+def test_fm_bf16_storage():
+    N, C, H = 8, 128, 16
+    r, f_ = rnd(N, C, H, H, seed=1), rnd(N, C, H, H, seed=2)
+    r16, f16 = nhwc16(r), nhwc16(f_)
+    r32, f32 = nhwc(r16.float().cpu()), nhwc(f16.float().cpu())
+    l16, d16, _, _ = ops.fm_fwd(r16, f16)
+    l32, d32, _, _ = ops.fm_fwd(r32, f32)
+    close(l16.reshape(1), l32.reshape(1), rtol=1e-5, atol=1e-9, what="fm loss")
+    close(d16, d32, rtol=1e-5, what="fm diff")
+    gout = torch.tensor(0.7, device=DEV)
+    a16, b16 = ops.fm_bwd(d16, r16, f16, gout, True, True)
+    a32, b32 = ops.fm_bwd(d32, r32, f32, gout, True, True)
+    assert a16.dtype == torch.bfloat16 and b16.dtype == torch.bfloat16
+    close16(a16, a32, what="fm dreal")
+    close16(b16, b32, what="fm dfake")
