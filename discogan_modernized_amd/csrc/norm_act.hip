@@ -276,6 +276,49 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
     }
 }
 
+// bf16 storage, forward apply with the reduction passes' geometry: fixed channels per thread (parameters loaded once, no
+// 64-bit modulo per access), U rows in flight
+__global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const __bf16* __restrict__ y, __bf16* __restrict__ z, int M, int C,
+                                                           int rchunks, int TX, const float* __restrict__ saved,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int act, float slope) {
+    constexpr int V = 8, U = 4;
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * V;
+    if (c >= C) return;
+    const int rows_per = (M + rchunks - 1) / rchunks;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float mean[V], gs[V], b[V];
+    bn_ldp<V>(saved + c, mean);
+    bn_ldp<V>(saved + C + c, b);
+    bn_ldp<V>(gamma + c, gs);
+#pragma unroll
+    for (int j = 0; j < V; ++j) gs[j] *= b[j];
+    bn_ldp<V>(beta + c, b);
+    const __bf16* py = y + c;
+    __bf16* pz = z + c;
+    int r = r0 + ty;
+    for (; r + (U - 1) * TY < r1; r += U * TY) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bn_ld(py + (long)(r + u * TY) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[u][j] = dg_apply_act(bn_norm(v[u][j], mean[j], gs[j], b[j]), act, slope);
+            bn_st(pz + (long)(r + u * TY) * C, v[u]);
+        }
+    }
+    for (; r < r1; r += TY) {
+        float v[V];
+        bn_ld(py + (long)r * C, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = dg_apply_act(bn_norm(v[j], mean[j], gs[j], b[j]), act, slope);
+        bn_st(pz + (long)r * C, v);
+    }
+}
+
 __device__ __forceinline__ float act_grad(float u, int act, float slope) {
     // derivative taken from the sign of the activation input == sign of its output (in-place
     // semantics of the reference: leaky_relu_backward(result), threshold_backward(result))
@@ -332,8 +375,26 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
                 bn_ld(py + (long)(r + u * TY) * C, v[u]);
                 bn_ld(pd + (long)(r + u * TY) * C, d[u]);
             }
+            if constexpr (V == 8) {
+                // bf16 storage: the inputs carry 8 significant bits, so the U terms of a batch are summed in fp32 and only the
+                // batch sums go into the fp64 accumulators (the per-element fp64 chain made this pass compute-bound)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float ls = 0.f, lq = 0.f;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float um = v[u][j] - mean[j];
+                        const float gg = d[u][j] * act_grad(fmaf(um, gs[j], b[j]), act, slope);
+                        ls += gg;
+                        lq = fmaf(gg, um * istd[j], lq);
+                    }
+                    s[j] += (double)ls;
+                    q[j] += (double)lq;
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) acc(v[u], d[u]);
+            }
         }
         for (; r < r1; r += TY) {
             float v[V], d[V];
@@ -407,6 +468,69 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     coef[C + c] = q / M;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+}
+
+// bf16 storage: dz, y in, dy out, all bf16.  The reduction geometry of the partial pass (fixed channels per thread, TY row
+// lanes, U rows in flight), so the per-channel constants are loaded ONCE per thread; fp32 arithmetic in the subtraction-first
+// form  dy = gs * ((g - c1) - (y - mean) * istd * c2)  -- the inputs carry 8 significant bits and dy is rounded to 8, which
+// is what bounds the result, not the fp32 evaluation (the fp32-storage kernel below keeps fp64: there the fp32 chain would be
+// the largest error).  Measured: the fp64 form ran at the SAME element rate as the fp32-storage kernel, i.e. compute-bound.
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const __bf16* __restrict__ dz, const __bf16* __restrict__ y,
+                                                             __bf16* __restrict__ dy, int M, int C, int rchunks, int TX,
+                                                             const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const double* __restrict__ coef,
+                                                             int act, float slope) {
+    constexpr int V = 8, U = 4;
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * V;
+    if (c >= C) return;
+    const int rows_per = (M + rchunks - 1) / rchunks;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float mean[V], gs[V], b[V], c1[V], k2[V];
+    bn_ldp<V>(saved + c, mean);
+    bn_ldp<V>(saved + C + c, k2);          // invstd for now
+    bn_ldp<V>(gamma + c, gs);
+    bn_ldp<V>(beta + c, b);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        gs[j] *= k2[j];
+        c1[j] = (float)coef[c + j];
+        k2[j] = (float)((double)gs[j] * (double)k2[j] * coef[C + c + j]);      // gs * invstd * c2
+    }
+    auto one = [&](const float (&v)[V], const float (&d)[V], float (&o)[V]) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float um = v[j] - mean[j];
+            const float gg = d[j] * act_grad(fmaf(um, gs[j], b[j]), act, slope);
+            o[j] = fmaf(-um, k2[j], gs[j] * (gg - c1[j]));
+        }
+    };
+    const __bf16* py = y + c;
+    const __bf16* pd = dz + c;
+    __bf16* po = dy + c;
+    int r = r0 + ty;
+    for (; r + (U - 1) * TY < r1; r += U * TY) {
+        float v[U][V], d[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bn_ld(py + (long)(r + u * TY) * C, v[u]);
+            bn_ld(pd + (long)(r + u * TY) * C, d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float o[V];
+            one(v[u], d[u], o);
+            bn_st(po + (long)(r + u * TY) * C, o);
+        }
+    }
+    for (; r < r1; r += TY) {
+        float v[V], d[V], o[V];
+        bn_ld(py + (long)r * C, v);
+        bn_ld(pd + (long)r * C, d);
+        one(v, d, o);
+        bn_st(po + (long)r * C, o);
+    }
 }
 
 // T: element type of dz / y / dy.  D16 (fp32 only): also write a bf16 shadow of dy
@@ -555,6 +679,13 @@ static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const floa
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
     const long totalv = (long)M * C / V;
+    if constexpr (V == 8) {
+        const BnGrid g = bn_grid(M, C, V);
+        hipLaunchKernelGGL(bn_act_fwd16_kernel, dim3(g.cchunks, g.rchunks), dim3(256), 0, (hipStream_t)stream, y, z, M, C, g.rchunks, g.tx,
+                           saved, gamma, beta, act, slope);
+        DG_CHECK_LAUNCH("bn_act_fwd16");
+        return DG_OK;
+    }
     if constexpr (V == 4) {
         if (z16) {
             hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, true>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
@@ -611,6 +742,11 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, dy, M, C, rc, g.tx, saved, gamma, beta,
+                           (const double*)coef, act, slope);
+        DG_CHECK_LAUNCH("bn_bwd_apply16");
+        return DG_OK;
     }
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
                        beta, (const double*)coef, act, slope, (__bf16*)nullptr);

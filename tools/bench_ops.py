@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bf16", type=int, default=0)
     ap.add_argument("--shadow", type=int, default=0, help="with --bf16 1: hand the conv kernels bf16 shadow operands (what the trainer does)")
+    ap.add_argument("--act16", type=int, default=0, help="time the BatchNorm / edge kernels on bf16-stored feature maps instead of the fp32 ones")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
@@ -89,7 +90,7 @@ def main():
         print(f"conv s2 {C:4d}->{K:4d} @{H:3d} [{amb:7.1f} MB] {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}")
         tot["fwd"] += t1; tot["dgrad"] += t2; tot["wgrad"] += t3; totf += gf
         h //= 2
-    if only:
+    if only and not a.act16:
         print(f"interior totals: {totf:.1f} GFLOP each dir | fwd {tot['fwd']:.3f} ms ({totf / max(tot['fwd'], 1e-9):.1f} TF/s) dgrad {tot['dgrad']:.3f} ms ({totf / max(tot['dgrad'], 1e-9):.1f}) wgrad {tot['wgrad']:.3f} ms ({totf / max(tot['wgrad'], 1e-9):.1f})")
         return
     ops.SHADOW = False
@@ -115,6 +116,29 @@ def main():
     t3 = timeit(lambda: ops.c3_wgrad(dy, x))
     mb = (x.numel() + dy.numel()) * 4 / 1e6
     print(f"edge c3    3->{K:4d} @{S:3d}       {gf:9.2f} | {t1:8.3f} {gf / t1:6.1f} | {t2:8.3f} {gf / t2:6.1f} | {t3:8.3f} {gf / t3:6.1f}   ({mb:.0f} MB -> {mb / t1 / 1e3:.2f}/{mb / t2 / 1e3:.2f}/{mb / t3 / 1e3:.2f} TB/s)")
+    if a.act16:
+        # bf16-stored feature maps: every BN shape of the nets through the typed kernels, and the edge kernels with a bf16 NHWC side
+        for C, H in [(ch[0], S // 2)] + [(ch[i], S // (4 << (i - 1))) for i in range(1, len(ch))]:
+            if H < 1:
+                continue
+            y = ops.empty_nhwc(N, C, H, H, dev, torch.bfloat16).normal_()
+            dz = ops.empty_nhwc(N, C, H, H, dev, torch.bfloat16).normal_()
+            g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            saved = ops.bn_train_stats(y, None, None, None, 1e-5, 0.1)
+            mbt = y.numel() * 2 / 1e6
+            t1 = timeit(lambda: ops.bn_train_stats(y, None, None, None, 1e-5, 0.1))
+            t2 = timeit(lambda: ops.bn_act_fwd(y, saved, g, b, ops.ACT_LEAKY, 0.2))
+            t3 = timeit(lambda: ops.bn_act_bwd(dz, y, saved, g, b, ops.ACT_LEAKY, 0.2))
+            print(f"bn16 [{N}x{H}x{H}x{C}] {mbt:.0f} MB: stats {t1:.3f} ms ({mbt / t1 / 1e3:.2f} TB/s)  apply {t2:.3f} ms ({2 * mbt / t2 / 1e3:.2f} TB/s)  bwd {t3:.3f} ms ({5 * mbt / t3 / 1e3:.2f} TB/s)")
+        ops.ACT16 = True
+        dy16 = ops.empty_nhwc(N, K, S // 2, S // 2, dev, torch.bfloat16).normal_()
+        t1 = timeit(lambda: ops.c3_fwd(x, w, ops.ACT_LEAKY, 0.2))
+        t2 = timeit(lambda: ops.c3_dgrad(dy16, w, ops.ACT_SIGMOID))
+        t3 = timeit(lambda: ops.c3_wgrad(dy16, x))
+        ops.ACT16 = False
+        mb1, mb2 = x.numel() * 4 / 1e6, dy16.numel() * 2 / 1e6
+        print(f"edge c3 bf16 side: fwd {t1:.3f} ms ({(mb1 + mb2) / t1 / 1e3:.2f} TB/s)  dgrad {t2:.3f} ms ({(mb1 + mb2) / t2 / 1e3:.2f} TB/s)  wgrad {t3:.3f} ms ({(mb1 + mb2) / t3 / 1e3:.2f} TB/s)")
+        return
     # BN + act streaming, every BN shape of the nets (decoder 64ch @S/2 ... bottleneck)
     for C, H in [(ch[0], S // 2)] + [(ch[i], S // (4 << (i - 1))) for i in range(1, len(ch))]:
         if H < 1:
