@@ -190,10 +190,16 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
 #define CS_LDP 52               // floats per pixel of the P image (48 + 4: the four k-quarters of a wave store to disjoint banks)
 // IN16: dy is bf16 -- a lane's 16 k values of a pixel are 32 contiguous bytes (two 16-byte loads), expanded to fp32 by a
 // shift / a mask per value right in front of the MFMA that takes it
-template <bool IN16>
+// MF16 (with IN16, option "bf16" = 1): the dense GEMM runs on v_mfma_f32_16x16x32_bf16 -- the bf16 dy values ARE the A operand
+// (lane (pixel p, kq) holds k = 32 st + 8 kq + j: two 16-byte loads, no unpacking), the weights are rounded to bf16 once per
+// lane; 12 MFMAs of 16 cycles per tile and wave instead of 96 of 32.
+template <bool IN16, bool MF16 = false>
 __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                   float* __restrict__ dx, int N, int H, int W, int act,
                                                                   int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
+    static_assert(!MF16 || IN16, "the bf16 MFMA form takes a bf16 dy");
+    typedef __bf16 bf16x8_d __attribute__((ext_vector_type(8)));
+    typedef float f32x8_d __attribute__((ext_vector_type(8)));
     __shared__ __attribute__((aligned(16))) float Ps[CS_PR * CS_PC * CS_LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, kq = lane >> 4;
@@ -201,11 +207,23 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
     // B operand: W[k][col], col = c*16 + r*4 + s (the weight tensor's own order).  MFMA step s multiplies the four k values
     // 16*kq + s (kq = lane >> 4): the k order inside the GEMM is free as long as A uses the same one, and this one lets
     // every lane fetch its 16 A values of a pixel as 64 contiguous bytes.
-    float breg[3][16];
+    float breg[3][MF16 ? 1 : 16];
+    bf16x8_d breg16[3][2];
 #pragma unroll
-    for (int blk = 0; blk < 3; ++blk)
+    for (int blk = 0; blk < 3; ++blk) {
+        if constexpr (MF16) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) breg[blk][s] = w[(16 * kq + s) * 48 + blk * 16 + p];
+            for (int st = 0; st < 2; ++st) {
+                f32x8_d t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = w[(32 * st + 8 * kq + j) * 48 + blk * 16 + p];
+                breg16[blk][st] = __builtin_convertvector(t, bf16x8_d);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) breg[blk][s] = w[(16 * kq + s) * 48 + blk * 16 + p];
+        }
+    }
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dybytes, 0x00020000);
     constexpr int OOR = (int)0x80000000;
     f32x4 areg[2][2][4];            // [set][row group][4 x float4 = 16 k values]
@@ -215,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
         for (int g = 0; g < 2; ++g) {
             const int a = tr * CS_TR - 1 + wave + 4 * g, b = tc * CS_TC - 1 + p;
             const bool ok = t < ntiles && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
-            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + 16 * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
+            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + (MF16 ? 8 : 16) * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
 #pragma unroll
             for (int j = 0; j < (IN16 ? 2 : 4); ++j)
-                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 16 * j, 0, 0));
+                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + (MF16 ? 64 : 16) * j, 0, 0));
         }
     };
     fetch(blockIdx.x, 0);
@@ -232,6 +250,16 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int blk = 0; blk < 3; ++blk) acc[g][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (MF16) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int blk = 0; blk < 3; ++blk)
+                        acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_d, areg[S][g][st]), breg16[blk][st],
+                                                                              acc[g][blk], 0, 0, 0);
+        } else
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
@@ -306,11 +334,14 @@ static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float
             const long ntiles = (long)N * tiles_r * tiles_c;
             DG_CHECK_ARG(ntiles < (1L << 30), "dg_conv4x4s2_c3_dgrad: too many tiles");
             const int grid = (int)(ntiles < 512 ? ntiles : 512);
-            if (dy_bf16)
-                hipLaunchKernelGGL(c3_dgrad_scatter_kernel<true>, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+            if (dy_bf16 && dg_get_option(DG_OPT_BF16) == 1)      // bf16 matrix path: bf16 MFMA
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, true>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
+            else if (dy_bf16)
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
             else
-                hipLaunchKernelGGL(c3_dgrad_scatter_kernel<false>, dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
             DG_CHECK_LAUNCH("c3_dgrad_scatter");
             return DG_OK;
@@ -450,6 +481,105 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __rest
     }
 }
 
+// ---- forward, K == 64, on the bf16 matrix path (option "bf16" = 1): v_mfma_f32_32x32x16_bf16 -------------------------
+// Same per-wave streaming structure, but the image and the weights are rounded to bf16 (RNE) on the way into the MFMA --
+// like every other convolution of the bf16 path -- and the 48-deep reduction is THREE k16 steps (one input channel each)
+// instead of 24 fp32 steps: 6 MFMAs of 32 cycles per 32 pixels instead of 48 of 64 (the fp32 kernel is matrix-bound at
+// ~100 us for 32 x 512 x 512; this one is bound by its loads and stores).  Lane (pixel p, half h) owns k = 16 c + 8 h + j,
+// j = 0..7 = filter rows 2h, 2h+1 x the 4 filter columns: two rows of 4 CONSECUTIVE input floats (an aligned 8-byte pair
+// plus the two outer dwords); padding rows / columns and out-of-range pixels read out of range (zeros).
+typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
+typedef float f32x8_e __attribute__((ext_vector_type(8)));
+typedef float f32x2_g __attribute__((ext_vector_type(2)));
+template <int ACT, bool OUT16>
+__global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
+                                                                 long npix, int ngroups, float slope, int xbytes) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // B operand: block nb, column p = channel (OUT16 ? 2p + nb : 32 nb + p); k = 16 c + 8 h + j are 8 consecutive weights
+    bf16x8_e wb[2][3];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* wp = w + (OUT16 ? 2 * p + nb : nb * 32 + p) * 48 + c * 16 + 8 * h;
+            const f32x4 lo = *(const f32x4*)wp, hi = *(const f32x4*)(wp + 4);
+            wb[nb][c] = __builtin_convertvector((f32x8_e){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, bf16x8_e);
+        }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+    const int HW4 = H * W * 4;
+    constexpr int BIG = 0x40000000;
+    // [set][channel][filter row 2h + rr]: the 4 consecutive input floats ix = 2ox-1 .. 2ox+2 as {left, pair, right}: the pair
+    // (2ox, 2ox+1) is an aligned 8-byte load, the two outer columns are single dwords whose offset goes out of range when the
+    // column is padding (zeros, no masking in registers)
+    float al[2][3][2], ar[2][3][2];
+    f32x2_g ap[2][3][2];
+    auto gather = [&](int g, int set) {
+        const int pix = g * 32 + p;
+        const bool okp = g < ngroups && pix < (int)npix;
+        const int ox = pix & (Wo - 1), oy = (pix >> lgWo) & (Ho - 1), n = pix >> (lgWo + lgHo);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int iy = 2 * oy - 1 + 2 * h + rr;
+            const bool okr = okp && (unsigned)iy < (unsigned)H;
+            const int pb = okr ? n * 3 * HW4 + iy * W * 4 + ox * 8 : BIG;
+            const int lb = (okr && ox != 0) ? pb - 4 : BIG;
+            const int rb = (okr && ox != Wo - 1) ? pb + 8 : BIG;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                al[set][c][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, lb, c * HW4, 0));
+                ap[set][c][rr] = __builtin_bit_cast(f32x2_g, __builtin_amdgcn_raw_buffer_load_b64(rx, pb, c * HW4, 0));
+                ar[set][c][rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, rb, c * HW4, 0));
+            }
+        }
+    };
+    int g = wave;
+    if (g < ngroups) gather(g, 0);
+    auto body = [&](auto PB, int gcur) {
+        constexpr int P = decltype(PB)::value;
+        gather(gcur + nwaves, P ^ 1);          // prefetch (out of range past the end)
+        f32x16 acc0 = {0.f}, acc1 = {0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bf16x8_e av = __builtin_convertvector((f32x8_e){al[P][c][0], ap[P][c][0][0], ap[P][c][0][1], ar[P][c][0],
+                                                                  al[P][c][1], ap[P][c][1][0], ap[P][c][1][1], ar[P][c][1]}, bf16x8_e);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wb[0][c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wb[1][c], acc1, 0, 0, 0);
+        }
+        const long pix0 = (long)gcur * 32;
+        const bool whole = pix0 + 32 <= npix;
+        if constexpr (OUT16) {
+            typedef __bf16 bf16x2_e __attribute__((ext_vector_type(2)));
+            typedef float f32x2_e __attribute__((ext_vector_type(2)));
+            unsigned* o16 = (unsigned*)((__bf16*)y + (pix0 + h * 4) * CF_K + 2 * p);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                const f32x2_e pr = {dg_apply_act(acc0[v], ACT, slope), dg_apply_act(acc1[v], ACT, slope)};
+                if (whole || pix0 + h * 4 + i < npix)
+                    o16[i * (CF_K / 2)] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_e));
+            }
+        } else {
+            float* o = y + (pix0 + h * 4) * CF_K + p;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                if (whole || pix0 + h * 4 + i < npix) {
+                    o[i * CF_K] = dg_apply_act(acc0[v], ACT, slope);
+                    o[i * CF_K + 32] = dg_apply_act(acc1[v], ACT, slope);
+                }
+            }
+        }
+    };
+    for (; g < ngroups; g += 2 * nwaves) {
+        body(std::integral_constant<int, 0>{}, g);
+        if (g + nwaves < ngroups) body(std::integral_constant<int, 1>{}, g + nwaves);
+    }
+}
+
 extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc_v, int y_bf16, int N, int H, int W, int act,
                                      float slope, hipStream_t st) {
     float* y_nhwc = (float*)y_nhwc_v;
@@ -469,6 +599,22 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
       (void)once; }                                                                                                     \
     hipLaunchKernelGGL((c3_fwd_mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W, \
                        dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
+    if (dg_get_option(DG_OPT_BF16) == 1 && dg_get_option(DG_OPT_KT) != 16) {     // bf16 matrix path ("kt" 16 keeps the fp32-MFMA kernel testable there)
+#define CF16_LAUNCH(ACT, O16)                                                                                              \
+        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W,    \
+                           dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
+        if (y_bf16) {
+            if (act == DG_ACT_LEAKY) { CF16_LAUNCH(DG_ACT_LEAKY, true); }
+            else if (act == DG_ACT_RELU) { CF16_LAUNCH(DG_ACT_RELU, true); }
+            else { CF16_LAUNCH(DG_ACT_NONE, true); }
+        } else {
+            if (act == DG_ACT_LEAKY) { CF16_LAUNCH(DG_ACT_LEAKY, false); }
+            else if (act == DG_ACT_RELU) { CF16_LAUNCH(DG_ACT_RELU, false); }
+            else { CF16_LAUNCH(DG_ACT_NONE, false); }
+        }
+#undef CF16_LAUNCH
+        return DG_OK;
+    }
     if (y_bf16) {
         if (act == DG_ACT_LEAKY) { CF_LAUNCH(DG_ACT_LEAKY, true); }
         else if (act == DG_ACT_RELU) { CF_LAUNCH(DG_ACT_RELU, true); }

@@ -706,3 +706,36 @@ def test_fm_bf16_storage():
     assert a16.dtype == torch.bfloat16 and b16.dtype == torch.bfloat16
     close16(a16, a32, what="fm dreal")
     close16(b16, b32, what="fm dfake")
+
+
+@pytest.mark.parametrize("N,S", [(2, 16), (3, 64), (1, 128), (5, 32)])
+def test_edge_kernels_on_the_bf16_matrix_path(N, S):
+    """Option "bf16" = 1: the 3-channel forward and (with a bf16 dy) the last-convT forward / conv1 input-grad run on the bf16
+    MFMA with image / dy and weights rounded to bf16 (RNE) -- they must equal the fp64 convolution of the ROUNDED operands at
+    fp32 tolerance (bf16 x bf16 products are exact in fp32), padding rows / columns and ragged groups included."""
+    r = lambda t_: t_.bfloat16().float()
+    x, w = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(1)), rnd(64, 3, 4, 4, seed=2, scale=0.2)
+    dy = rnd(N, 64, S // 2, S // 2, seed=3)
+    yr = TF.leaky_relu(TF.conv2d(r(x).double(), r(w).double(), stride=2, padding=1), 0.2).float()
+    yr_none = TF.conv2d(r(x).double(), r(w).double(), stride=2, padding=1).float()
+    dxr = TF.conv_transpose2d(r(dy).double(), r(w).double(), stride=2, padding=1)
+    xg, wg = x.to(DEV), w.to(DEV)
+    _lib.set_option("bf16", 1)
+    try:
+        close(ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2), yr, what="c3_fwd bf16 MFMA, fp32 out")
+        close(ops.c3_fwd(xg, wg, ops.ACT_NONE, 0.2), yr_none, what="c3_fwd bf16 MFMA, no act")
+        ops.ACT16 = True
+        y16 = ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2)
+        ops.ACT16 = False
+        assert y16.dtype == torch.bfloat16
+        close16(y16, yr, extra=2e-5, what="c3_fwd bf16 MFMA, bf16 out")
+        dy16 = nhwc16(dy)
+        close(ops.c3_dgrad(dy16, wg, ops.ACT_NONE), dxr.float(), rtol=2e-5, what="c3_dgrad bf16 MFMA")
+        close(ops.c3_dgrad(dy16, wg, ops.ACT_SIGMOID), torch.sigmoid(dxr).float(), rtol=2e-5, what="c3_dgrad bf16 MFMA + sigmoid")
+        # the fp32-MFMA kernels stay reachable on this path (option kt = 16 for the forward)
+        _lib.set_option("kt", 16)
+        close(ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2), TF.leaky_relu(TF.conv2d(x.double(), w.double(), stride=2, padding=1), 0.2).float(), what="c3_fwd fp32 MFMA")
+    finally:
+        ops.ACT16 = False
+        _lib.set_option("kt", 0)
+        _lib.set_option("bf16", 0)

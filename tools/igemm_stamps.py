@@ -9,10 +9,18 @@ from discogan_modernized_amd import ops, _lib
 
 op = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 C, K, H, N = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (64, 128, 32, 256)
+MODE = sys.argv[6] if len(sys.argv) > 6 else "f32"     # f32 | bf16 (fp32 tensors, bf16 tiles) | x3 | dma (bf16 tensors in and out: LDS-DMA kernel where the shape allows)
 dev = "cuda"
-x = ops.empty_nhwc(N, C, H, H, dev).normal_()
+_lib.set_option("bf16", {"f32": 0, "bf16": 1, "x3": 2, "dma": 1}[MODE])
+adt = torch.bfloat16 if MODE == "dma" else torch.float32
+x = ops.empty_nhwc(N, C, H, H, dev, adt).normal_()
 w = ops.krsc_param(torch.randn(K, C, 4, 4, device=dev) * 0.05)
-dy = ops.empty_nhwc(N, K, H // 2, H // 2, dev).normal_()
+dy = ops.empty_nhwc(N, K, H // 2, H // 2, dev, adt).normal_()
+if MODE == "dma":
+    ops.SHADOW = ops.ACT16 = True
+    w16 = torch.empty_like(w, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+    ops.f32_to_bf16(w, w16)
+    w._dg_bf16, w._dg_bf16_ver = w16, w._version
 fn = {"fwd": lambda: ops.conv_fwd(x, w, 2, 1), "dgrad": lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1),
       "wgrad": lambda: ops.conv_wgrad(dy, x, 2, 1)}[op]
 for _ in range(5):
