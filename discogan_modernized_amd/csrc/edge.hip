@@ -782,6 +782,134 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __re
     for (int e = tid; e < 64 * 48; e += 256) slab[e] = ((slabS[0][e] + slabS[1][e]) + slabS[2][e]) + slabS[3][e];
 }
 
+// ---- weight gradient on the bf16 matrix path (option "bf16" = 1, bf16 dy): v_mfma_f32_32x32x16_bf16 ---------------------
+// Same per-wave streaming (no LDS, no barriers), but one MFMA k-step is SIXTEEN pixels: lane (row l31, half lh) supplies 8
+// consecutive pixels 8 lh .. 8 lh + 7 of the batch.  A (dy^T): one dword per pixel = channels (2 l31, 2 l31 + 1), the two
+// parities are split into the two row blocks with v_perm_b32 (block i, row rho <-> channel 2 rho + i, as in the IN16 kernel
+// above); B (im2col of the fp32 image): 8 strided floats per column, rounded to bf16.  4 MFMAs of 32 cycles per 16 pixels
+// instead of 32 of 64 -- the kernel is bound by its gathers, not by the matrix pipe.
+typedef __bf16 bf16x8_w __attribute__((ext_vector_type(8)));
+typedef float f32x8_w __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_w __attribute__((ext_vector_type(4)));
+template <bool FACT>
+__global__ __launch_bounds__(256, 2) void c3_wgrad_bf16mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   float* __restrict__ part, int N, int H, int W, int K,
+                                                                   int lgHo, int lgWo, long npix, int pix_per_wave,
+                                                                   const float* __restrict__ act_out, float slope) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int kg = blockIdx.y;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int jr[2], js[2], joff[2];
+    bool jok[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int j = jn * 32 + l31;
+        jok[jn] = j < 48;
+        const int c = (j >> 4) % 3;
+        jr[jn] = (j >> 2) & 3;
+        js[jn] = j & 3;
+        joff[jn] = (c * H + jr[jn]) * W + js[jn];
+    }
+    const long wave_id = (long)blockIdx.x * 4 + wave;
+    const long p_begin = wave_id * pix_per_wave;
+    const long p_end = min(npix, p_begin + pix_per_wave);
+    constexpr int BIG = 0x40000000;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(npix * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, (int)(npix * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, N * 3 * H * W * 4, 0x00020000);
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, int off) -> unsigned {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    };
+    unsigned wa[2][8], wo[2][FACT ? 8 : 1];
+    float fb[2][2][8];
+    auto load_batch = [&](int set, long p0) {       // 16 pixels p0 .. p0 + 15; this lane's are p0 + 8 lh + t
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pp = (int)p0 + 8 * lh + t;
+            const bool pok = pp < (int)p_end;
+            const int ox = pp & (Wo - 1), oy = (pp >> lgWo) & (Ho - 1), n = pp >> (lgWo + lgHo);
+            const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+            const int xb = (n * 3 * H + iy0) * W + ix0;
+            const int aoff = pok ? (pp * K + kg * 64 + 2 * l31) * 2 : BIG;
+            wa[set][t] = bload(rdy, aoff);
+            if constexpr (FACT) wo[set][t] = bload(rao, aoff);
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const bool ok = pok && jok[jn] && (unsigned)(iy0 + jr[jn]) < (unsigned)H && (unsigned)(ix0 + js[jn]) < (unsigned)W;
+                fb[set][jn][t] = __builtin_bit_cast(float, bload(rx, ok ? (xb + joff[jn]) * 4 : BIG));
+            }
+        }
+    };
+    auto mma_batch = [&](int set) {
+        unsigned w8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            unsigned wv = wa[set][t];
+            if constexpr (FACT) {     // dy * act'(act_out) per channel of the pair; the product is rounded to bf16 again (RNE)
+                const unsigned ov = wo[set][t];
+                float a0 = __builtin_bit_cast(float, wv << 16), a1 = __builtin_bit_cast(float, wv & 0xffff0000u);
+                a0 = __builtin_bit_cast(float, ov << 16) > 0.f ? a0 : a0 * slope;
+                a1 = __builtin_bit_cast(float, ov & 0xffff0000u) > 0.f ? a1 : a1 * slope;
+                typedef __bf16 bf16x2_w __attribute__((ext_vector_type(2)));
+                typedef float f32x2_w __attribute__((ext_vector_type(2)));
+                wv = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_w){a0, a1}, bf16x2_w));
+            }
+            w8[t] = wv;
+        }
+        bf16x8_w fa[2], fbv[2];
+        u32x4_w ev, od;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {     // pixels 2u, 2u+1: low halves = even channel, high halves = odd channel
+            ev[u] = __builtin_amdgcn_perm(w8[2 * u + 1], w8[2 * u], 0x05040100u);
+            od[u] = __builtin_amdgcn_perm(w8[2 * u + 1], w8[2 * u], 0x07060302u);
+        }
+        fa[0] = __builtin_bit_cast(bf16x8_w, ev);
+        fa[1] = __builtin_bit_cast(bf16x8_w, od);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            f32x8_w t8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) t8[t] = fb[set][jn][t];
+            fbv[jn] = __builtin_convertvector(t8, bf16x8_w);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fbv[jn], acc[i][jn], 0, 0, 0);
+    };
+    load_batch(0, p_begin);
+    for (long p0 = p_begin; p0 < p_end; p0 += 32) {
+        load_batch(1, p0 + 16);
+        mma_batch(0);
+        load_batch(0, p0 + 32);
+        mma_batch(1);
+    }
+    __shared__ float slabS[4][64 * 48];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int k = 2 * rho + i;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int j = jn * 32 + l31;
+                if (j < 48) slabS[wave][k * 48 + j] = acc[i][jn][r];
+            }
+        }
+    __syncthreads();
+    float* slab = part + ((long)blockIdx.x * K + kg * 64) * 48;
+    for (int e = tid; e < 64 * 48; e += 256) slab[e] = ((slabS[0][e] + slabS[1][e]) + slabS[2][e]) + slabS[3][e];
+}
+
 // fixed-order reduction over slabs: block = 16 outputs x 16 slab lanes
 __global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int nslabs, int total, int accumulate) {
@@ -858,7 +986,14 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
                        K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
     if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
-    if (io_bf16 && fact) {
+    if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1) {        // bf16 matrix path: bf16 MFMA
+        if (fact)
+            hipLaunchKernelGGL(c3_wgrad_bf16mfma_kernel<true>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
+                               K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+        else
+            hipLaunchKernelGGL(c3_wgrad_bf16mfma_kernel<false>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
+                               K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+    } else if (io_bf16 && fact) {
         hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, true, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
                            K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
     } else if (io_bf16) {

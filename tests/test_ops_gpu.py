@@ -732,6 +732,14 @@ def test_edge_kernels_on_the_bf16_matrix_path(N, S):
         dy16 = nhwc16(dy)
         close(ops.c3_dgrad(dy16, wg, ops.ACT_NONE), dxr.float(), rtol=2e-5, what="c3_dgrad bf16 MFMA")
         close(ops.c3_dgrad(dy16, wg, ops.ACT_SIGMOID), torch.sigmoid(dxr).float(), rtol=2e-5, what="c3_dgrad bf16 MFMA + sigmoid")
+        # weight gradient on the bf16 MFMA: rounded image x bf16 dy; with the fused LeakyReLU backward dy * act'(y) is rounded again
+        dwr = torch.nn.grad.conv2d_weight(r(x).double(), w.shape, r(dy).double(), stride=2, padding=1).float()
+        close(ops.c3_wgrad(dy16, xg), dwr, rtol=2e-5, what="c3_wgrad bf16 MFMA")
+        gm = (dy16.float() * torch.where(y16.float() > 0, 1.0, 0.2)).bfloat16().float().cpu()
+        dwr2 = torch.nn.grad.conv2d_weight(r(x).double(), w.shape, gm.double(), stride=2, padding=1).float()
+        close(ops.c3_wgrad(dy16, xg, act_out=y16, act=ops.ACT_LEAKY, slope=0.2), dwr2, rtol=2e-5, what="c3_wgrad_act bf16 MFMA")
+        acc0 = torch.ones(64, 3, 4, 4, device=DEV)
+        close(ops.c3_wgrad(dy16, xg, out=acc0, accumulate=True), dwr + 1.0, rtol=2e-5, what="c3_wgrad bf16 MFMA accumulate")
         # the fp32-MFMA kernels stay reachable on this path (option kt = 16 for the forward)
         _lib.set_option("kt", 16)
         close(ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2), TF.leaky_relu(TF.conv2d(x.double(), w.double(), stride=2, padding=1), 0.2).float(), what="c3_fwd fp32 MFMA")
