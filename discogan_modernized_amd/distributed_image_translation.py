@@ -67,7 +67,8 @@ def main_worker(local_rank, args):
         device = torch.device("cuda", torch.cuda.current_device())
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
                                   process_group=pg, use_graph=not args.no_graph,
-                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), comm=getattr(args, "comm", "auto"))
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), act_dtype=getattr(args, "act_dtype", "f32"),
+                                  comm=getattr(args, "comm", "auto"))
         load_checkpoints(args, trainer)
         if args.distributed:
             dist.barrier()

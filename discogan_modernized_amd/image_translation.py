@@ -80,6 +80,9 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
     p.add_argument("--mfma_dtype", type=str, default="f32", choices=["f32", "bf16", "f32x3"],
                    help="bf16: conv operands rounded to bf16 on the matrix cores, fp32 accumulate/BatchNorm/weights/Adam; "
                         "f32x3: fp32-accurate products from three bf16 planes per operand (six bf16 MFMAs per block)")
+    p.add_argument("--act_dtype", type=str, default="f32", choices=["f32", "bf16"],
+                   help="with --mfma_dtype bf16: feature maps and their gradients stored in bf16 (fp32 BatchNorm statistics and arithmetic, "
+                        "fp32 weights / parameter gradients / Adam)")
     return p
 
 
@@ -166,7 +169,8 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
     if trainer is None:
         trainer = DiscoGANTrainer(args, device=device, image_size=args.image_size, seed=args.seed,
                                   process_group=process_group, use_graph=not args.no_graph,
-                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), comm=getattr(args, "comm", "auto"))
+                                  mfma_dtype=getattr(args, "mfma_dtype", "f32"), act_dtype=getattr(args, "act_dtype", "f32"),
+                                  comm=getattr(args, "comm", "auto"))
     data_A, data_B = load_domains(args, device, rank, world_size)
     data_size = min(len(data_A), len(data_B))
     n_batches = batches_per_epoch(args, data_size, world_size)
