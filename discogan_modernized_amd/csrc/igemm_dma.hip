@@ -25,6 +25,7 @@
 // Epilogue, split-K slabs and the blockIdx -> tile orders are those of igemm.hip.
 #include "igemm_args.h"
 #include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -32,11 +33,21 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 #define DG_NEG_BIG (-(1 << 28))
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- `#pragma unroll` gives up on the 64-MFMA
+// body of the 16x16x32 K-tile (pragma-unroll-threshold), and a runtime index would put the accumulator blocks in scratch
+template <int... Q, typename F>
+__device__ __forceinline__ void dg_static_for(std::integer_sequence<int, Q...>, F&& f) {
+    (f(std::integral_constant<int, Q>{}), ...);
+}
 #ifndef DG_DMA_SPREAD_FETCH
 #define DG_DMA_SPREAD_FETCH 0
 #endif
 
-template <int MODE, int WM, int WN>
+// M16: the MFMA shape.  false: v_mfma_f32_32x32x16_bf16 (4 x 2 accumulator blocks of 32x32 per wave); true:
+// v_mfma_f32_16x16x32_bf16 (8 x 4 blocks of 16x16, the same 128 accumulator registers, the same LDS traffic).  The loop is
+// power-limited (the chip holds 1.6-1.9 GHz under it) and the 16x16x32 shape delivers more FLOP/s at equal cycles
+// (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int MODE, int WM, int WN, bool M16>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_kernel(const IgemmArgs p) {
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
     constexpr int NW = WM * WN;
@@ -121,6 +132,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (p.dbg_zero & 1) ? 0 : (int)p.abytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_zero & 2) ? 0 : (int)p.bbytes, 0x00020000);
 
+    // granule swizzle of a reduction-major image row k: the four rows of a transposed-read block go to four different 64-B bank
+    // segments; with the 16x16x32 fragments a 32-lane half reads two 4-row blocks 8 rows apart in the same 16 columns, which
+    // the extra bit puts into the two 32-B halves of the segment
+    auto kmswz = [](int k) -> int { return ((k & 3) << 2) ^ (M16 ? ((k >> 3) & 1) << 1 : 0); };
     // ---- per-lane source descriptors of this wave's DMA pieces (fixed over the K loop) --------------------------
     // k-contiguous image: piece pq covers rows 8 pq .. 8 pq + 7; lane L lands in (row 8 pq + L / 8, slot L % 8) and fetches
     // granule slot ^ swizzle(row).  Reduction-major image of NC columns: GR = NC / 8 granules per row, piece pq covers
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
         } else {       // WGRAD: rows = reduction pixels, columns = out channels m0 .. m0 + BM - 1 of dy[pixel][K]
             constexpr int GR = BM / 8, RP = 64 / GR;
             const int krow = pq * RP + lane / GR;
-            const int gc = (lane % GR) ^ ((krow & 3) << 2);
+            const int gc = (lane % GR) ^ kmswz(krow);
             const int col = m0 + gc * 8;
             a_ob[i] = col < K ? (krow * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the tensor: zeros
         }
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
         } else {
             constexpr int GR = BN / 8, RP = 64 / GR;
             const int krow = pq * RP + lane / GR;
-            const int gc = (lane % GR) ^ ((krow & 3) << 2);
+            const int gc = (lane % GR) ^ kmswz(krow);
             const int col = n0 + gc * 8;
             if (MODE == MODE_DGRAD_S2) {
                 b_ob[i] = col < Cc ? (krow * 16 * Cc + col) * 2 : OOR;
@@ -303,9 +318,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     // transposed read (igemm.hip frag_km) from the swizzled reduction-major image; rowb = bytes per k row
     auto frag_km = [&](const char* img, int rowb, int k0, int c0) -> bf16x8 {
         const int kr = k0 + tr_q, col = c0 + tr_c;
-        const char* p0 = img + kr * rowb + ((((col >> 3) ^ ((kr & 3) << 2))) << 4) + (col & 7) * 2;
+        const char* p0 = img + kr * rowb + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * rowb));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // 16x16x32 operand: lane l holds row / column (l & 15), k = 8 (l >> 4) + j of the 32-deep step.  k-contiguous image: one
+    // ds_read_b128 (granule 4 s2 + (l >> 4)); reduction-major image: the 16-lane group l >> 4 transposes the 4-row blocks at
+    // k rows 32 s2 + 8 (l >> 4) and + 4, columns c0 .. c0 + 15
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto frag16_kc = [&](const char* img, int row0, int s2) -> bf16x8 {
+        const int row = row0 + l15;
+        return *(const bf16x8*)(img + row * 128 + (((4 * s2 + l4) ^ ((row >> 1) & 7)) << 4));
+    };
+    auto frag16_km = [&](const char* img, int rowb, int s2, int c0) -> bf16x8 {
+        const int kr = 32 * s2 + 8 * l4 + tr_q, col = c0 + (lane & 3) * 4;
+        const char* p0 = img + kr * rowb + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * rowb));     // kr + 4: same swizzle
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     bf16x8 fa[2][FM], fb[2][FN];
@@ -330,14 +360,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
 #pragma unroll
         for (int f = 0; f < FM + FN; ++f) fetch1(stage, s, set, f);
     };
+    // M16 fragments: the A blocks of a k32 step sit in 8 slots (block i in slot i, fetched 4 blocks ahead), the B blocks of a
+    // step in one of two sets (fetched during blocks 4, 5 of the step before)
+    constexpr int AM = 2 * FM, BNB = 2 * FN;          // 16-row / 16-column blocks per wave: 8 x 4
+    bf16x8 ga[AM], gb[2][BNB];
+    auto fetchA16 = [&](int stage, int s2, int i) {
+        const char* As = smem + stage * A_BYTES;
+        const int row0 = wm * (32 * FM) + i * 16;
+        if (!A_KM) ga[i] = frag16_kc(As, row0, s2);
+        else ga[i] = frag16_km(As, BM * 2, s2, row0);
+    };
+    auto fetchB16 = [&](int stage, int s2, int set, int j) {
+        const char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
+        const int col0 = wn * (32 * FN) + j * 16;
+        if (!B_KM) gb[set][j] = frag16_kc(Bs, col0, s2);
+        else gb[set][j] = frag16_km(Bs, BN * 2, s2, col0);
+    };
 
-    f32x16 acc[FM][FN];
+    f32x16 acc[M16 ? 1 : FM][M16 ? 1 : FN];
+    f32x4 acc16[M16 ? AM : 1][M16 ? BNB : 1];
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < BNB; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     // ---- prologue: tile 0 entirely, the first half of tile 1 --------------------------------------------------------
     if (it_begin < it_end) {
@@ -351,7 +405,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     }
     __builtin_amdgcn_s_barrier();
     if (stp) stp[2] = clock64();
-    fetch(0, 0, 0);
+    if constexpr (M16) {
+#pragma unroll
+        for (int j = 0; j < BNB; ++j) fetchB16(0, 0, 0, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fetchA16(0, 0, i);
+    } else {
+        fetch(0, 0, 0);
+    }
 
     // ---- one K-tile (32 MFMAs per wave): ST = LDS stage of the current tile ------------------------------------------
     constexpr int NMF = 4 * FM * FN;                       // 4 k16 steps x 8 accumulator blocks
@@ -398,9 +459,59 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // ---- M16: one K-tile = 2 k32 steps x (8 x 4) blocks = 64 MFMAs of 16 cycles.  Block (s2, i) runs its 4 MFMAs on A slot i
+    // and B set s2; behind its first MFMA the A block 4 ahead is fetched (the next step's, the next TILE's behind the barrier),
+    // blocks 4 and 5 also fetch the next step's B blocks.  The tile barrier sits in front of block (1, 4) = 16 MFMAs (256
+    // cycles) before the end of the tile: every read of the current stage was issued by block (1, 3).
+    auto body16 = [&](auto ST_) {
+        constexpr int ST = decltype(ST_)::value;
+        constexpr int NMF16 = 2 * AM * BNB, QB16 = NMF16 - 4 * BNB;
+        dg_static_for(std::make_integer_sequence<int, NMF16>{}, [&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            constexpr int s2 = q / (AM * BNB), i = (q / BNB) % AM, j = q % BNB;
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == QB16) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (j == 0) {                                     // A block 4 ahead
+                const int ni = (i + 4) % AM, ns2 = s2 + (i + 4) / AM;          // ns2 == 2: step 0 of the next tile
+                fetchA16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ni);
+            }
+            if (j == 1 && (i == 4 || i == 5)) {               // the next step's B blocks into the other set
+                const int ns2 = s2 + 1;
+                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - 4));
+                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - 4) + 1);
+            }
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], gb[s2][j], acc16[i][j], 0, 0, 0);
+            // DMA pieces: as in the 32x32 body, scaled to 64 MFMAs per tile
+            if constexpr (NHEAD > 0) {
+                if (q < 2 * PER) {
+#pragma unroll
+                    for (int k = 0; k < NHEAD; ++k)
+                        if (k * 2 * PER / NHEAD == q) issue(ST ^ 1, NTAIL + k);
+                    if (q == (NHEAD - 1) * 2 * PER / NHEAD) advance();
+                }
+            }
+            if (q >= QB16) {
+#pragma unroll
+                for (int k = 0; k < NTAIL; ++k)
+                    if (QB16 + k * 2 * PER / NTAIL == q) issue(ST, k);
+                if constexpr (NHEAD == 0) {
+                    if (q == NMF16 - 1) advance();
+                }
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
     for (int it = it_begin; it < it_end; it += 2) {
-        body(std::integral_constant<int, 0>{});
-        if (it + 1 < it_end) body(std::integral_constant<int, 1>{});
+        if constexpr (M16) {
+            body16(std::integral_constant<int, 0>{});
+            if (it + 1 < it_end) body16(std::integral_constant<int, 1>{});
+        } else {
+            body(std::integral_constant<int, 0>{});
+            if (it + 1 < it_end) body(std::integral_constant<int, 1>{});
+        }
     }
     // the clamped re-loads of the last tile and the fragment prefetch behind the last barrier still touch LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -415,11 +526,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     const int ncol = n0 + wn * (32 * FN) + ec4;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        if constexpr (M16) {      // 16x16 blocks: row 4 (lane >> 4) + e, column lane & 15; rows 32 i .. 32 i + 31 = block rows 2i, 2i + 1
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < BNB; ++bj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) eps[(bi * 16 + 4 * l4 + e) * 68 + bj * 16 + l15] = acc16[2 * i + bi][bj][e];
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
             eps[lr * 68 + l31] = acc[i][0][r];
             eps[lr * 68 + 32 + l31] = acc[i][1][r];
+        }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -456,10 +576,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
 // host: launch the LDS-DMA kernel for a plan made by igemm.hip (mode, args); returns 0 when there is no instantiation
 int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    if (dg_get_option(DG_OPT_DMA_MFMA) != 32) {     // default: 16x16x32; option "dma_mfma" 32 selects the 32x32x16 body
+        switch (mode) {
+            case MODE_FWD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_FWD, 2, 4, true>), dim3(grid), dim3(512), 0, st, a); return 1;
+            case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_kernel<MODE_DGRAD_S2, 2, 4, true>), dim3(grid), dim3(512), 0, st, a); return 1;
+            case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_WGRAD, 2, 4, true>), dim3(grid), dim3(512), 0, st, a); return 1;
+            default: return 0;
+        }
+    }
     switch (mode) {
-        case MODE_FWD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_FWD, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
-        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_kernel<MODE_DGRAD_S2, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
-        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_WGRAD, 2, 4>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_FWD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_FWD, 2, 4, false>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_kernel<MODE_DGRAD_S2, 2, 4, false>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_kernel<MODE_WGRAD, 2, 4, false>), dim3(grid), dim3(512), 0, st, a); return 1;
         default: return 0;
     }
 }

@@ -131,11 +131,11 @@ DMA_SHAPES = [
 
 
 @pytest.mark.parametrize("N,C,K,H", DMA_SHAPES)
-@pytest.mark.parametrize("splitk", [0, 1, 3])
-def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk):
+@pytest.mark.parametrize("splitk,mfma", [(0, 16), (1, 16), (3, 16), (0, 32), (3, 32)])
+def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk, mfma):
     """bf16 shadow operands -> igemm_dma.hip (LDS-DMA staging, XOR-swizzled LDS images, 256x256 tile).  bf16 x bf16 products
     are exact in fp32, so the result must equal the fp64 convolution of the ROUNDED operands at fp32 tolerance -- and agree
-    with the register-staged bf16 tiles (option no_dma) to the same bound."""
+    with the register-staged bf16 tiles (option no_dma) to the same bound.  mfma: the 16x16x32 body (default) / the 32x32x16 body."""
     r = lambda t_: t_.bfloat16().float()
     x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
     yr = TF.conv2d(r(x).double(), r(w).double(), stride=2, padding=1).float()
@@ -144,6 +144,7 @@ def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk):
     L = _lib.load()
     _lib.set_option("bf16", 1)
     _lib.set_option("splitk", splitk)
+    _lib.set_option("dma_mfma", mfma)
     ops.SHADOW = True
     try:
         xg, wg, dyg = _with_shadow(nhwc(x)), _with_shadow(krsc(w)), _with_shadow(nhwc(dy))
@@ -165,6 +166,7 @@ def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk):
         ops.SHADOW = False
         ops.shadow_clear()
         _lib.set_option("no_dma", 0)
+        _lib.set_option("dma_mfma", 0)
         _lib.set_option("splitk", 0)
         _lib.set_option("bf16", 0)
 

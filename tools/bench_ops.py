@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--bf16", type=int, default=0)
     ap.add_argument("--shadow", type=int, default=0, help="with --bf16 1: hand the conv kernels bf16 shadow operands (what the trainer does)")
     ap.add_argument("--act16", type=int, default=0, help="time the BatchNorm / edge kernels on bf16-stored feature maps instead of the fp32 ones")
+    ap.add_argument("--dma_mfma", type=int, default=0, help="32: the LDS-DMA kernel's 32x32x16 body (default 16x16x32)")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
@@ -53,6 +54,7 @@ def main():
     _lib.set_option("bf16", a.bf16)
     _lib.set_option("dbg_zero", a.dbg_zero)
     _lib.set_option("no_dma", a.no_dma)
+    _lib.set_option("dma_mfma", a.dma_mfma)
     ops.SHADOW = bool(a.shadow)
     only = {int(v) for v in a.layers.split(",") if v}
 
