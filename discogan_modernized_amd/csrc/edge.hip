@@ -910,6 +910,190 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_bf16mfma_kernel(const float* 
     for (int e = tid; e < 64 * 48; e += 256) slab[e] = ((slabS[0][e] + slabS[1][e]) + slabS[2][e]) + slabS[3][e];
 }
 
+// ---- weight gradient on the bf16 matrix path, image rows staged through LDS (W >= 32) ------------------------------------
+// The per-lane im2col gathers of the kernel above touch 24 cache lines per load instruction and bound it at ~1.4 TB/s.  Here a
+// workgroup walks output rows (n, oy): the 4 x 3 input rows of the row are loaded COALESCED (float4), rounded to bf16 and written
+// to LDS de-interleaved by column parity, in four arrays per (channel, filter row) -- one per filter column s -- such that the 8
+// consecutive output pixels a lane needs for ITS (c, r, s) are 8 consecutive bf16 = ONE aligned ds_read_b128:
+//   s = 0: x[2 ox - 1] -> O0[ox] (O0[0] = 0: left padding)     s = 1: x[2 ox]     -> E[ox]
+//   s = 2: x[2 ox + 1] -> O[ox]                                 s = 3: x[2 ox + 2] -> E1[ox] (E1[Wo-1] = 0: right padding)
+// Rows above / below the image are staged as zeros.  Two LDS stages: the next output row is staged while the current one is
+// multiplied; the A operand (dy, one dword = two channels of a pixel) is loaded as in the kernel above.
+#define CWL_WOMAX 256
+template <bool FACT>
+__global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ part, int N, int H, int W, int K,
+                                                              long npix, int rows_per_wg, const float* __restrict__ act_out, float slope) {
+    constexpr int ROWE = CWL_WOMAX + 8;                       // bf16 elements per LDS array row (zero tail)
+    __shared__ __attribute__((aligned(16))) __bf16 img[2][4][12][ROWE];      // [stage][s][c * 4 + r][ox]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int kg = blockIdx.y;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // this lane's two im2col columns j = l31, 32 + l31 (valid < 48): (c, r, s) -> LDS array s, row c * 4 + r
+    int jrow[2], jarr[2];
+    bool jok[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int j = jn * 32 + l31;
+        jok[jn] = j < 48;
+        const int jj = jok[jn] ? j : 0;
+        jarr[jn] = jj & 3;
+        jrow[jn] = (jj >> 4) * 4 + ((jj >> 2) & 3);
+    }
+    const int nrows = N * Ho;
+    const int u0 = blockIdx.x * rows_per_wg, u1 = min(nrows, u0 + rows_per_wg);
+    constexpr int BIG = 0x40000000;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(npix * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, (int)(npix * K * 2), 0x00020000);
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, int off) -> unsigned {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    };
+    // ---- staging of output row u: 12 input rows x W / 4 float4 chunks over 256 threads (<= 6 per thread).  The global loads
+    // are issued BEFORE the current row's MFMAs (into registers), converted and written to the other LDS stage after them
+    const int wq = W >> 2, chunks = 12 * wq;
+    f32x4 sv[6];
+    auto stage_load = [&](int u) {
+        const int n = u / Ho, oy = u - n * Ho;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int e = tid + 256 * k;
+            const int rowi = e / wq, m = e - rowi * wq;
+            const int c = rowi >> 2, r = rowi & 3;
+            const int iy = 2 * oy - 1 + r;
+            sv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e < chunks && (unsigned)iy < (unsigned)H) sv[k] = *(const f32x4*)(x + ((long)(n * 3 + c) * H + iy) * W + 4 * m);
+        }
+    };
+    auto stage_store = [&](int st) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int e = tid + 256 * k;
+            if (e >= chunks) continue;
+            const int rowi = e / wq, m = e - rowi * wq;          // rowi = c * 4 + r, chunk m = columns 4m .. 4m+3
+            typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
+            typedef __bf16 bf16x2_s __attribute__((ext_vector_type(2)));
+            const bf16x4_s b = __builtin_convertvector(sv[k], bf16x4_s);          // x[4m], x[4m+1], x[4m+2], x[4m+3]
+            __bf16* E = &img[st][1][rowi][0];
+            __bf16* O = &img[st][2][rowi][0];
+            __bf16* O0 = &img[st][0][rowi][0];
+            __bf16* E1 = &img[st][3][rowi][0];
+            *(bf16x2_s*)(E + 2 * m) = (bf16x2_s){b[0], b[2]};
+            *(bf16x2_s*)(O + 2 * m) = (bf16x2_s){b[1], b[3]};
+            O0[2 * m + 1] = b[1];                                             // x[2 ox - 1] at ox = 2m + 1
+            if (2 * m + 2 < Wo) O0[2 * m + 2] = b[3];
+            E1[2 * m] = b[2];                                                 // x[2 ox + 2] at ox = 2m
+            if (m > 0) E1[2 * m - 1] = b[0];
+            if (m == 0) O0[0] = (__bf16)0.f;
+            if (2 * m + 2 == Wo) E1[Wo - 1] = (__bf16)0.f;
+        }
+    };
+    // ---- A operand of batch b of row u: 8 pixels per lane, one dword (two channels) each
+    unsigned wa[2][8], wo[2][FACT ? 8 : 1];
+    const int nbatch = Wo >> 4;
+    auto load_a = [&](int set, int u, int b) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pp = u * Wo + 16 * b + 8 * lh + t;
+            const int aoff = (u < u1 && b < nbatch) ? (pp * K + kg * 64 + 2 * l31) * 2 : BIG;
+            wa[set][t] = bload(rdy, aoff);
+            if constexpr (FACT) wo[set][t] = bload(rao, aoff);
+        }
+    };
+    typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4_l __attribute__((ext_vector_type(4)));
+    auto mma = [&](int set, int st, int b) {
+        unsigned w8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            unsigned wv = wa[set][t];
+            if constexpr (FACT) {
+                const unsigned ov = wo[set][t];
+                float a0 = __builtin_bit_cast(float, wv << 16), a1 = __builtin_bit_cast(float, wv & 0xffff0000u);
+                a0 = __builtin_bit_cast(float, ov << 16) > 0.f ? a0 : a0 * slope;
+                a1 = __builtin_bit_cast(float, ov & 0xffff0000u) > 0.f ? a1 : a1 * slope;
+                typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));
+                typedef float f32x2_l __attribute__((ext_vector_type(2)));
+                wv = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_l){a0, a1}, bf16x2_l));
+            }
+            w8[t] = wv;
+        }
+        u32x4_l ev, od;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ev[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x05040100u);
+            od[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
+        }
+        const bf16x8_l fa0 = __builtin_bit_cast(bf16x8_l, ev), fa1 = __builtin_bit_cast(bf16x8_l, od);
+        bf16x8_l fb[2];
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            fb[jn] = *(const bf16x8_l*)&img[st][jarr[jn]][jrow[jn]][16 * b + 8 * lh];
+            if (!jok[jn]) fb[jn] = __builtin_bit_cast(bf16x8_l, (u32x4_l){0u, 0u, 0u, 0u});
+        }
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[jn], acc[0][jn], 0, 0, 0);
+            acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[jn], acc[1][jn], 0, 0, 0);
+        }
+    };
+    // zero the tails of the LDS rows once (columns >= Wo are never written by the staging; batches never reach them, but keep
+    // the arrays defined)
+    for (int e = tid; e < 2 * 4 * 12 * ROWE; e += 256) (&img[0][0][0][0])[e] = (__bf16)0.f;
+    __syncthreads();
+    if (u0 < u1) {
+        stage_load(u0);
+        stage_store(0);
+    }
+    load_a(0, u0, wave);
+    __syncthreads();
+    // this wave's work items: batches wave, wave + 4, ... of every row; while item k is multiplied out of register set (k & 1)
+    // the A operand of item k + 1 (of this or the next row) is loaded into the other set
+    bool odd = false;
+    auto item = [&](auto S_, int u, int b, int st) {
+        constexpr int S = decltype(S_)::value;
+        const bool last = b + 4 >= nbatch;
+        load_a(S ^ 1, last ? u + 1 : u, last ? wave : b + 4);
+        mma(S, st, b);
+    };
+    for (int u = u0; u < u1; ++u) {
+        const int st = (u - u0) & 1;
+        if (u + 1 < u1) stage_load(u + 1);                        // the next row's image rows fly under this row's MFMAs
+        for (int b = wave; b < nbatch; b += 4) {
+            if (odd) item(std::integral_constant<int, 1>{}, u, b, st);
+            else item(std::integral_constant<int, 0>{}, u, b, st);
+            odd = !odd;
+        }
+        if (u + 1 < u1) stage_store(st ^ 1);
+        __syncthreads();
+    }
+    // the 4 waves' accumulators are summed through LDS (the image stages are free now: 4 x 12 KB of their 50 KB)
+    static_assert(sizeof(img) >= 4 * 64 * 48 * sizeof(float), "slab reduction lives in the image stages");
+    float (*slabS)[64 * 48] = (float (*)[64 * 48]) & img[0][0][0][0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int k = 2 * rho + i;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int j = jn * 32 + l31;
+                if (j < 48) slabS[wave][k * 48 + j] = acc[i][jn][r];
+            }
+        }
+    __syncthreads();
+    float* slab = part + ((long)blockIdx.x * K + kg * 64) * 48;
+    for (int e = tid; e < 64 * 48; e += 256) slab[e] = ((slabS[0][e] + slabS[1][e]) + slabS[2][e]) + slabS[3][e];
+}
+
 // fixed-order reduction over slabs: block = 16 outputs x 16 slab lanes
 __global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int nslabs, int total, int accumulate) {
@@ -986,7 +1170,17 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
                        K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
     if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
-    if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1) {        // bf16 matrix path: bf16 MFMA
+    if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
+        // bf16 matrix path, image rows staged through LDS: the same nb slabs, a contiguous range of output rows per workgroup
+        const int nrows = N * (H / 2);
+        const int rpw = (nrows + nb - 1) / nb;
+        if (fact)
+            hipLaunchKernelGGL(c3_wgrad_lds_kernel<true>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
+                               npix, rpw, act_out, slope);
+        else
+            hipLaunchKernelGGL(c3_wgrad_lds_kernel<false>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
+                               npix, rpw, act_out, slope);
+    } else if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1) {        // bf16 matrix path: bf16 MFMA, per-lane gathers
         if (fact)
             hipLaunchKernelGGL(c3_wgrad_bf16mfma_kernel<true>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
                                K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
