@@ -761,3 +761,48 @@ def test_bf16_activation_storage_training_step():
     tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234, mfma_dtype="bf16", act_dtype="bf16")
     out = tr.train_iteration(Ag, Bg, 0, do_step=False)
     assert out.AB.dtype == torch.float32 and out.A_feats_real[0].dtype == torch.bfloat16 and out.A_dis_real.dtype == torch.float32
+
+
+@pytest.mark.parametrize("act_dtype", ["f32", "bf16"])
+def test_bf16_path_vs_reference_golden_512_n2(act_dtype):
+    """BASELINE configs[4]'s arithmetic at the reference's only size: 512 px, batch 2, against the TRUE reference's fixture
+    (tests/golden/ref_s512_n2.json, iteration 0 = a D-step from the seeded init).  SURVEY 8(c) bf16 tolerances: losses rtol
+    2e-2, discriminator outputs 2e-2, image outputs' sums 2e-2 of their absolute sums, gradient norms of the stepped side
+    within 25 % per tensor (bf16 operand rounding moves single tensors' gradients by 10-20 % in relative L2 at this batch:
+    tools/bf16_storage_error.py), BatchNorm running statistics 2e-2; finite everywhere.  Both feature-map storages: fp32 + bf16
+    shadows, and bf16-only (LDS-DMA conv kernel, bf16-MFMA edge kernels)."""
+    fix = _load("ref_s512_n2.json")
+    rec = fix["iters"][0]
+    assert rec["step"] == "D" and rec["iter"] == 0
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234, mfma_dtype="bf16", act_dtype=act_dtype)
+    check_init_against_fixture(tr, fix)
+    A, B = synthetic_batch(2, 512, 0, DEV)
+    out = tr.train_iteration(A, B, 0, do_step=False)
+    got = tr.losses_to_floats(out)
+    for k, v in rec["losses"].items():
+        assert got[k] == got[k], f"{k} is NaN"
+        assert abs(got[k] - v) <= 2e-2 * abs(v) + 1e-5, f"bf16 ({act_dtype} maps) {k}: {got[k]} vs reference {v}"
+    for k, v in rec["dis_out"].items():
+        t = getattr(out, {"A_real": "A_dis_real", "A_fake": "A_dis_fake", "B_real": "B_dis_real", "B_fake": "B_dis_fake"}[k])
+        assert torch.allclose(t.detach().reshape(-1).float().cpu(), torch.tensor(v), rtol=2e-2, atol=1e-4), f"D out {k}"
+    for k in ("AB", "BA", "ABA", "BAB"):
+        f_ = getattr(out, k).detach().reshape(-1).float().cpu()
+        ref = rec["outputs"][k]
+        assert torch.isfinite(f_).all()
+        assert abs(float(f_.double().sum()) - ref["sum"]) <= 2e-2 * ref["abssum"], f"{k} sum"
+    worst = 0.0
+    for name in ("dis_A", "dis_B"):
+        for pn, p in tr.nets[name].named_parameters():
+            ref_norm = rec["grad_norms"][name][pn]
+            gn = float(p.grad.double().norm())
+            assert gn == gn
+            worst = max(worst, abs(gn - ref_norm) / max(ref_norm, 1e-30))
+    assert worst < 0.25, f"worst gradient-norm deviation {worst:.3f}"
+    for name, net in tr.nets.items():
+        for bn_, b in net.named_buffers():
+            ref = rec["buffers"][name][bn_]
+            if b.dtype == torch.int64:
+                assert int(b) == ref
+            else:
+                f_ = b.detach().reshape(-1).cpu()
+                assert abs(float(f_.double().sum()) - ref["sum"]) <= 2e-2 * ref["abssum"] + 1e-6, f"{name}.{bn_}"
