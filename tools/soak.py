@@ -1,15 +1,18 @@
 """Determinism / stability soak: N iterations at 64 px / batch 256 in every dispatch mode of one matrix path; all runs must end
-bitwise identical and finite.    python tools/soak.py [f32|bf16|f32x3] [iterations]"""
+bitwise identical and finite.    python tools/soak.py [f32|bf16|f32x3|bf16a] [iterations]     (bf16a = bf16 MFMA + bf16-stored feature maps)"""
 import sys, torch, time
 sys.path.insert(0, ".")
 from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+act = "f32"
+if dtype == "bf16a":
+    dtype, act = "bf16", "bf16"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 450
 res = []
 modes = [dict(use_graph=True), dict(use_graph=False), dict(use_graph=False, two_streams=False),
          dict(use_graph=False, overlap_comm=True, comm="capi", bucket_mb=4.0), dict(use_graph=True, overlap_comm=False, comm="capi")]
 for kw in modes:
-    tr = DiscoGANTrainer(default_args(), device="cuda", image_size=64, seed=1234, mfma_dtype=dtype, **kw)
+    tr = DiscoGANTrainer(default_args(), device="cuda", image_size=64, seed=1234, mfma_dtype=dtype, act_dtype=act, **kw)
     A, B = synthetic_batch(256, 64, 1000, "cuda")
     t0 = time.time()
     for it in range(iters):
