@@ -55,7 +55,12 @@ const char* dg_last_error(void);
  * "no_xcd_group" 1: plain blockIdx -> tile order (default: workgroups sharing operand rows are placed on one XCD);
  * "bf16" 1: the interior conv GEMMs (dg_conv_fwd/_dgrad/_wgrad and their named wrappers) round both operands to
  * bf16 and multiply on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor stays fp32 (BASELINE
- * configs[4]).  The result equals the fp32 op applied to the rounded operands up to summation order. */
+ * configs[4]).  The result equals the fp32 op applied to the rounded operands up to summation order.  With "bf16" 1 the
+ * 3-channel edge layers also round their operands and run on the bf16 MFMA ("kt" 16 keeps their fp32-MFMA kernels);
+ * "bf16" 2: fp32-accurate products from three bf16 planes per operand (f32x3);
+ * "no_dma" 1: convolutions with two bf16 operands stay on the register-staged tiles instead of the LDS-DMA kernel;
+ * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one;
+ * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results). */
 int dg_set_option(const char* name, int value);
 
 /* ---- interior convolutions: implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------
