@@ -39,6 +39,11 @@ template <int... Q, typename F>
 __device__ __forceinline__ void dg_static_for(std::integer_sequence<int, Q...>, F&& f) {
     (f(std::integral_constant<int, Q>{}), ...);
 }
+#ifndef DG_M16_FD
+#define DG_M16_FD 4
+#define DG_M16_BB 4
+#define DG_M16_B0 4
+#endif
 #ifndef DG_DMA_SPREAD_FETCH
 #define DG_DMA_SPREAD_FETCH 0
 #endif
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
 #pragma unroll
         for (int j = 0; j < BNB; ++j) fetchB16(0, 0, 0, j);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fetchA16(0, 0, i);
+        for (int i = 0; i < DG_M16_FD; ++i) fetchA16(0, 0, i);
     } else {
         fetch(0, 0, 0);
     }
@@ -463,9 +468,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     // and B set s2; behind its first MFMA the A block 4 ahead is fetched (the next step's, the next TILE's behind the barrier),
     // blocks 4 and 5 also fetch the next step's B blocks.  The tile barrier sits in front of block (1, 4) = 16 MFMAs (256
     // cycles) before the end of the tile: every read of the current stage was issued by block (1, 3).
+    // Schedule parameters (same-box A/B, tools/bench_ops.py): FD = how many blocks ahead an A block is fetched (8 slots: <= 7),
+    // BB = the block of step 1 the tile barrier sits in front of (every read of the current stage must have been issued: the
+    // last one, A(1, 7), is fetched in block (1, 7 - FD) < BB), B0 = the block of step 0 that starts fetching step 1's B blocks.
     auto body16 = [&](auto ST_) {
         constexpr int ST = decltype(ST_)::value;
-        constexpr int NMF16 = 2 * AM * BNB, QB16 = NMF16 - 4 * BNB;
+        constexpr int FD = DG_M16_FD, BB = DG_M16_BB, B0 = DG_M16_B0;
+        static_assert(FD >= 1 && FD <= 7 && 7 - FD < BB && BB <= 6 && B0 <= 6, "M16 schedule");
+        constexpr int NMF16 = 2 * AM * BNB, QB16 = AM * BNB + BB * BNB;
         dg_static_for(std::make_integer_sequence<int, NMF16>{}, [&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
             constexpr int s2 = q / (AM * BNB), i = (q / BNB) % AM, j = q % BNB;
@@ -474,14 +484,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (j == 0) {                                     // A block 4 ahead
-                const int ni = (i + 4) % AM, ns2 = s2 + (i + 4) / AM;          // ns2 == 2: step 0 of the next tile
+            if (j == 0) {                                     // A block FD ahead
+                const int ni = (i + FD) % AM, ns2 = s2 + (i + FD) / AM;          // ns2 == 2: step 0 of the next tile
                 fetchA16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ni);
             }
-            if (j == 1 && (i == 4 || i == 5)) {               // the next step's B blocks into the other set
+            constexpr int BF = s2 == 0 ? B0 : BB;             // the next step's B blocks into the other set (next tile: behind the barrier)
+            if (j == 1 && (i == BF || i == BF + 1)) {
                 const int ns2 = s2 + 1;
-                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - 4));
-                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - 4) + 1);
+                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - BF));
+                fetchB16(ns2 < 2 ? ST : ST ^ 1, ns2 & 1, ns2 & 1, 2 * (i - BF) + 1);
             }
             acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], gb[s2][j], acc16[i][j], 0, 0, 0);
             // DMA pieces: as in the 32x32 body, scaled to 64 MFMAs per tile
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
             if (q >= QB16) {
 #pragma unroll
                 for (int k = 0; k < NTAIL; ++k)
-                    if (QB16 + k * 2 * PER / NTAIL == q) issue(ST, k);
+                    if (QB16 + k * (NMF16 - QB16) / NTAIL == q) issue(ST, k);
                 if constexpr (NHEAD == 0) {
                     if (q == NMF16 - 1) advance();
                 }
