@@ -127,6 +127,11 @@ def load():
             f"{LIB_PATH} not found: the HIP kernel library is not built. "
             "Run `python -m discogan_modernized_amd.build` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the product path.")
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library is
+    # dlopen'ed, so that the library's libamdhip64 dependency resolves to that same instance: loaded the other way round (e.g.
+    # __graft_entry__.build() followed by smoke() in one process) the process ends up with two HIP runtimes and every launch
+    # through this library fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError -> missing export
