@@ -422,7 +422,10 @@ def main():
         extra["note_side"] = ("side measurements, NOT the headline value; bf16 = conv operands rounded to bf16 on the bf16 MFMA path, fp32 "
                               "accumulate/BatchNorm/weights/Adam (configs[4] arithmetic); f32x3 = fp32-ACCURATE conv products on the bf16 "
                               "MFMA path: each fp32 operand split into three bf16 planes (24 significand bits), six MFMAs per block, fp32 "
-                              "accumulate -- measured closer to fp64 than the exact-fp32 MFMA chain (tests/test_ops_gpu.py::test_conv_f32x3_is_fp32_accurate)")
+                              "accumulate -- measured closer to fp64 than the exact-fp32 MFMA chain (tests/test_ops_gpu.py::test_conv_f32x3_is_fp32_accurate); "
+                              "*_bf16_mfma_bf16_activations = BASELINE configs[4]'s arithmetic in full: bf16 MFMA (LDS-DMA conv kernel, bf16-MFMA edge "
+                              "kernels), feature maps and their gradients STORED in bf16, fp32 BatchNorm statistics / parameters / parameter gradients / "
+                              "losses / master weights / Adam (tests: test_bf16_path_vs_reference_golden_512_n2, test_bf16_activation_storage_training_step)")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
