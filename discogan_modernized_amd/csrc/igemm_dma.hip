@@ -1,28 +1,31 @@
-// Implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 with BOTH operands staged by LDS-DMA (gfx950).
+// Implicit-GEMM convolution on the bf16 MFMA with BOTH operands staged by LDS-DMA (gfx950).
 //
 // Replaces (reference file:line) the same ops as igemm.hip -- nn.Conv2d(k4,s2,p1) forward / input-grad / weight-grad
 // (model.py:11-31,83-103 via autograd) and nn.ConvTranspose2d(k4,s2,p1) (model.py:118-140) -- for the bf16 matrix path
-// (BASELINE configs[4]) when both operands exist as bf16 tensors in HBM (the shadows their producers write: Adam for
-// weights, the BatchNorm kernels / first conv for activations and gradients).
+// (BASELINE configs[4]) when both operands exist as bf16 tensors in HBM (the feature maps themselves with bf16 activation
+// storage, or the shadows their producers write: Adam for weights, the BatchNorm kernels / first conv for activations).
 //
 // Why a second kernel: the register-staged bf16 tiles of igemm.hip (128x128 block, 64x64 per wave, global -> VGPR ->
-// ds_write) move 1 KB of LDS reads + 0.5 KB of LDS writes per MFMA and 64 B/clk/CU through the vector memory path, and the
-// VGPR -> LDS store path (~80 B/clk/CU) plus the staging instructions bound the loop at ~0.7 PFLOP/s.  Here
-//   * a workgroup is 8 waves (2 x 4) on a 256 x 256 output tile, 128 x 64 per wave (4 x 2 accumulators of 32x32 = 128
-//     registers): 0.75 KB of LDS reads and 0.25 KB of global -> LDS traffic per MFMA;
+// ds_write) move 1 KB of LDS reads + 0.5 KB of LDS writes per MFMA and 64 B/clk/CU through the vector memory path.  Here
+//   * a workgroup is 8 waves (2 x 4) on a 256 x 256 output tile, 128 x 64 per wave (128 accumulator registers):
+//     0.75 KB of LDS reads and 0.25 KB of global -> LDS traffic per 32-cycle MFMA slot;
 //   * operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (one 1-KiB piece per wave-instruction, no VGPRs, no
-//     ds_write, no conversions); the LDS image is lane-linear per piece, so the bank-conflict-free layouts are XOR
-//     swizzles applied to the per-lane SOURCE address and again in the fragment reads:
+//     ds_write, no conversions), issued from inline asm (see `dma` below: through the builtin hipcc serialised every tile on
+//     the DMA); the LDS image is lane-linear per piece, so the bank-conflict-free layouts are XOR swizzles applied to the
+//     per-lane SOURCE address and again in the fragment reads:
 //       k-contiguous images [row][64 k] (128-B rows): 16-B granule g of row r sits in slot g ^ ((r >> 1) & 7)
-//           -> the 16 lanes of a ds_read_b128 group hit 16 different 16-B slots of the 256-B bank row;
-//       reduction-major images [64 k][cols] (rows of 256 or 512 B): granule gc of row k sits in slot gc ^ ((k & 3) << 2)
-//           -> the four rows of a ds_read_b64_tr_b16 block hit four different 64-B bank segments;
-//   * padding / ragged rows are out-of-range buffer offsets (the DMA then writes zeros), exactly as in igemm.hip;
-//   * two LDS stages (2 x 64 KB), one workgroup per CU, ONE barrier per K-tile placed 8 MFMAs before the end of the tile
-//     (igemm.hip's pipeline): behind it the first fragments of tile t+1 are fetched and the DMA of tile t+2 starts into
-//     the stage tile t just vacated, so a tile's DMA has a whole K-tile (32 MFMAs per wave, two waves per SIMD) to land;
-//     the only vmcnt wait is the one in front of that barrier.
-// Epilogue, split-K slabs and the blockIdx -> tile orders are those of igemm.hip.
+//           -> the 16 lanes of a ds_read_b128 group hit 16 different 16-B slots of the 256-B bank row (both MFMA shapes);
+//       reduction-major images [64 k][cols] (rows of 512 B): granule gc of row k sits in slot gc ^ kmswz(k)
+//           -> the rows of a ds_read_b64_tr_b16 half hit different 64-B / 32-B bank segments;
+//   * padding / ragged rows are out-of-range buffer offsets (the DMA then writes zeros: tools/probes/lds_dma_oob.hip),
+//     exactly as in igemm.hip;
+//   * two LDS stages (2 x 64 KB), one workgroup per CU, ONE barrier per K-tile placed 256 cycles of MFMA work before the
+//     end of the tile (igemm.hip's pipeline): behind it the first fragments of tile t+1 are fetched and the DMA of tile t+2
+//     starts into the stage tile t just vacated, so a tile's DMA has a whole K-tile to land; the only vmcnt wait is the
+//     one in front of that barrier;
+//   * two loop bodies: v_mfma_f32_16x16x32_bf16 (default: the chip holds 1.81-1.85 GHz under it) and
+//     v_mfma_f32_32x32x16_bf16 (1.62-1.73 GHz; option "dma_mfma" 32) -- the loop is power-limited, DESIGN.md section 3.1.
+// Epilogue (fp32 or bf16 output), split-K slabs and the blockIdx -> tile orders are those of igemm.hip.
 #include "igemm_args.h"
 #include <type_traits>
 #include <utility>
