@@ -18,6 +18,7 @@ _i = C.c_int
 _f = C.c_float
 _d = C.c_double
 _z = C.c_size_t
+_l = C.c_int64
 
 # name -> (restype, argtypes); mirrors include/discogan_hip.h one to one
 SIGNATURES = {
@@ -94,6 +95,12 @@ SIGNATURES = {
     "dg_bn_act_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "dg_bn_act_bwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
     "dg_conv_bf16_operands_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_f32_to_bf16x3": (_i, [_p, _p, _z, _z, _p]),
+    "dg_adam_step_flat_x3": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p, _z, _p]),
+    "dg_conv_x3_planes_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd_x3": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_dgrad_x3": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_wgrad_x3": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_bn_train_stats_t": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),

@@ -8,6 +8,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 dg_bf16x4_t __attribute__((ext_vector_type(4)));
 
 // ---- error plumbing (thread-local message, never abort) ---------------------------------------
 extern thread_local char dg_err_buf[512];
@@ -64,4 +65,13 @@ __device__ __forceinline__ float dg_apply_act(float u, int act, float slope) {
     if (act == DG_ACT_RELU) return u > 0.f ? u : 0.f;
     if (act == DG_ACT_SIGMOID) return 1.f / (1.f + __expf(-u));
     return u;
+}
+
+// fp32 -> three bf16 planes (the "f32x3" operand form of igemm.hip PREC 2 / igemm_dma_x3.hip): hi = bf16(v) (RNE),
+// mid = bf16(v - hi), lo = bf16(v - hi - mid); both subtractions are exact in fp32, hi + mid + lo carries 24 significand bits
+__device__ __forceinline__ void dg_split3(const f32x4& v, dg_bf16x4_t& hi, dg_bf16x4_t& mid, dg_bf16x4_t& lo) {
+    hi = __builtin_convertvector(v, dg_bf16x4_t);
+    const f32x4 r = v - __builtin_convertvector(hi, f32x4);
+    mid = __builtin_convertvector(r, dg_bf16x4_t);
+    lo = __builtin_convertvector(r - __builtin_convertvector(mid, f32x4), dg_bf16x4_t);
 }

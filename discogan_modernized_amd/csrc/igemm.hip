@@ -1077,9 +1077,11 @@ struct Plan {
     size_t ws_bytes;
     int stat_rows;   // partial rows the fused BatchNorm statistics would produce (0: not supported)
     int dma;         // 1: igemm_dma.hip (both operands bf16 in HBM, LDS-DMA staging, 256 x 256 tile, 512 threads)
+                     // 2: igemm_dma_x3.hip (both operands as three bf16 planes in HBM; same tile, K-tile 16)
 };
 
-int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma.hip
+int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);      // igemm_dma.hip
+int dg_igemm_dma_x3_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
     const int cch = (Ng + 127) / 128;
@@ -1156,6 +1158,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     }
     {   // operand sizes for the buffer-descriptor kernels; 0 = use the 64-bit pointer kernels
         const long xb = (long)g.N * g.H * g.W * g.C * 4, yb = (long)npix * g.K * 4, wb = (long)g.K * 16 * g.C * 4;
+        // a16 / b16 = 3: three bf16 planes; the descriptors cover ONE plane (the planes' distance is set by the caller)
         const long ab = (op == 0 ? xb : yb) / (a16 ? 2 : 1), bb = (op == 2 ? xb : wb) / (b16 ? 2 : 1);
         const bool fits = ab < (1L << 31) && bb < (1L << 31) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
         a.abytes = fits ? (unsigned)ab : 0u;
@@ -1178,6 +1181,11 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         g.C % 8 == 0 && g.K % 8 == 0 &&
         ((pl->mode == MODE_FWD && g.C % 64 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 64 == 0) || pl->mode == MODE_WGRAD))
         pl->dma = 1;
+    // plane kernel (igemm_dma_x3.hip): the same tile and grid rules with 16-deep K-tiles
+    if (a.prec == 2 && a16 == 3 && b16 == 3 && dg_get_option(DG_OPT_NO_DMA) == 0 && pl->kt == 16 && a.Ng >= 192 && a.M >= 192 &&
+        g.C % 8 == 0 && g.K % 8 == 0 &&
+        ((pl->mode == MODE_FWD && g.C % 16 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 16 == 0) || pl->mode == MODE_WGRAD))
+        pl->dma = 2;
     const int BM = pl->dma ? 256 : 64 * pl->wm, BN = pl->dma ? 256 : 64 * pl->wn;
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
@@ -1245,7 +1253,8 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     if (pl.dma) {
-        if (!dg_igemm_dma_launch(pl.mode, a, zmul, st)) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
+        const int ok = pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
+        if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
         DG_CHECK_LAUNCH(who);
     } else {
     const int key = a.prec == 1 ? 1000 + pl.mode * 100 + pl.wm * 10 + (pl.kt == 64 ? 1 : 0)
@@ -1311,6 +1320,10 @@ extern "C" size_t dg_conv_workspace_bytes(int op, int N, int H, int W, int C, in
             make_plan(op, g, &pl, v & 1, v >> 1);
             if (pl.ws_bytes > ws) ws = pl.ws_bytes;
         }
+    }
+    if (dg_get_option(DG_OPT_BF16) == 2) {      // the plane-operand forms (dg_conv_*_x3)
+        make_plan(op, g, &pl, 3, 3);
+        if (pl.ws_bytes > ws) ws = pl.ws_bytes;
     }
     return ws;
 }
@@ -1447,6 +1460,50 @@ extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int 
     Plan pl;
     make_plan(op, g, &pl, 1, 1);
     return pl.a.prec == 1 ? (pl.dma ? 2 : 1) : 0;
+}
+
+// ---- fp32 operands as three bf16 planes (option "bf16" = 2 only): igemm_dma_x3.hip -----------------------------------------
+// a3 / b3 point at plane 0 (hi) of an operand; planes 1 (mid) and 2 (lo) follow a_plane / b_plane BYTES further on (>= the
+// tensor's 2 * numel; a weight inside a flat parameter group has the group's plane distance).  Written by dg_f32_to_bf16x3 or
+// by the fused producers (dg_adam_step_flat_x3, dg_bn_act_fwd_x3, dg_bn_act_bwd_x3); outputs are fp32.
+static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_plane, float* out, int N, int H, int W, int C, int K,
+                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const char* who = op == 0 ? "dg_conv_fwd_x3" : (op == 1 ? "dg_conv_dgrad_x3" : "dg_conv_wgrad_x3");
+    ConvGeom g;
+    int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(a3 && b3 && out, "%s: null pointer", who);
+    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 2, "%s: plane operands need option bf16 = 2", who);
+    DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no plane form", who);
+    Plan pl;
+    make_plan(op, g, &pl, 3, 3);
+    if (pl.dma != 2) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
+    DG_CHECK_ARG(a_plane >= (long)pl.a.abytes && b_plane >= (long)pl.a.bbytes && a_plane % 16 == 0 && b_plane % 16 == 0,
+                 "%s: plane distances %ld / %ld (operands are %u / %u bytes per plane)", who, a_plane, b_plane, pl.a.abytes, pl.a.bbytes);
+    pl.a.A = (const float*)a3; pl.a.B = (const float*)b3; pl.a.C = out; pl.a.accumulate = accumulate;
+    pl.a.a_plane = a_plane; pl.a.b_plane = b_plane;
+    return run_plan(who, pl, ws, ws_bytes, st);
+}
+extern "C" int dg_conv_fwd_x3(const void* x3, long x_plane, const void* w3, long w_plane, float* y, int N, int H, int W, int C, int K,
+                              int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(0, x3, x_plane, w3, w_plane, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_dgrad_x3(const void* dy3, long dy_plane, const void* w3, long w_plane, float* dx, int N, int H, int W, int C, int K,
+                                int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(1, dy3, dy_plane, w3, w_plane, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, const void* x3, long x_plane, float* dw, int N, int H, int W, int C, int K,
+                                int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(2, dy3, dy_plane, x3, x_plane, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
+}
+// does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)
+extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (check_geom("dg_conv_x3_planes_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
+    if (dg_get_option(DG_OPT_BF16) != 2) return 0;
+    Plan pl;
+    make_plan(op, g, &pl, 3, 3);
+    return pl.dma == 2 ? 1 : 0;
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

@@ -1,5 +1,5 @@
 // Arguments shared by the implicit-GEMM conv kernels (igemm.hip: register-staged fp32 / bf16 / f32x3 tiles;
-// igemm_dma.hip: bf16 operands staged by LDS-DMA).  Internal; the public ABI is include/discogan_hip.h.
+// igemm_dma.hip: bf16 operands staged by LDS-DMA; igemm_dma_x3.hip: fp32 operands as three bf16 planes staged by LDS-DMA).  Internal; the public ABI is include/discogan_hip.h.
 #pragma once
 #include "dg_common.h"
 
@@ -19,7 +19,9 @@ struct IgemmArgs {
     int accumulate;
     int act;      // fused activation on the output (FWD_C3 training path; every mode on the inference path)
     float slope;
-    int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element)
+    int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element);
+                         // 3 (PREC 2, igemm_dma_x3.hip): three bf16 planes hi / mid / lo, plane-major, a_plane / b_plane bytes apart
+    long a_plane, b_plane;
     int out16;           // the output tensor C is bf16 (RNE of the fp32 accumulators; FWD / DGRAD modes, never the weight gradient)
     int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
     int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)

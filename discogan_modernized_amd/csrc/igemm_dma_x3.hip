@@ -1,0 +1,435 @@
+// fp32-accurate implicit-GEMM convolution on the bf16 MFMA, operands = THREE bf16 PLANES per tensor staged by LDS-DMA (gfx950).
+//
+// Replaces (reference file:line) the same ops as igemm.hip / igemm_dma.hip -- nn.Conv2d(k4,s2,p1) forward / input-grad /
+// weight-grad (model.py:11-31,83-103 via autograd) and nn.ConvTranspose2d(k4,s2,p1) (model.py:118-140) -- for the
+// `mfma_dtype="f32x3"` matrix path (option "bf16" = 2) when BOTH operands exist in HBM as plane triples
+//     hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)          (plane-major: [3][numel] bf16; dg_f32_to_bf16x3)
+// -- 24 significand bits of v, both subtractions exact in fp32.  A product block is the same SIX bf16 MFMAs as the
+// register-staged PREC 2 tiles of igemm.hip (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi into one fp32 accumulator,
+// smallest first); where the reduction is also walked in the same order (weight gradient; channel counts that are not a
+// multiple of 64) the two kernels agree bit for bit on an unsplit GEMM.
+//
+// Why a second kernel: the register-staged form splits every fp32 value on the VALU while it is staged (5.5 instructions per
+// element) and its two waves per SIMD spend the SIMD's whole issue budget on that -- K loop at 73 % of the matrix rate.  Here
+// the split is done ONCE by whoever produces the tensor, and the conv kernel is igemm_dma.hip's pipeline with 3 planes:
+//   * 256 x 256 output tile, 8 waves (2 x 4) of 128 x 64; K-tile = 16 reduction elements = 48 MFMAs (1536 matrix cycles) per
+//     wave; a fragment (3 planes) is reused by 6 MFMAs from registers: 18 ds_read_b128 (36 ds_read_b64_tr_b16 for
+//     reduction-major images) and 6 DMA instructions per wave and tile -- 0.19 KB of LDS reads and 16 B/clk/CU of
+//     global -> LDS traffic per MFMA slot (bf16 kernel: 0.75 KB, 32 B/clk/CU);
+//   * LDS stage = [A p0][A p1][A p2][B p0][B p1][B p2], 8 KB each (256 rows x 16 k), two stages (96 KB, one workgroup
+//     per CU); every wave DMAs one 1-KiB piece per plane and operand;
+//       k-contiguous image [row][16 k] (32-B rows): 16-B granule g of row r sits in slot g ^ ((r >> 3) & 1);
+//       reduction-major image [16 k][256 cols] (512-B rows): granule gc of row k sits in slot gc ^ ((k & 3) << 2);
+//   * fragments live in ONE register set (A: 48, B: 24 + 8 VGPRs) and are replaced as the MFMA sequence releases them: the
+//     A blocks of row i behind row i, B lo / mid during the last row, B hi (first operand of the next tile) in a second set;
+//   * ONE barrier per K-tile in front of MFMA 8: behind it tile t+1 may be read and the DMA of tile t+2 starts into the
+//     stage tile t has left (every fragment of tile t is in registers since the end of tile t-1).
+// Epilogue, split-K slabs and the blockIdx -> tile orders are those of igemm.hip.
+#include "igemm_args.h"
+#include <type_traits>
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <int... Q, typename F>
+__device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...>, F&& f) {
+    (f(std::integral_constant<int, Q>{}), ...);
+}
+#ifndef DG_X3_QB
+#define DG_X3_QB 8
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
+    static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
+    constexpr int WN = 4, FM = 4, FN = 2;               // 2 x 4 waves, 4 x 2 accumulator blocks of 32x32 per wave
+    constexpr int BM = 256, BN = 256, KT = 16;
+    constexpr bool A_KM = MODE == MODE_WGRAD;           // operand image is reduction-major ([k][cols])
+    constexpr bool B_KM = MODE != MODE_FWD;
+    constexpr int PL = 256 * KT * 2;                    // one plane of one operand: 8 KB
+    constexpr int OPB = 3 * PL, STAGE = 2 * OPB;        // 48 KB per stage
+    constexpr int LDS_BYTES = 2 * STAGE;
+    constexpr int EPI_BYTES = 8 * 32 * 68 * 4;
+    static_assert(EPI_BYTES <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long* const stp = (p.stamps != nullptr && tid == 0) ? p.stamps + (long)blockIdx.x * 8 : nullptr;
+    if (stp) {
+        stp[0] = wall_clock64();
+        stp[1] = clock64();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stp[6] = ((long long)xcc << 32) | hwid;
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- blockIdx -> (tile, parity, split): the three orders of igemm.hip -------------------------------------
+    int bid = blockIdx.x;
+    int tn, tm, parity = 0, split;
+    if (p.xcd_group == 2) {
+        const int G = p.tilesM;
+        tm = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = rest & 3;
+            rest >>= 2;
+        }
+        tn = rest % p.tilesN;
+        split = rest / p.tilesN;
+    } else if (p.xcd_group) {
+        const int G = p.tilesN * (MODE == MODE_DGRAD_S2 ? 4 : 1);
+        int inner = (bid >> 3) % G;
+        int rest = (bid / (8 * G)) * 8 + (bid & 7);
+        if (MODE == MODE_DGRAD_S2) {
+            parity = inner & 3;
+            inner >>= 2;
+        }
+        tn = inner;
+        tm = rest % p.tilesM;
+        split = rest / p.tilesM;
+    } else {
+        tn = bid % p.tilesN;
+        bid /= p.tilesN;
+        tm = bid % p.tilesM;
+        bid /= p.tilesM;
+        split = bid;
+        if (MODE == MODE_DGRAD_S2) {
+            parity = bid & 3;
+            split = bid >> 2;
+        }
+    }
+    const int ph = parity >> 1, pw = parity & 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int it_begin = split * p.itPerSplit;
+    const int it_end = min(p.nIt, it_begin + p.itPerSplit);
+
+    const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
+    const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
+
+    constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB plane: the DMA writes zeros
+    // one buffer descriptor per plane: an offset that runs off the end of a plane must not land in the next one
+    __amdgpu_buffer_rsrc_t rA[3], rB[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        rA[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + pl * p.a_plane), 0, (p.dbg_zero & 1) ? 0 : (int)p.abytes, 0x00020000);
+        rB[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + pl * p.b_plane), 0, (p.dbg_zero & 2) ? 0 : (int)p.bbytes, 0x00020000);
+    }
+
+    auto kmswz = [](int k) -> int { return (k & 3) << 2; };
+    // ---- per-lane source descriptors of this wave's DMA pieces (the same for the three planes; fixed over the K loop) ----
+    // k-contiguous image: the wave's piece covers rows 32 w .. 32 w + 31; lane L lands in (row 32 w + L / 2, slot L % 2) and
+    // fetches granule slot ^ ((row >> 3) & 1).  Reduction-major image: the piece covers k rows 2 w, 2 w + 1; lane L lands in
+    // (k row 2 w + L / 32, slot L % 32) and fetches granule slot ^ kmswz(k row).
+    const int kc_row = wave * 32 + (lane >> 1);
+    const int kc_g = (lane & 1) ^ ((kc_row >> 3) & 1);
+    const int km_row = wave * 2 + (lane >> 5);
+    const int km_gc = (lane & 31) ^ kmswz(km_row);
+    int a_ob = 0, a_inv = 0;
+    if (!A_KM) {
+        const int m = m0 + kc_row;
+        if (MODE == MODE_FWD) {
+            a_inv = 0xFFFF;
+            if (m < p.M) {
+                const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                const int ay = oy * p.stride - p.pad, ax = ox * p.stride - p.pad;
+                a_ob = (((n * H + ay) * W + ax) * Cc + kc_g * 8) * 2;
+                int colok = 0, okmask = 0;
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(ax + sx) < (unsigned)W) ? (1 << sx) : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(ay + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
+                a_inv = ~okmask & 0xFFFF;
+            }
+        } else {   // DGRAD_S2
+            a_inv = 0xF;
+            if (m < p.M) {
+                const int bx = m & (Wo - 1), ay = (m >> lgWo) & (Ho - 1);
+                a_ob = (m * K + kc_g * 8) * 2;
+                a_inv = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ty = t >> 1, tx = t & 1;
+                    const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+                    const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+                    const bool ok = (unsigned)(ay + dyo) < (unsigned)Ho && (unsigned)(bx + dxo) < (unsigned)Wo;
+                    a_inv |= ok ? 0 : (1 << t);
+                }
+            }
+        }
+    } else {       // WGRAD: rows = reduction pixels, columns = out channels m0 .. m0 + 255 of dy[pixel][K]
+        const int col = m0 + km_gc * 8;
+        a_ob = col < K ? (km_row * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the plane: zeros
+    }
+    int b_ob = 0;
+    // WGRAD: the columns of B are (tap, c) of im2col(x); everything about the column is fixed per lane
+    int wg_c = 0, wg_cst = 0, wg_ybad = -1, wg_xbad = -1, wg_colbad = 0;
+    const bool wg_s2 = p.stride == 2;
+    const int wg_lpm = wg_s2 ? 2 : 4, wg_pxm = wg_s2 ? -1 : 0;
+    if (MODE == MODE_FWD) {
+        const int k = n0 + kc_row;
+        b_ob = k < K ? (k * 16 * Cc + kc_g * 8) * 2 : OOR;
+    } else {
+        const int col = n0 + km_gc * 8;
+        if (MODE == MODE_DGRAD_S2) {
+            b_ob = col < Cc ? (km_row * 16 * Cc + col) * 2 : OOR;
+        } else {
+            const bool colok = col < p.Ng;
+            const int tap = colok ? col / Cc : 0;
+            const int r = tap >> 2, s = tap & 3;
+            wg_c = col - tap * Cc;
+            wg_cst = wg_s2 ? (r - 1) * W + (s - 1) : r * 4 + s;
+            wg_ybad = !wg_s2 ? -1 : (r == 0 ? 0 : (r == 3 ? Ho - 1 : -1));
+            wg_xbad = !wg_s2 ? -1 : (s == 0 ? 0 : (s == 3 ? Wo - 1 : -1));
+            wg_colbad = colok ? 0 : -1;
+        }
+    }
+
+    // ---- DMA-side K-iteration state (wave-uniform): the tile the NEXT piece belongs to ---------------------------------
+    // FWD / DGRAD_S2 walk the reduction in 64-channel chunks, the taps of a chunk (r, s in the order 0, 2, 1, 3 / the 2x2 taps
+    // of the parity class) inside, and the chunk's FOUR 16-channel K-tiles innermost: a k-contiguous row gives a K-tile only
+    // 32 bytes, so the four tiles that share a 128-byte line run back to back (the line is fetched once), while the taps of
+    // a chunk still re-use the same input pixels.  Channel counts that are not a multiple of 64 walk 16-channel chunks (the
+    // order of igemm.hip's K-tile 16).  WGRAD walks pixel tiles.
+    constexpr int NTAP = MODE == MODE_FWD ? 16 : 4;
+    const int SUB = (MODE == MODE_WGRAD) ? 1 : (((MODE == MODE_FWD ? Cc : K) & 63) == 0 ? 4 : 1);
+    int dt = it_begin, tap = 0, chunk = 0, sub = 0;          // channel offset of the tile = (chunk * SUB + sub) * 16
+    if (MODE != MODE_WGRAD) {
+        sub = it_begin % SUB;
+        tap = (it_begin / SUB) % NTAP;
+        chunk = it_begin / (SUB * NTAP);
+    }
+    auto advance = [&]() {                       // next tile, clamped to the last one (re-loaded, never used)
+        const int go = dt + 1 < it_end ? 1 : 0;
+        dt += go;
+        if (MODE != MODE_WGRAD) {
+            sub += go;
+            const int w1 = (sub == SUB) ? 1 : 0;
+            sub = w1 ? 0 : sub;
+            tap += w1;
+            const int w2 = (tap == NTAP) ? 1 : 0;
+            tap = w2 ? 0 : tap;
+            chunk += w2;
+        }
+    };
+    auto coff = [&]() { return (chunk * SUB + sub) * KT; };
+    auto fwd_r = [&]() { const int a = tap >> 2; return ((a & 1) << 1) | (a >> 1); };
+    auto fwd_s = [&]() { const int b = tap & 3; return ((b & 1) << 1) | (b >> 1); };
+
+    // LDS-DMA from inline asm (igemm_dma.hip: the compiler must not order the fragment reads behind it); M0 saved / restored
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int lds_off, int voff) {
+        unsigned keep;
+        const unsigned dst = lds_base + (unsigned)lds_off;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(r), "s"(dst)
+                     : "memory");
+    };
+    // the per-lane source offset of this wave's A / B piece of tile `dt` (the same in every plane)
+    auto a_voff = [&]() -> int {
+        if (MODE == MODE_FWD) {
+            const int r = fwd_r(), sx = fwd_s();
+            const int soff = ((r * W + sx) * Cc + coff()) * 2;                 // wave-uniform
+            return (a_ob + soff) | -((a_inv >> (r * 4 + sx)) & 1);
+        } else if (MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1;
+            const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+            const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+            const int soff = ((dyo * Wo + dxo) * K + coff()) * 2;
+            return (a_ob + soff) | -((a_inv >> tap) & 1);
+        }
+        return a_ob + dt * (KT * 2) * K;
+    };
+    auto b_voff = [&]() -> int {
+        if (MODE == MODE_FWD) {
+            return b_ob + (((fwd_r() * 4 + fwd_s()) * Cc) + coff()) * 2;
+        } else if (MODE == MODE_DGRAD_S2) {
+            const int ty = tap >> 1, tx = tap & 1;
+            const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
+            const int sx = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+            return b_ob + ((coff() * 16 + r * 4 + sx) * Cc) * 2;
+        }
+        // reduction row = output pixel mrow = (n, oy, ox) packed; see igemm.hip load_B (WGRAD)
+        const int mrow = dt * KT + km_row;
+        const int oxv = mrow & (Wo - 1), oyv = (mrow >> lgWo) & (Ho - 1);
+        const int bad = (oyv == wg_ybad) | (oxv == wg_xbad) | (mrow >= p.R);
+        const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst;
+        return ((pix * Cc + wg_c) * 2) | wg_colbad | -bad;
+    };
+    // piece k (0..2: A planes, 3..5: B planes) of tile `dt` into LDS stage `stage`
+    int va = 0, vb = 0;
+    auto issue = [&](int stage, int k) {
+        if (k == 0) va = a_voff();
+        if (k == 3) vb = b_voff();
+        const int lds_off = stage * STAGE + k * PL + wave * 1024;
+        if (k < 3) dma(rA[k], lds_off, va);
+        else dma(rB[k - 3], lds_off, vb);
+    };
+
+    // ---- fragment reads: plane pl of 32-row block (k-contiguous) / 32-column block (reduction-major) -----------------
+    const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    auto frag_kc = [&](const char* img, int row) -> bf16x8 {
+        return *(const bf16x8*)(img + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
+    };
+    auto frag_km = [&](const char* img, int c0) -> bf16x8 {
+        const int kr = 8 * lh + tr_q, col = c0 + tr_c;
+        const char* p0 = img + kr * 512 + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * 512));     // kr + 4: same swizzle
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 fa[3][FM];            // [plane][row block]
+    bf16x8 fb[2][FN], fbh[2][FN];   // mid / lo planes [plane - 1][column block]; hi plane [tile parity][column block]
+    auto fetchA = [&](int stage, int pl, int i) {
+        const char* img = smem + stage * STAGE + pl * PL;
+        const int row = wm * (32 * FM) + i * 32;
+        fa[pl][i] = A_KM ? frag_km(img, row) : frag_kc(img, row + l31);
+    };
+    auto fetchB = [&](int stage, int pl, int j) {
+        const char* img = smem + stage * STAGE + OPB + pl * PL;
+        const int col = wn * (32 * FN) + j * 32;
+        const bf16x8 v = B_KM ? frag_km(img, col) : frag_kc(img, col + l31);
+        if (pl == 0) fbh[stage][j] = v;
+        else fb[pl - 1][j] = v;
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: tiles 0 and 1 --------------------------------------------------------------------------------------
+    if (it_begin < it_end) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) issue(0, k);
+        advance();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) issue(1, k);
+        advance();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile 0 has landed (this wave's pieces)
+    }
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[2] = clock64();
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fetchB(0, pl, j);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fetchA(0, pl, i);
+    }
+
+    // ---- one K-tile: 48 MFMAs per wave, row of blocks i = q / 12, plane pair (q % 12) / 2, column block q % 2 -------------
+    // ST = LDS stage of the current tile t.  Fragment replacement (tile t+1, stage ST ^ 1), always one MFMA behind the last
+    // reader: A row i-1 in front of MFMA 12 i + 1; B lo in front of MFMA 41, B mid in front of 47, A row 3 at the end; B hi
+    // (other register set) right behind the barrier.
+    constexpr int QB = DG_X3_QB;
+    static_assert(QB >= 1 && QB <= 12, "the tile barrier precedes the first read of tile t+1");
+    auto body = [&](auto ST_) {
+        constexpr int ST = decltype(ST_)::value;
+        dg_x3_static_for(std::make_integer_sequence<int, 48>{}, [&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            constexpr int i = q / 12, pr = (q % 12) / 2, j = q % 2;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q == QB) {
+                // this wave's DMA pieces of tile t+1 have landed and its fragment reads of tile t are complete; behind the
+                // barrier that holds for every wave: tile t+1 may be read, tile t's stage may be overwritten
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fetchB(ST ^ 1, 0, 0);
+                fetchB(ST ^ 1, 0, 1);
+            }
+            if constexpr (q % 12 == 1 && i > 0 && q > QB) {
+                fetchA(ST ^ 1, 0, i - 1);
+                fetchA(ST ^ 1, 1, i - 1);
+                fetchA(ST ^ 1, 2, i - 1);
+            }
+            if constexpr (q == 41) { fetchB(ST ^ 1, 2, 0); fetchB(ST ^ 1, 2, 1); }
+            if constexpr (q == 47) { fetchB(ST ^ 1, 1, 0); fetchB(ST ^ 1, 1, 1); }
+            if constexpr (PB[pr] == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fbh[ST][j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr] > 0 ? PB[pr] - 1 : 0][j], acc[i][j], 0, 0, 0);
+            // DMA of tile t+2 into the stage tile t has left: one piece behind every second MFMA after the barrier
+            if constexpr (q >= QB && q < QB + 12 && (q - QB) % 2 == 0) issue(ST, (q - QB) / 2);
+            if constexpr (q == QB + 11) advance();
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fetchA(ST ^ 1, 0, 3);
+        fetchA(ST ^ 1, 1, 3);
+        fetchA(ST ^ 1, 2, 3);
+    };
+    for (int it = it_begin; it < it_end; it += 2) {
+        body(std::integral_constant<int, 0>{});
+        if (it + 1 < it_end) body(std::integral_constant<int, 1>{});
+    }
+    // the clamped re-loads of the last tile and the fragment prefetch behind the last barrier still touch LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[3] = clock64();
+
+    // ---- epilogue (igemm.hip): acc[i][jn][r] = row (r&3)+8*(r>>2)+4*lh, col jn*32+l31 of the wave's 32x64 block i,
+    // transposed through a private [32][68] LDS region per wave, float4 stores with 16 lanes per 256-B row segment
+    const bool to_part = p.part != nullptr;
+    float* const eps = (float*)smem + wave * (32 * 68);
+    const int erow = lane >> 4, ec4 = (lane & 15) * 4;
+    const int ncol = n0 + wn * (32 * FN) + ec4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            eps[lr * 68 + l31] = acc[i][0][r];
+            eps[lr * 68 + 32 + l31] = acc[i][1][r];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + erow;
+            f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
+            const int m = m0 + wm * (32 * FM) + i * 32 + row;
+            if (m >= p.M || ncol >= p.Ng) continue;
+            float* dst;
+            long eoff;
+            if (to_part) {
+                const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m : (long)split * p.M + m;
+                dst = p.part;
+                eoff = srow * p.Ng + ncol;
+            } else if (MODE == MODE_DGRAD_S2) {
+                const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                dst = p.C;
+                eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ncol;
+            } else {
+                dst = p.C;
+                eoff = (long)m * p.Ng + ncol;
+            }
+            if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
+            *(f32x4*)(dst + eoff) = v;
+        }
+    }
+    if (stp) {
+        stp[4] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[5] = wall_clock64();
+        stp[7] = clock64();
+    }
+}
+
+// host: launch the plane kernel for a plan made by igemm.hip (mode, args); returns 0 when there is no instantiation
+int dg_igemm_dma_x3_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st) {
+    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    switch (mode) {
+        case MODE_FWD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD>), dim3(grid), dim3(512), 0, st, a); return 1;
+        default: return 0;
+    }
+}

@@ -16,12 +16,13 @@ __global__ void adam_advance_kernel(double* state, double lr, double b1, double 
 }
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-// P16: also write a bf16 (RNE) shadow of the updated parameters for the bf16 matrix path (+2 B/param on 28)
-template <bool P16>
+// P16 = 1: also write a bf16 (RNE) shadow of the updated parameters for the bf16 matrix path (+2 B/param on 28);
+// P16 = 3: the three bf16 planes of the f32x3 matrix path (dg_split3; planes `pstride` elements apart, +6 B/param)
+template <int P16>
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long n,
                                                         const double* __restrict__ state, float b1, float b2, float eps,
-                                                        float wd, float gscale, __bf16* __restrict__ p16) {
+                                                        float wd, float gscale, __bf16* __restrict__ p16, long pstride) {
     const float step_size = (float)state[1];
     const float bc2_sqrt = (float)state[2];
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
@@ -42,7 +43,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
         *(f32x4*)(p + i * 4) = pp;
         *(f32x4*)(m + i * 4) = mm;
         *(f32x4*)(v + i * 4) = vv;
-        if (P16) *(bf16x4_t*)(p16 + i * 4) = __builtin_convertvector(pp, bf16x4_t);
+        if (P16 == 1) *(bf16x4_t*)(p16 + i * 4) = __builtin_convertvector(pp, bf16x4_t);
+        if (P16 == 3) {
+            dg_bf16x4_t h, md, l;
+            dg_split3(pp, h, md, l);
+            *(dg_bf16x4_t*)(p16 + i * 4) = h;
+            *(dg_bf16x4_t*)(p16 + pstride + i * 4) = md;
+            *(dg_bf16x4_t*)(p16 + 2 * pstride + i * 4) = l;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (long e = n4 * 4; e < n; ++e) {
@@ -51,7 +59,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
             v[e] = v[e] * b2 + omb2 * gr * gr;
             const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
             p[e] = p[e] - step_size * (m[e] / denom);
-            if (P16) p16[e] = (__bf16)p[e];
+            if (P16 == 1) p16[e] = (__bf16)p[e];
+            if (P16 == 3) {
+                const __bf16 h = (__bf16)p[e];
+                const float r = p[e] - (float)h;
+                const __bf16 md = (__bf16)r;
+                p16[e] = h;
+                p16[pstride + e] = md;
+                p16[2 * pstride + e] = (__bf16)(r - (float)md);
+            }
         }
     }
 }
@@ -69,8 +85,8 @@ extern "C" int dg_adam_step_flat(float* p, const float* g, float* m, float* v, s
     long grid = ((long)(n / 4) + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(adam_step_kernel<false>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
-                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)nullptr);
+    hipLaunchKernelGGL(adam_step_kernel<0>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
+                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)nullptr, 0L);
     DG_CHECK_LAUNCH("adam_step");
     return DG_OK;
 }
@@ -81,9 +97,24 @@ extern "C" int dg_adam_step_flat_bf16(float* p, const float* g, float* m, float*
     long grid = ((long)(n / 4) + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(adam_step_kernel<true>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
-                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)p16);
+    hipLaunchKernelGGL(adam_step_kernel<1>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
+                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)p16, 0L);
     DG_CHECK_LAUNCH("adam_step_bf16");
+    return DG_OK;
+}
+// the same step, also writing the parameters' three bf16 planes (hi / mid / lo, plane_elems elements apart; plane_elems >= n, % 8 == 0)
+extern "C" int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n, const double* state, float beta1,
+                                    float beta2, float eps, float weight_decay, float grad_scale, void* p3, size_t plane_elems,
+                                    dg_stream_t stream) {
+    DG_CHECK_ARG(p && g && m && v && state && p3, "dg_adam_step_flat_x3: null pointer");
+    DG_CHECK_ARG(plane_elems >= n && plane_elems % 8 == 0, "dg_adam_step_flat_x3: plane distance %zu for %zu parameters", plane_elems, n);
+    if (n == 0) return DG_OK;
+    long grid = ((long)(n / 4) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(adam_step_kernel<3>, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state,
+                       beta1, beta2, eps, weight_decay, grad_scale, (__bf16*)p3, (long)plane_elems);
+    DG_CHECK_LAUNCH("adam_step_x3");
     return DG_OK;
 }
 // fp32 -> bf16 (RNE) copy: initial weight shadow / shadows of tensors that have no fused producer
@@ -102,5 +133,36 @@ extern "C" int dg_f32_to_bf16(const float* x, void* y, size_t n, dg_stream_t str
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, (long)n);
     DG_CHECK_LAUNCH("f32_to_bf16");
+    return DG_OK;
+}
+// fp32 -> three bf16 planes (dg_split3): plane operands of tensors that have no fused producer
+__global__ __launch_bounds__(256) void f32_to_bf16x3_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n, long pstride) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        dg_bf16x4_t h, md, l;
+        dg_split3(*(const f32x4*)(x + i * 4), h, md, l);
+        *(dg_bf16x4_t*)(y + i * 4) = h;
+        *(dg_bf16x4_t*)(y + pstride + i * 4) = md;
+        *(dg_bf16x4_t*)(y + 2 * pstride + i * 4) = l;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long e = n4 * 4; e < n; ++e) {
+            const __bf16 h = (__bf16)x[e];
+            const float r = x[e] - (float)h;
+            const __bf16 md = (__bf16)r;
+            y[e] = h;
+            y[pstride + e] = md;
+            y[2 * pstride + e] = (__bf16)(r - (float)md);
+        }
+}
+extern "C" int dg_f32_to_bf16x3(const float* x, void* y3, size_t n, size_t plane_elems, dg_stream_t stream) {
+    DG_CHECK_ARG(x && y3, "dg_f32_to_bf16x3: null pointer");
+    DG_CHECK_ARG(plane_elems >= n && plane_elems % 8 == 0, "dg_f32_to_bf16x3: plane distance %zu for %zu elements", plane_elems, n);
+    if (n == 0) return DG_OK;
+    long grid = ((long)(n / 4) + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(f32_to_bf16x3_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y3, (long)n, (long)plane_elems);
+    DG_CHECK_LAUNCH("f32_to_bf16x3");
     return DG_OK;
 }

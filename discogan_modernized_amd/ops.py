@@ -248,6 +248,64 @@ def _bf16_ok(op, n, h, wd, c, k, stride, pad):
     return SHADOW and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) >= 1
 
 
+# ---- f32x3 plane operands (mfma_dtype="f32x3") -----------------------------------------------------------------
+# A plane triple is three bf16 tensors hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid) of an fp32 tensor,
+# plane-major ([3, numel] bf16).  With X3 on, the conv wrappers hand plane triples of BOTH operands to dg_conv_*_x3 where the
+# shape has the plane kernel (csrc/igemm_dma_x3.hip); everything else keeps the fp32 tensors (register-staged f32x3 tiles).
+#   weights    : ``param._dg_x3`` = (flat [3, P] bf16 buffer of optim.Adam, element offset), refreshed by the Adam kernel;
+#                valid while ``param._version`` is unchanged (a foreign write re-splits the one weight)
+#   activations: side table like the bf16 shadows; filled by the producers (BatchNorm kernels) or, for a tensor nobody has
+#                split yet, by dg_f32_to_bf16x3 at its first use (the triple then serves the forward AND the weight gradient)
+X3 = False
+_PLANE_TAB = {}
+
+
+def planes_clear():
+    _PLANE_TAB.clear()
+
+
+def planes_put(t, t3):
+    _PLANE_TAB[t.data_ptr()] = (t, t3)
+
+
+def f32_to_bf16x3(x, out3):
+    """out3 ([3, P] bf16, P >= x.numel()) <- the plane triple of x's memory image."""
+    assert out3.dtype == torch.bfloat16 and out3.dim() == 2 and out3.shape[0] == 3 and out3.stride(1) == 1
+    _lib.check(_lib.load().dg_f32_to_bf16x3(_ptr(x), _ptr(out3), x.numel(), out3.stride(0), _stream()), "dg_f32_to_bf16x3")
+    return out3
+
+
+def planes_of(t):
+    """(plane-0 address, plane distance in bytes) of an fp32 activation / gradient tensor; splits it on first use."""
+    e = _PLANE_TAB.get(t.data_ptr())
+    if e is None or e[0].shape != t.shape or e[0].stride() != t.stride():
+        t3 = torch.empty((3, t.numel()), device=t.device, dtype=torch.bfloat16)
+        with _hbm("x3_split", 10.0 * t.numel()):
+            f32_to_bf16x3(t, t3)
+        planes_put(t, t3)
+    else:
+        t3 = e[1]
+    return t3.data_ptr(), t3.stride(0) * 2
+
+
+def weight_planes(w):
+    """(plane-0 address, plane distance in bytes) of a conv weight Parameter's triple."""
+    e = getattr(w, "_dg_x3", None)
+    if e is None:                                    # a parameter outside a flat Adam group
+        e = (torch.empty((3, w.numel()), device=w.device, dtype=torch.bfloat16), 0)
+        w._dg_x3, w._dg_x3_ver = e, None
+    buf, off = e
+    if getattr(w, "_dg_x3_ver", None) != w._version:            # e.g. load_state_dict wrote the fp32 weights
+        _lib.check(_lib.load().dg_f32_to_bf16x3(_ptr(w), buf.data_ptr() + 2 * off, w.numel(), buf.stride(0), _stream()),
+                   "dg_f32_to_bf16x3")
+        w._dg_x3_ver = w._version
+    return buf.data_ptr() + 2 * off, buf.stride(0) * 2
+
+
+def _x3_ok(op, n, h, wd, c, k, stride, pad):
+    return X3 and k > 1 and _lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad) == 1
+
+
 # ---- interior convolutions ------------------------------------------------------------------------------
 def _out_hw(h, w, stride, pad):
     return (h + 2 * pad - 4) // stride + 1, (w + 2 * pad - 4) // stride + 1
@@ -275,6 +333,14 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
+    if rows == 0 and _x3_ok(0, n, h, wd, c, k, stride, pad):
+        xp, xd = planes_of(x)
+        wp, wdist = weight_planes(w)
+        y = empty_nhwc(n, k, ho, wo, x.device)
+        with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
+            _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                       "dg_conv_fwd_x3")
+        return (y, None) if want_stats else y
     mixed = False
     xa, x16, wa, w16, o16 = x, 0, w, 0, 0
     if k == 1:
@@ -320,6 +386,14 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0
+    if rows == 0 and _x3_ok(1, n, h, wd, c, k, stride, pad):
+        dp, dd = planes_of(dy)
+        wp, wdist = weight_planes(w)
+        dx = empty_nhwc(n, c, h, wd, dy.device)
+        with _prof("conv_dgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
+            _lib.check(L.dg_conv_dgrad_x3(dp, dd, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                       "dg_conv_dgrad_x3")
+        return (dx, None) if want_stats else dx
     mixed = False
     da, d16, wa, w16, o16 = dy, 0, w, 0, 0
     if k == 1:
@@ -392,6 +466,13 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
+    if _x3_ok(2, n, h, wd, c, k, stride, pad):
+        dp, dd = planes_of(dy)
+        xp, xd = planes_of(x)
+        with _prof("conv_wgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
+            _lib.check(L.dg_conv_wgrad_x3(dp, dd, xp, xd, _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate), _ptr(ws), wsb,
+                                          _stream()), "dg_conv_wgrad_x3")
+        return dw
     da, d16, xa, x16 = dy, 0, x, 0
     if k == 1:
         x16 = int(_is16(x))
@@ -725,7 +806,12 @@ def adam_advance(state, lr, beta1, beta2):
     _lib.check(_lib.load().dg_adam_advance(_ptr(state), lr, beta1, beta2, _stream()), "dg_adam_advance")
 
 
-def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0, p16=None):
+def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scale=1.0, p16=None, p3=None):
+    if p3 is not None:      # (plane-0 address of this range, plane distance in elements): the f32x3 plane triples
+        with _hbm("adam", 34.0 * p.numel()):
+            _lib.check(_lib.load().dg_adam_step_flat_x3(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2,
+                                                        eps, weight_decay, grad_scale, p3[0], p3[1], _stream()), "dg_adam_step_flat_x3")
+        return
     if p16 is not None:
         with _hbm("adam", 30.0 * p.numel()):
             _lib.check(_lib.load().dg_adam_step_flat_bf16(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2,

@@ -59,6 +59,18 @@ class Adam:
             p._dg_bf16 = self.flat_p16[off:off + p.numel()].as_strided(p.shape, p.stride())
             p._dg_bf16_ver = p._version
 
+    def enable_x3_planes(self):
+        """Keep the three bf16 planes (hi / mid / lo, ops.f32_to_bf16x3) of every parameter for the f32x3 matrix path: one
+        flat [3, numel] bf16 buffer refreshed by the Adam kernel itself (+6 B/param), exposed as ``param._dg_x3`` =
+        (buffer, element offset)."""
+        if getattr(self, "flat_p3", None) is not None:
+            return
+        self.flat_p3 = torch.empty((3, self.numel), device=self.flat_p.device, dtype=torch.bfloat16)
+        ops.f32_to_bf16x3(self.flat_p, self.flat_p3)
+        for p, off in zip(self.params, self.offsets):
+            p._dg_x3 = (self.flat_p3, off)
+            p._dg_x3_ver = p._version
+
     # -- torch.optim.Optimizer surface used by the reference loop ------------------------------------
     def zero_grad(self, set_to_none: bool = True):
         self.flat_g.zero_()
@@ -99,10 +111,12 @@ class Adam:
         self._sync_foreign_grads()
         ops.adam_advance(self.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
         p16 = getattr(self, "flat_p16", None)
+        p3 = getattr(self, "flat_p3", None)
         for b, e in (active if active is not None else [(0, self.numel)]):
             ops.adam_step_flat(self.flat_p[b:e], self.flat_g[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], self.state,
                                float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                               float(grad_scale), p16=None if p16 is None else p16[b:e])
+                               float(grad_scale), p16=None if p16 is None else p16[b:e],
+                               p3=None if p3 is None else (p3.data_ptr() + 2 * b, self.numel))
 
     def state_dict(self):
         return dict(step=self.state[0:1].clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

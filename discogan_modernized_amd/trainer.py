@@ -54,7 +54,7 @@ class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
                  cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
-                 bucket_mb=128.0, act_dtype="f32"):
+                 bucket_mb=128.0, act_dtype="f32", x3_planes=True):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -127,6 +127,13 @@ class DiscoGANTrainer:
         if self.bf16_shadow:
             self.optim_gen.enable_bf16_shadow()
             self.optim_dis.enable_bf16_shadow()
+        # f32x3 path: the conv kernels read the three bf16 PLANES of their operands, written once per tensor (Adam: weights;
+        # ops.planes_of: activations and gradients) instead of splitting every fp32 value in every conv (ops.X3,
+        # csrc/igemm_dma_x3.hip); x3_planes=False keeps the register-staged split everywhere
+        self.x3_planes = mfma_dtype == "f32x3" and bool(x3_planes)
+        if self.x3_planes:
+            self.optim_gen.enable_x3_planes()
+            self.optim_dis.enable_x3_planes()
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -360,7 +367,9 @@ class DiscoGANTrainer:
             _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 2)
         _ops.SHADOW = self.bf16_shadow
         _ops.ACT16 = self.act_dtype == "bf16"
+        _ops.X3 = self.x3_planes
         _ops.shadow_clear()
+        _ops.planes_clear()
         try:
             out = self.forward_losses(A, B, iters, need_losses)
             (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
@@ -369,7 +378,9 @@ class DiscoGANTrainer:
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
             _ops.SHADOW = False
             _ops.ACT16 = False
+            _ops.X3 = False
             _ops.shadow_clear()
+            _ops.planes_clear()
             if self.mfma_dtype != "f32":
                 _l.set_option("bf16", 0)          # the library default stays exact fp32 for everyone else
         if self.skip_dead_work and not dstep:

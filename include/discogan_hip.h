@@ -285,6 +285,30 @@ int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, 
 int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
                         int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 
+/* ---- fp32 operands as THREE bf16 PLANES for the f32x3 matrix path (option "bf16" = 2; DiscoGANTrainer(mfma_dtype="f32x3")) ----
+ * A plane triple of an fp32 tensor v: hi = bf16(v) (RNE), mid = bf16(v - hi), lo = bf16(v - hi - mid) -- 24 significand
+ * bits of v (both subtractions are exact in fp32).  Layout: plane-major, each plane in the tensor's own logical layout;
+ * `*_plane` = distance between planes in BYTES (multiple of 16, >= 2 * numel; a weight inside a flat parameter group uses
+ * the group's distance), dg_f32_to_bf16x3 / dg_adam_step_flat_x3 take it in ELEMENTS (multiple of 8).  Written by the
+ * tensor's producer: dg_adam_step_flat_x3 (weights, +6 B/param), dg_bn_act_fwd_x3 / dg_bn_act_bwd_x3 (activations /
+ * gradients), dg_f32_to_bf16x3 (everything else).  The *_x3 convolutions return the fp32 convolution with the same six
+ * bf16 MFMAs per product block and the same reduction order as the fp32-pointer entry points under option "bf16" = 2
+ * (bit-identical on an unsplit GEMM), without the per-element split in the conv kernel: csrc/igemm_dma_x3.hip, operand
+ * planes global -> LDS by `buffer_load ... lds`, 256x256 tile.  dg_conv_x3_planes_ok: 1 = the shape has the plane kernel
+ * (GEMM of at least 192 rows and columns, C % 16 == 0 forward / K % 16 == 0 input-grad), 0 = use dg_conv_fwd / _dgrad /
+ * _wgrad.  Outputs are fp32; the caller keeps the fp32 tensors for BatchNorm and the element-wise kernels. */
+int dg_f32_to_bf16x3(const float* x, void* y_planes, size_t n, size_t plane_elems, dg_stream_t s);
+int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n, const double* state,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                         void* p_planes, size_t plane_elems, dg_stream_t s);
+int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
+int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, float* y, int N, int H, int W,
+                   int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad_x3(const void* dy_planes, int64_t dy_plane, const void* w_planes, int64_t w_plane, float* dx, int N, int H, int W,
+                     int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_wgrad_x3(const void* dy_planes, int64_t dy_plane, const void* x_planes, int64_t x_plane, float* dw, int N, int H, int W,
+                     int C, int K, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+
 /* ---- bf16 ACTIVATION STORAGE (option "bf16" = 1; DiscoGANTrainer(mfma_dtype="bf16", act_dtype="bf16")) --------------------
  * Feature maps and their gradients live in HBM as bf16 ONLY (no fp32 copy): the conv epilogues round the fp32
  * accumulators once (y_bf16 / dx_bf16 of the *_mixed convolutions above; never the weight gradient), BatchNorm reads

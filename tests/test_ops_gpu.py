@@ -222,6 +222,64 @@ def test_conv_f32x3_is_fp32_accurate(N, C, K, H):
         assert a <= 2.0 * b + 2e-7, f"f32x3 {what}: {a:.2e} vs exact-fp32 path {b:.2e}"
 
 
+# shapes that reach the plane kernel (igemm_dma_x3.hip: GEMM rows and columns >= 192; C % 16 forward, K % 16 input-grad)
+X3_SHAPES = DMA_SHAPES + [
+    (5, 224, 288, 16),     # C = 14 chunks of 16, K = 18 chunks: neither is a multiple of 64 (the bf16 LDS-DMA kernel refuses these)
+    (32, 192, 512, 8),     # 512 rows, 192 input-grad columns (a 3/4 used tile)
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", X3_SHAPES)
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
+    """mfma_dtype="f32x3" with PLANE operands: the three bf16 planes of both operands are written once (dg_f32_to_bf16x3) and
+    igemm_dma_x3.hip stages them by LDS-DMA.  Same six MFMAs per product block and the same reduction order as the
+    register-staged split of igemm.hip: bit-identical on an unsplit GEMM, fp32 tolerance against fp64 otherwise, and at most
+    2x the exact-fp32 MFMA path's distance from fp64."""
+    x, w, dy = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    y64 = TF.conv2d(x.double(), w.double(), stride=2, padding=1)
+    dx64 = TF.conv_transpose2d(dy.double(), w.double(), stride=2, padding=1)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=2, padding=1)
+    xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+    e32 = (_rel(ops.conv_fwd(xg, wg, 2, 1), y64), _rel(ops.conv_dgrad(dyg, wg, (H, H), 2, 1), dx64), _rel(ops.conv_wgrad(dyg, xg, 2, 1), dw64))
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    _lib.set_option("splitk", splitk)
+    try:
+        yreg, dxreg, dwreg = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
+        assert all(L.dg_conv_x3_planes_ok(op, N, H, H, C, K, 2, 1) == 1 for op in (0, 2))       # input-grad: where C >= 192
+        ops.X3 = True
+        y, dx, dw = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
+        dw2 = ops.conv_wgrad(dyg, xg, 2, 1, out=dw.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        assert len(ops._PLANE_TAB) == 2 and hasattr(wg, "_dg_x3")       # x and dy were split once each, the weight once
+        # the triple reproduces the fp32 tensor exactly
+        t3 = ops._PLANE_TAB[xg.data_ptr()][1].float().sum(0)
+        assert torch.equal(t3, xg.permute(0, 2, 3, 1).reshape(-1))
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("splitk", 0)
+        _lib.set_option("bf16", 0)
+    close(y, y64.float(), what="plane conv fwd")
+    close(dx, dx64.float(), rtol=2e-4, what="plane conv dgrad")
+    close(dw, dw64.float(), rtol=2e-4, what="plane conv wgrad")
+    close(dw2, 2 * dw64.float(), rtol=2e-4, what="plane conv wgrad accumulate")
+    ex3 = (_rel(y, y64), _rel(dx, dx64), _rel(dw, dw64))
+    if splitk == 0:          # the default plans of both paths (a forced single slab has 8x longer accumulation chains)
+        for a, b, what in zip(ex3, e32, ("fwd", "dgrad", "wgrad")):
+            assert a <= 2.0 * b + 2e-7, f"plane {what}: {a:.2e} vs exact-fp32 path {b:.2e}"
+    close(y, yreg, what="plane vs register-staged fwd")
+    close(dx, dxreg, rtol=2e-4, what="plane vs register-staged dgrad")
+    close(dw, dwreg, rtol=2e-4, what="plane vs register-staged wgrad")
+    if splitk == 1:          # one slab and the same K walk: the same sequence of MFMAs per accumulator as the register-staged kernel
+        assert torch.equal(dw, dwreg), "plane kernel vs register-staged split: weight gradient"
+        if C % 64:           # (channel counts that are multiples of 64 run the four 16-channel tiles of a 128-byte line back to back)
+            assert torch.equal(y, yreg), "plane kernel vs register-staged split: forward"
+        if K % 64:
+            assert torch.equal(dx, dxreg), "plane kernel vs register-staged split: input gradient"
+
+
 @pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100)])
 def test_conv_head_f32x3(N, C, K):
     x, w, dy = rnd(N, C, 4, 4, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, 1, 1, seed=3)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--act16", type=int, default=0, help="time the BatchNorm / edge kernels on bf16-stored feature maps instead of the fp32 ones")
     ap.add_argument("--dma_mfma", type=int, default=0, help="32: the LDS-DMA kernel's 32x32x16 body (default 16x16x32)")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
+    ap.add_argument("--x3planes", type=int, default=0, help="with --bf16 2: plane operands (igemm_dma_x3.hip), what the f32x3 trainer does")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
     a = ap.parse_args()
@@ -56,6 +57,7 @@ def main():
     _lib.set_option("no_dma", a.no_dma)
     _lib.set_option("dma_mfma", a.dma_mfma)
     ops.SHADOW = bool(a.shadow)
+    ops.X3 = bool(a.x3planes)
     only = {int(v) for v in a.layers.split(",") if v}
 
     def shadowed(t):
