@@ -1466,7 +1466,7 @@ extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int 
 // a3 / b3 point at plane 0 (hi) of an operand; planes 1 (mid) and 2 (lo) follow a_plane / b_plane BYTES further on (>= the
 // tensor's 2 * numel; a weight inside a flat parameter group has the group's plane distance).  Written by dg_f32_to_bf16x3 or
 // by the fused producers (dg_adam_step_flat_x3, dg_bn_act_fwd_x3, dg_bn_act_bwd_x3); outputs are fp32.
-static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_plane, float* out, int N, int H, int W, int C, int K,
+static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_plane, int b_transposed, float* out, int N, int H, int W, int C, int K,
                    int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     const char* who = op == 0 ? "dg_conv_fwd_x3" : (op == 1 ? "dg_conv_dgrad_x3" : "dg_conv_wgrad_x3");
     ConvGeom g;
@@ -1482,19 +1482,22 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
                  "%s: plane distances %ld / %ld (operands are %u / %u bytes per plane)", who, a_plane, b_plane, pl.a.abytes, pl.a.bbytes);
     pl.a.A = (const float*)a3; pl.a.B = (const float*)b3; pl.a.C = out; pl.a.accumulate = accumulate;
     pl.a.a_plane = a_plane; pl.a.b_plane = b_plane;
+    DG_CHECK_ARG(!b_transposed || op == 0, "%s: only the forward form takes transposed weight planes", who);
+    pl.a.b_transposed = b_transposed ? 1 : 0;
     return run_plan(who, pl, ws, ws_bytes, st);
 }
-extern "C" int dg_conv_fwd_x3(const void* x3, long x_plane, const void* w3, long w_plane, float* y, int N, int H, int W, int C, int K,
-                              int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_x3(0, x3, x_plane, w3, w_plane, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+// w_transposed: w3 is the transposed copy wT[(r, s, c)][k] of the weight planes (dg_x3_transpose_planes) -- the faster form
+extern "C" int dg_conv_fwd_x3(const void* x3, long x_plane, const void* w3, long w_plane, int w_transposed, float* y, int N, int H, int W,
+                              int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(0, x3, x_plane, w3, w_plane, w_transposed, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int dg_conv_dgrad_x3(const void* dy3, long dy_plane, const void* w3, long w_plane, float* dx, int N, int H, int W, int C, int K,
                                 int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_x3(1, dy3, dy_plane, w3, w_plane, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+    return conv_x3(1, dy3, dy_plane, w3, w_plane, 0, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, const void* x3, long x_plane, float* dw, int N, int H, int W, int C, int K,
                                 int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_x3(2, dy3, dy_plane, x3, x_plane, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return conv_x3(2, dy3, dy_plane, x3, x_plane, 0, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 // does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)
 extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {

@@ -22,6 +22,7 @@ struct IgemmArgs {
     int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element);
                          // 3 (PREC 2, igemm_dma_x3.hip): three bf16 planes hi / mid / lo, plane-major, a_plane / b_plane bytes apart
     long a_plane, b_plane;
+    int b_transposed;    // igemm_dma_x3.hip FWD: the weight planes are the transposed copy [(r, s, c)][k]
     int out16;           // the output tensor C is bf16 (RNE of the fp32 accumulators; FWD / DGRAD modes, never the weight gradient)
     int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads
     int bias_mod;        // channels the bias cycles over in the column index (Ng, or Cc for DGRAD_PLAIN's (r,s,c) columns)

@@ -41,14 +41,18 @@ __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...
 #ifndef DG_X3_QB
 #define DG_X3_QB 8
 #endif
+#define DG_X3T_MAX 48
 
-template <int MODE>
+// BT (FWD only): the weight planes are the TRANSPOSED copy wT[(r, s, c)][k] (dg_x3_transpose_planes): the B tile of a K-tile is
+// 16 reduction rows x 256 contiguous out channels (512-byte pieces) instead of 256 rows x 32 bytes 16 C elements apart.
+template <int MODE, bool BT>
 __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
+    static_assert(!BT || MODE == MODE_FWD, "the transposed weight copy serves the forward form");
     constexpr int WN = 4, FM = 4, FN = 2;               // 2 x 4 waves, 4 x 2 accumulator blocks of 32x32 per wave
     constexpr int BM = 256, BN = 256, KT = 16;
     constexpr bool A_KM = MODE == MODE_WGRAD;           // operand image is reduction-major ([k][cols])
-    constexpr bool B_KM = MODE != MODE_FWD;
+    constexpr bool B_KM = MODE != MODE_FWD || BT;
     constexpr int PL = 256 * KT * 2;                    // one plane of one operand: 8 KB
     constexpr int OPB = 3 * PL, STAGE = 2 * OPB;        // 48 KB per stage
     constexpr int LDS_BYTES = 2 * STAGE;
@@ -173,9 +177,12 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     int wg_c = 0, wg_cst = 0, wg_ybad = -1, wg_xbad = -1, wg_colbad = 0;
     const bool wg_s2 = p.stride == 2;
     const int wg_lpm = wg_s2 ? 2 : 4, wg_pxm = wg_s2 ? -1 : 0;
-    if (MODE == MODE_FWD) {
+    if (MODE == MODE_FWD && !BT) {
         const int k = n0 + kc_row;
         b_ob = k < K ? (k * 16 * Cc + kc_g * 8) * 2 : OOR;
+    } else if (MODE == MODE_FWD) {
+        const int col = n0 + km_gc * 8;
+        b_ob = col < K ? (km_row * K + col) * 2 : OOR;
     } else {
         const int col = n0 + km_gc * 8;
         if (MODE == MODE_DGRAD_S2) {
@@ -250,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     };
     auto b_voff = [&]() -> int {
         if (MODE == MODE_FWD) {
-            return b_ob + (((fwd_r() * 4 + fwd_s()) * Cc) + coff()) * 2;
+            const int red = (fwd_r() * 4 + fwd_s()) * Cc + coff();        // first reduction element of the tile
+            return BT ? b_ob + red * K * 2 : b_ob + red * 2;
         } else if (MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
@@ -427,9 +435,106 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
 int dg_igemm_dma_x3_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
     switch (mode) {
-        case MODE_FWD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD>), dim3(grid), dim3(512), 0, st, a); return 1;
-        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2>), dim3(grid), dim3(512), 0, st, a); return 1;
-        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_FWD:
+            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false>), dim3(grid), dim3(512), 0, st, a);
+            return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false>), dim3(grid), dim3(512), 0, st, a); return 1;
         default: return 0;
     }
+}
+
+// ---- transposed weight planes for the forward form -------------------------------------------------------------------------
+// For every conv weight of a flat parameter group: planes [3][K][J] (J = 16 C, the KRSC image) -> [3][J][K] at the same flat
+// offset of a second plane buffer.  One launch for the whole group: 64 x 64 tiles through LDS, 128-byte rows both ways.
+struct X3TransposeTable {
+    int n;
+    int tile0[DG_X3T_MAX + 1];      // first tile of weight i (prefix sums); tile0[n] = grid
+    int K[DG_X3T_MAX], J[DG_X3T_MAX];
+    long off[DG_X3T_MAX];           // element offset of the weight inside a plane
+};
+__global__ __launch_bounds__(256) void x3_transpose_kernel(const __bf16* __restrict__ src, __bf16* __restrict__ dst, long plane, X3TransposeTable t) {
+    // the tile as 64 k rows x 32 words (a word = two neighbouring j of one k), pitch 33: the loads write rows, the stores read
+    // columns -- 8 words W[8 q .. 8 q + 7][jp] give the 16-byte runs of output rows j = 2 jp (low halves) and 2 jp + 1 (high halves)
+    __shared__ unsigned tile[64][33];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    int wi = 0;
+    while (wi + 1 < t.n && (int)blockIdx.x >= t.tile0[wi + 1]) ++wi;
+    const int K = t.K[wi], J = t.J[wi];
+    const int tj = (J + 63) / 64;
+    const int b = blockIdx.x - t.tile0[wi];
+    const int k0 = (b / tj) * 64, j0 = (b % tj) * 64;
+    const bool vec = (K % 8 == 0) && (J % 8 == 0) && (t.off[wi] % 8 == 0);
+    const int lk = threadIdx.x >> 2, lv = threadIdx.x & 3;          // load: row k, 16-byte vectors lv and lv + 4 of the row
+    const int sq = threadIdx.x & 7, sjp = threadIdx.x >> 3;          // store: k run 8 sq .. 8 sq + 7 of output rows 2 sjp, 2 sjp + 1
+    for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short* s = (const unsigned short*)src + pl * plane + t.off[wi];
+        unsigned short* d = (unsigned short*)dst + pl * plane + t.off[wi];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + lk, j = j0 + (lv + 4 * h) * 8;
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (k < K) {
+                if (vec && j < J) v = *(const u32x4*)(s + (long)k * J + j);
+                else if (!vec) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (j + e < J) v[e >> 1] |= (unsigned)s[(long)k * J + j + e] << (16 * (e & 1));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[lk][(lv + 4 * h) * 4 + e] = v[e];
+        }
+        __syncthreads();
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = tile[8 * sq + e][sjp];
+        u32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = (w[2 * e] & 0xffffu) | (w[2 * e + 1] << 16);
+            hi[e] = (w[2 * e] >> 16) | (w[2 * e + 1] & 0xffff0000u);
+        }
+        const int j = j0 + 2 * sjp, k = k0 + 8 * sq;
+        if (vec) {
+            if (k < K && j < J) {
+                *(u32x4*)(d + (long)j * K + k) = lo;
+                *(u32x4*)(d + (long)(j + 1) * K + k) = hi;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (k + e < K && j < J) d[(long)j * K + k + e] = (unsigned short)(lo[e >> 1] >> (16 * (e & 1)));
+                if (k + e < K && j + 1 < J) d[(long)(j + 1) * K + k + e] = (unsigned short)(hi[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        __syncthreads();
+    }
+}
+// w_off / w_K / w_J: host arrays of n conv weights ([K][J] images at element offset w_off inside each plane); src and dst are
+// [3][plane_elems] bf16 buffers
+extern "C" int dg_x3_transpose_planes(const void* src_planes, void* dst_planes, size_t plane_elems, const int64_t* w_off,
+                                      const int* w_K, const int* w_J, int n, dg_stream_t stream) {
+    DG_CHECK_ARG(src_planes && dst_planes && w_off && w_K && w_J, "dg_x3_transpose_planes: null pointer");
+    DG_CHECK_ARG(n >= 0, "dg_x3_transpose_planes: n=%d", n);
+    for (int i0 = 0; i0 < n; i0 += DG_X3T_MAX) {
+        X3TransposeTable t;
+        t.n = n - i0 < DG_X3T_MAX ? n - i0 : DG_X3T_MAX;
+        int tiles = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const int K = w_K[i0 + i], J = w_J[i0 + i];
+            DG_CHECK_ARG(K >= 1 && J >= 1 && w_off[i0 + i] >= 0 && (size_t)(w_off[i0 + i] + (long)K * J) <= plane_elems,
+                         "dg_x3_transpose_planes: weight %d (K=%d, J=%d, offset %ld) outside the plane", i0 + i, K, J, (long)w_off[i0 + i]);
+            t.tile0[i] = tiles;
+            t.K[i] = K; t.J[i] = J; t.off[i] = w_off[i0 + i];
+            tiles += ((K + 63) / 64) * ((J + 63) / 64);
+        }
+        t.tile0[t.n] = tiles;
+        if (tiles == 0) continue;
+        hipLaunchKernelGGL(x3_transpose_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src_planes,
+                           (__bf16*)dst_planes, (long)plane_elems, t);
+        DG_CHECK_LAUNCH("x3_transpose");
+    }
+    return DG_OK;
 }

@@ -288,18 +288,41 @@ def planes_of(t):
     return t3.data_ptr(), t3.stride(0) * 2
 
 
-def weight_planes(w):
-    """(plane-0 address, plane distance in bytes) of a conv weight Parameter's triple."""
+def x3_transpose_table(convs):
+    """Host-side table for x3_transpose_planes: convs = [(element offset inside a plane, K, J = 16 C), ...]."""
+    import ctypes as C
+    n = len(convs)
+    return (n, (C.c_int64 * max(n, 1))(*[c[0] for c in convs]), (C.c_int * max(n, 1))(*[c[1] for c in convs]),
+            (C.c_int * max(n, 1))(*[c[2] for c in convs]))
+
+
+def x3_transpose_planes(src3, dst3, table):
+    """dst3 <- for every conv weight of the table the [K][J] plane images of src3 transposed to [J][K] (same offsets)."""
+    n, off, k, j = table
+    assert src3.shape == dst3.shape and src3.stride(0) == dst3.stride(0)
+    nbytes = 12.0 * sum(int(k[i]) * int(j[i]) for i in range(n))
+    with _hbm("x3_split", nbytes):
+        _lib.check(_lib.load().dg_x3_transpose_planes(_ptr(src3), _ptr(dst3), src3.stride(0), off, k, j, n, _stream()),
+                   "dg_x3_transpose_planes")
+
+
+def weight_planes(w, transposed=False):
+    """(plane-0 address, plane distance in bytes, is the transposed copy) of a conv weight Parameter's triple.  transposed:
+    prefer the [(r, s, c)][k] copy the forward form of the plane kernel reads (weights of a flat Adam group have one)."""
     e = getattr(w, "_dg_x3", None)
     if e is None:                                    # a parameter outside a flat Adam group
-        e = (torch.empty((3, w.numel()), device=w.device, dtype=torch.bfloat16), 0)
+        e = (torch.empty((3, w.numel()), device=w.device, dtype=torch.bfloat16), 0, None)
         w._dg_x3, w._dg_x3_ver = e, None
-    buf, off = e
+    buf, off, buft = e
     if getattr(w, "_dg_x3_ver", None) != w._version:            # e.g. load_state_dict wrote the fp32 weights
         _lib.check(_lib.load().dg_f32_to_bf16x3(_ptr(w), buf.data_ptr() + 2 * off, w.numel(), buf.stride(0), _stream()),
                    "dg_f32_to_bf16x3")
+        if buft is not None:
+            x3_transpose_planes(buf, buft, x3_transpose_table([(off, w.shape[0], 16 * w.shape[1])]))
         w._dg_x3_ver = w._version
-    return buf.data_ptr() + 2 * off, buf.stride(0) * 2
+    if transposed and buft is not None:
+        return buft.data_ptr() + 2 * off, buft.stride(0) * 2, 1
+    return buf.data_ptr() + 2 * off, buf.stride(0) * 2, 0
 
 
 def _x3_ok(op, n, h, wd, c, k, stride, pad):
@@ -335,10 +358,10 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
     if rows == 0 and _x3_ok(0, n, h, wd, c, k, stride, pad):
         xp, xd = planes_of(x)
-        wp, wdist = weight_planes(w)
+        wp, wdist, wt = weight_planes(w, transposed=True)
         y = empty_nhwc(n, k, ho, wo, x.device)
         with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
-            _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+            _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
                        "dg_conv_fwd_x3")
         return (y, None) if want_stats else y
     mixed = False
@@ -388,7 +411,7 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
         rows = 0
     if rows == 0 and _x3_ok(1, n, h, wd, c, k, stride, pad):
         dp, dd = planes_of(dy)
-        wp, wdist = weight_planes(w)
+        wp, wdist, _ = weight_planes(w)
         dx = empty_nhwc(n, c, h, wd, dy.device)
         with _prof("conv_dgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
             _lib.check(L.dg_conv_dgrad_x3(dp, dd, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),

@@ -67,9 +67,18 @@ class Adam:
             return
         self.flat_p3 = torch.empty((3, self.numel), device=self.flat_p.device, dtype=torch.bfloat16)
         ops.f32_to_bf16x3(self.flat_p, self.flat_p3)
+        # the forward form of the plane kernel wants the conv weights' planes TRANSPOSED ([(r, s, c)][k]): a second buffer,
+        # same flat offsets, rewritten for all conv weights of the group by one launch behind every Adam step
+        convs = [(off, p.shape[0], 16 * p.shape[1]) for p, off in zip(self.params, self.offsets)
+                 if p.dim() == 4 and tuple(p.shape[2:]) == (4, 4) and p.shape[0] > 1 and ops.is_krsc(p)]
+        self.flat_p3t = torch.zeros((3, self.numel), device=self.flat_p.device, dtype=torch.bfloat16) if convs else None
+        self._x3t_table = ops.x3_transpose_table(convs)
+        conv_offs = {c[0] for c in convs}
         for p, off in zip(self.params, self.offsets):
-            p._dg_x3 = (self.flat_p3, off)
+            p._dg_x3 = (self.flat_p3, off, self.flat_p3t if off in conv_offs else None)
             p._dg_x3_ver = p._version
+        if convs:
+            ops.x3_transpose_planes(self.flat_p3, self.flat_p3t, self._x3t_table)
 
     # -- torch.optim.Optimizer surface used by the reference loop ------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -117,6 +126,8 @@ class Adam:
                                float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                                float(grad_scale), p16=None if p16 is None else p16[b:e],
                                p3=None if p3 is None else (p3.data_ptr() + 2 * b, self.numel))
+        if p3 is not None and self.flat_p3t is not None:
+            ops.x3_transpose_planes(p3, self.flat_p3t, self._x3t_table)
 
     def state_dict(self):
         return dict(step=self.state[0:1].clone(), exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

@@ -296,14 +296,20 @@ int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, 
  * (bit-identical on an unsplit GEMM), without the per-element split in the conv kernel: csrc/igemm_dma_x3.hip, operand
  * planes global -> LDS by `buffer_load ... lds`, 256x256 tile.  dg_conv_x3_planes_ok: 1 = the shape has the plane kernel
  * (GEMM of at least 192 rows and columns, C % 16 == 0 forward / K % 16 == 0 input-grad), 0 = use dg_conv_fwd / _dgrad /
- * _wgrad.  Outputs are fp32; the caller keeps the fp32 tensors for BatchNorm and the element-wise kernels. */
+ * _wgrad.  Outputs are fp32; the caller keeps the fp32 tensors for BatchNorm and the element-wise kernels.
+ * dg_conv_fwd_x3 with w_transposed != 0 reads the weight planes as wT[(r, s, c)][k] (k contiguous): a K-tile of the weight
+ * operand is then 16 rows of 512 contiguous bytes instead of 256 pieces of 32 bytes (forward K loop 49-81 % -> ~90 % of the
+ * matrix rate).  dg_x3_transpose_planes writes that copy for n conv weights of a plane buffer in one launch per 48 weights
+ * ([K][J] images, J = 16 C, at element offsets w_off inside each plane; host arrays). */
 int dg_f32_to_bf16x3(const float* x, void* y_planes, size_t n, size_t plane_elems, dg_stream_t s);
 int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n, const double* state,
                          float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                          void* p_planes, size_t plane_elems, dg_stream_t s);
+int dg_x3_transpose_planes(const void* src_planes, void* dst_planes, size_t plane_elems, const int64_t* w_off, const int* w_K,
+                           const int* w_J, int n, dg_stream_t s);
 int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
-int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, float* y, int N, int H, int W,
-                   int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, int w_transposed, float* y,
+                   int N, int H, int W, int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_dgrad_x3(const void* dy_planes, int64_t dy_plane, const void* w_planes, int64_t w_plane, float* dx, int N, int H, int W,
                      int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_wgrad_x3(const void* dy_planes, int64_t dy_plane, const void* x_planes, int64_t x_plane, float* dw, int N, int H, int W,

@@ -253,6 +253,15 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
         dw2 = ops.conv_wgrad(dyg, xg, 2, 1, out=dw.clone(), accumulate=True)
         torch.cuda.synchronize()
         assert len(ops._PLANE_TAB) == 2 and hasattr(wg, "_dg_x3")       # x and dy were split once each, the weight once
+        # the forward form on the TRANSPOSED weight planes (what a weight of a flat Adam group gets): the same MFMAs in the
+        # same order, only the weight tile's path into LDS differs -> bit-identical
+        buf = wg._dg_x3[0]
+        wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
+        yt = ops.conv_fwd(xg, wg, 2, 1)
+        assert ops.weight_planes(wg, transposed=True)[2] == 1
+        t_ref = buf.view(3, K, 16 * C).transpose(1, 2).reshape(3, -1)
+        assert torch.equal(wg._dg_x3[2], t_ref), "dg_x3_transpose_planes"
+        assert torch.equal(yt, y), "forward on transposed weight planes"
         # the triple reproduces the fp32 tensor exactly
         t3 = ops._PLANE_TAB[xg.data_ptr()][1].float().sum(0)
         assert torch.equal(t3, xg.permute(0, 2, 3, 1).reshape(-1))
@@ -278,6 +287,24 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
             assert torch.equal(y, yreg), "plane kernel vs register-staged split: forward"
         if K % 64:
             assert torch.equal(dx, dxreg), "plane kernel vs register-staged split: input gradient"
+
+
+def test_x3_transpose_planes_group():
+    """dg_x3_transpose_planes over a flat plane buffer holding several weights: [K][J] images -> [J][K] at the same offsets
+    (16-byte path for K % 8 == 0 and J % 8 == 0, element path otherwise, ragged 64 x 64 tiles); the rest of dst is untouched."""
+    shapes = [(256, 16 * 64), (100, 16 * 32), (36, 80), (8, 16), (200, 16 * 24), (64, 64)]
+    offs, total = [], 0
+    for k, j in shapes:
+        offs.append(total)
+        total += (k * j + 63) // 64 * 64 + 64
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(3, total, generator=g).to(DEV).bfloat16()
+    dst = torch.full_like(src, 7.0)
+    ops.x3_transpose_planes(src, dst, ops.x3_transpose_table([(o, k, j) for o, (k, j) in zip(offs, shapes)]))
+    ref = torch.full_like(src, 7.0)
+    for o, (k, j) in zip(offs, shapes):
+        ref[:, o:o + k * j] = src[:, o:o + k * j].view(3, k, j).transpose(1, 2).reshape(3, -1)
+    assert torch.equal(dst, ref)
 
 
 @pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100)])

@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--act16", type=int, default=0, help="time the BatchNorm / edge kernels on bf16-stored feature maps instead of the fp32 ones")
     ap.add_argument("--dma_mfma", type=int, default=0, help="32: the LDS-DMA kernel's 32x32x16 body (default 16x16x32)")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
-    ap.add_argument("--x3planes", type=int, default=0, help="with --bf16 2: plane operands (igemm_dma_x3.hip), what the f32x3 trainer does")
+    ap.add_argument("--x3planes", type=int, default=0, help="with --bf16 2: plane operands (igemm_dma_x3.hip), what the f32x3 trainer does; 2 = forward on the transposed weight planes")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
     a = ap.parse_args()
@@ -87,6 +87,9 @@ def main():
         w = shadowed(ops.empty_krsc(K, C, dev).normal_())
         dy = shadowed(ops.empty_nhwc(N, K, H // 2, H // 2, dev).normal_())
         gf = 2.0 * N * (H // 2) ** 2 * K * C * 16 / 1e9
+        if a.x3planes == 2:      # with the transposed weight copy (weights of a flat Adam group have one)
+            buf = torch.empty((3, w.numel()), device=dev, dtype=torch.bfloat16)
+            w._dg_x3, w._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
         t1 = timeit(lambda: ops.conv_fwd(x, w, 2, 1))
         t2 = timeit(lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1))
         t3 = timeit(lambda: ops.conv_wgrad(dy, x, 2, 1))

@@ -9,9 +9,10 @@ from discogan_modernized_amd import ops, _lib
 
 op = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 C, K, H, N = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (64, 128, 32, 256)
-MODE = sys.argv[6] if len(sys.argv) > 6 else "f32"     # f32 | bf16 (fp32 tensors, bf16 tiles) | x3 | dma (bf16 tensors in and out: LDS-DMA kernel where the shape allows)
+MODE = sys.argv[6] if len(sys.argv) > 6 else "f32"     # f32 | bf16 (fp32 tensors, bf16 tiles) | x3 | x3p (x3 with plane operands: igemm_dma_x3.hip) | dma (bf16 tensors in and out: LDS-DMA kernel where the shape allows)
 dev = "cuda"
-_lib.set_option("bf16", {"f32": 0, "bf16": 1, "x3": 2, "dma": 1}[MODE])
+_lib.set_option("bf16", {"f32": 0, "bf16": 1, "x3": 2, "x3p": 2, "dma": 1}[MODE])
+ops.X3 = MODE == "x3p"
 adt = torch.bfloat16 if MODE == "dma" else torch.float32
 x = ops.empty_nhwc(N, C, H, H, dev, adt).normal_()
 w = ops.krsc_param(torch.randn(K, C, 4, 4, device=dev) * 0.05)
