@@ -1081,7 +1081,7 @@ struct Plan {
 };
 
 int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);      // igemm_dma.hip
-int dg_igemm_dma_x3_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
+int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
     const int cch = (Ng + 127) / 128;
@@ -1182,15 +1182,20 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         ((pl->mode == MODE_FWD && g.C % 64 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 64 == 0) || pl->mode == MODE_WGRAD))
         pl->dma = 1;
     // plane kernel (igemm_dma_x3.hip): the same tile and grid rules with 16-deep K-tiles
-    if (a.prec == 2 && a16 == 3 && b16 == 3 && dg_get_option(DG_OPT_NO_DMA) == 0 && pl->kt == 16 && a.Ng >= 192 && a.M >= 192 &&
-        g.C % 8 == 0 && g.K % 8 == 0 &&
-        ((pl->mode == MODE_FWD && g.C % 16 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 16 == 0) || pl->mode == MODE_WGRAD))
-        pl->dma = 2;
-    const int BM = pl->dma ? 256 : 64 * pl->wm, BN = pl->dma ? 256 : 64 * pl->wn;
+    // wm x wn waves of 128 x 64: the 256 x 256 tile (8 waves, one workgroup per CU); 128 x 256 for a weight gradient of 96..191
+    // rows (4 waves, two workgroups per CU: 184 -> 218 TFLOP/s on 64 -> 128 channels).  A 256 x 128 tile for 96..191 COLUMNS was
+    // built and measured slower than the register-staged tiles (109 vs 146 forward, 102 vs 188 TFLOP/s input-grad at 512 px):
+    // with half the columns the k-contiguous activation operand is fetched twice per FLOP in 32-byte pieces, HBM-bound.
+    if (a.prec == 2 && a16 == 3 && b16 == 3 && dg_get_option(DG_OPT_NO_DMA) == 0 && pl->kt == 16 && g.C % 8 == 0 && g.K % 8 == 0 &&
+        ((pl->mode == MODE_FWD && g.C % 16 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 16 == 0) || pl->mode == MODE_WGRAD)) {
+        if (a.Ng >= 192 && a.M >= 192) { pl->dma = 2; pl->wm = 2; pl->wn = 4; }
+        else if (pl->mode == MODE_WGRAD && a.M >= 96 && a.Ng >= 192) { pl->dma = 2; pl->wm = 1; pl->wn = 4; }
+    }
+    const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm), BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma ? 256 : 64 * pl->wn);
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
     const int base = a.tilesM * a.tilesN * zmul;
-    a.splits = choose_splits(base, a.nIt, pl->dma ? 256 : 0);
+    a.splits = choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
     // measured (PMC, MB per launch beyond L2, 64 px layers): forward 83 -> 76, weight-grad 222 -> 90, input-grad with
@@ -1253,7 +1258,7 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     if (pl.dma) {
-        const int ok = pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
+        const int ok = pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
         if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
         DG_CHECK_LAUNCH(who);
     } else {

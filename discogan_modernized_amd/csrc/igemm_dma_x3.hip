@@ -45,18 +45,25 @@ __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...
 
 // BT (FWD only): the weight planes are the TRANSPOSED copy wT[(r, s, c)][k] (dg_x3_transpose_planes): the B tile of a K-tile is
 // 16 reduction rows x 256 contiguous out channels (512-byte pieces) instead of 256 rows x 32 bytes 16 C elements apart.
-template <int MODE, bool BT>
-__global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
+// WM x WN waves of 128 x 64: 2 x 4 = the 256 x 256 tile (8 waves, 96 KB of LDS, one workgroup per CU); 1 x 4 = 128 x 256 for a
+// weight gradient of 96..191 rows (4 waves, 72 KB, TWO workgroups per CU).  2 x 2 = 256 x 128 also compiles; igemm.hip does
+// not plan it (measured slower than the register-staged tiles: see make_plan).
+template <int MODE, bool BT, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
     static_assert(!BT || MODE == MODE_FWD, "the transposed weight copy serves the forward form");
-    constexpr int WN = 4, FM = 4, FN = 2;               // 2 x 4 waves, 4 x 2 accumulator blocks of 32x32 per wave
-    constexpr int BM = 256, BN = 256, KT = 16;
+    constexpr int NW = WM * WN, FM = 4, FN = 2;         // 4 x 2 accumulator blocks of 32x32 per wave
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN, KT = 16;
+    static_assert((BM == 256 || BM == 128) && (BN == 256 || BN == 128), "tile");
     constexpr bool A_KM = MODE == MODE_WGRAD;           // operand image is reduction-major ([k][cols])
     constexpr bool B_KM = MODE != MODE_FWD || BT;
-    constexpr int PL = 256 * KT * 2;                    // one plane of one operand: 8 KB
-    constexpr int OPB = 3 * PL, STAGE = 2 * OPB;        // 48 KB per stage
+    constexpr int PLA = BM * KT * 2, PLB = BN * KT * 2; // one plane of an operand tile: 8 KB per 256 rows
+    constexpr int OPA = 3 * PLA, STAGE = OPA + 3 * PLB; // stage = [A p0][A p1][A p2][B p0][B p1][B p2]
+    constexpr int NPA = PLA / 1024 / NW, NPB = PLB / 1024 / NW;     // 1-KiB DMA pieces per wave, plane and tile
+    static_assert(NPA * NW * 1024 == PLA && NPB * NW * 1024 == PLB, "pieces must divide over the waves");
+    constexpr int NPC = 3 * (NPA + NPB);
     constexpr int LDS_BYTES = 2 * STAGE;
-    constexpr int EPI_BYTES = 8 * 32 * 68 * 4;
+    constexpr int EPI_BYTES = NW * 32 * 68 * 4;
     static_assert(EPI_BYTES <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
 
@@ -129,73 +136,93 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
 
     auto kmswz = [](int k) -> int { return (k & 3) << 2; };
     // ---- per-lane source descriptors of this wave's DMA pieces (the same for the three planes; fixed over the K loop) ----
-    // k-contiguous image: the wave's piece covers rows 32 w .. 32 w + 31; lane L lands in (row 32 w + L / 2, slot L % 2) and
-    // fetches granule slot ^ ((row >> 3) & 1).  Reduction-major image: the piece covers k rows 2 w, 2 w + 1; lane L lands in
-    // (k row 2 w + L / 32, slot L % 32) and fetches granule slot ^ kmswz(k row).
-    const int kc_row = wave * 32 + (lane >> 1);
-    const int kc_g = (lane & 1) ^ ((kc_row >> 3) & 1);
-    const int km_row = wave * 2 + (lane >> 5);
-    const int km_gc = (lane & 31) ^ kmswz(km_row);
-    int a_ob = 0, a_inv = 0;
-    if (!A_KM) {
-        const int m = m0 + kc_row;
-        if (MODE == MODE_FWD) {
-            a_inv = 0xFFFF;
-            if (m < p.M) {
-                const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
-                const int ay = oy * p.stride - p.pad, ax = ox * p.stride - p.pad;
-                a_ob = (((n * H + ay) * W + ax) * Cc + kc_g * 8) * 2;
-                int colok = 0, okmask = 0;
+    // k-contiguous image: piece pq covers rows 32 pq .. 32 pq + 31; lane L lands in (row 32 pq + L / 2, slot L % 2) and fetches
+    // granule slot ^ ((row >> 3) & 1).  Reduction-major image of NC columns: GR = NC / 8 granules per row, piece pq covers k rows
+    // RP pq .. RP pq + RP - 1 (RP = 64 / GR); lane L lands in (k row RP pq + L / GR, slot L % GR) and fetches granule
+    // slot ^ kmswz(k row).  This wave owns pieces wave * NP + i of every plane.
+    int a_ob[NPA], a_inv[NPA];
 #pragma unroll
-                for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(ax + sx) < (unsigned)W) ? (1 << sx) : 0;
+    for (int i = 0; i < NPA; ++i) {
+        const int pq = wave * NPA + i;
+        a_ob[i] = 0;
+        a_inv[i] = 0;
+        if (!A_KM) {
+            const int row = pq * 32 + (lane >> 1);
+            const int g = (lane & 1) ^ ((row >> 3) & 1);
+            const int m = m0 + row;
+            if (MODE == MODE_FWD) {
+                a_inv[i] = 0xFFFF;
+                if (m < p.M) {
+                    const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                    const int ay = oy * p.stride - p.pad, ax = ox * p.stride - p.pad;
+                    a_ob[i] = (((n * H + ay) * W + ax) * Cc + g * 8) * 2;
+                    int colok = 0, okmask = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(ay + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
-                a_inv = ~okmask & 0xFFFF;
-            }
-        } else {   // DGRAD_S2
-            a_inv = 0xF;
-            if (m < p.M) {
-                const int bx = m & (Wo - 1), ay = (m >> lgWo) & (Ho - 1);
-                a_ob = (m * K + kc_g * 8) * 2;
-                a_inv = 0;
+                    for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(ax + sx) < (unsigned)W) ? (1 << sx) : 0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int ty = t >> 1, tx = t & 1;
-                    const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
-                    const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
-                    const bool ok = (unsigned)(ay + dyo) < (unsigned)Ho && (unsigned)(bx + dxo) < (unsigned)Wo;
-                    a_inv |= ok ? 0 : (1 << t);
+                    for (int r = 0; r < 4; ++r) okmask |= ((unsigned)(ay + r) < (unsigned)H) ? (colok << (4 * r)) : 0;
+                    a_inv[i] = ~okmask & 0xFFFF;
+                }
+            } else {   // DGRAD_S2
+                a_inv[i] = 0xF;
+                if (m < p.M) {
+                    const int bx = m & (Wo - 1), ay = (m >> lgWo) & (Ho - 1);
+                    a_ob[i] = (m * K + g * 8) * 2;
+                    a_inv[i] = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int ty = t >> 1, tx = t & 1;
+                        const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+                        const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+                        const bool ok = (unsigned)(ay + dyo) < (unsigned)Ho && (unsigned)(bx + dxo) < (unsigned)Wo;
+                        a_inv[i] |= ok ? 0 : (1 << t);
+                    }
                 }
             }
+        } else {       // WGRAD: rows = reduction pixels, columns = out channels m0 .. m0 + BM - 1 of dy[pixel][K]
+            constexpr int GR = BM / 8, RP = 64 / GR;
+            const int krow = pq * RP + lane / GR;
+            const int gc = (lane % GR) ^ kmswz(krow);
+            const int col = m0 + gc * 8;
+            a_ob[i] = col < K ? (krow * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the plane: zeros
         }
-    } else {       // WGRAD: rows = reduction pixels, columns = out channels m0 .. m0 + 255 of dy[pixel][K]
-        const int col = m0 + km_gc * 8;
-        a_ob = col < K ? (km_row * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the plane: zeros
     }
-    int b_ob = 0;
-    // WGRAD: the columns of B are (tap, c) of im2col(x); everything about the column is fixed per lane
-    int wg_c = 0, wg_cst = 0, wg_ybad = -1, wg_xbad = -1, wg_colbad = 0;
+    int b_ob[NPB];
+    // WGRAD: the columns of B are (tap, c) of im2col(x); everything about the column is fixed per lane and piece
+    int wg_c[NPB], wg_cst[NPB], wg_ybad[NPB], wg_xbad[NPB], wg_colbad[NPB], wg_krow[NPB];
     const bool wg_s2 = p.stride == 2;
     const int wg_lpm = wg_s2 ? 2 : 4, wg_pxm = wg_s2 ? -1 : 0;
-    if (MODE == MODE_FWD && !BT) {
-        const int k = n0 + kc_row;
-        b_ob = k < K ? (k * 16 * Cc + kc_g * 8) * 2 : OOR;
-    } else if (MODE == MODE_FWD) {
-        const int col = n0 + km_gc * 8;
-        b_ob = col < K ? (km_row * K + col) * 2 : OOR;
-    } else {
-        const int col = n0 + km_gc * 8;
-        if (MODE == MODE_DGRAD_S2) {
-            b_ob = col < Cc ? (km_row * 16 * Cc + col) * 2 : OOR;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int pq = wave * NPB + i;
+        b_ob[i] = 0;
+        wg_c[i] = wg_cst[i] = wg_colbad[i] = wg_krow[i] = 0;
+        wg_ybad[i] = wg_xbad[i] = -1;
+        if (MODE == MODE_FWD && !BT) {
+            const int row = pq * 32 + (lane >> 1);
+            const int g = (lane & 1) ^ ((row >> 3) & 1);
+            const int k = n0 + row;
+            b_ob[i] = k < K ? (k * 16 * Cc + g * 8) * 2 : OOR;
         } else {
-            const bool colok = col < p.Ng;
-            const int tap = colok ? col / Cc : 0;
-            const int r = tap >> 2, s = tap & 3;
-            wg_c = col - tap * Cc;
-            wg_cst = wg_s2 ? (r - 1) * W + (s - 1) : r * 4 + s;
-            wg_ybad = !wg_s2 ? -1 : (r == 0 ? 0 : (r == 3 ? Ho - 1 : -1));
-            wg_xbad = !wg_s2 ? -1 : (s == 0 ? 0 : (s == 3 ? Wo - 1 : -1));
-            wg_colbad = colok ? 0 : -1;
+            constexpr int GR = BN / 8, RP = 64 / GR;
+            const int krow = pq * RP + lane / GR;
+            const int gc = (lane % GR) ^ kmswz(krow);
+            const int col = n0 + gc * 8;
+            if (MODE == MODE_FWD) {
+                b_ob[i] = col < K ? (krow * K + col) * 2 : OOR;
+            } else if (MODE == MODE_DGRAD_S2) {
+                b_ob[i] = col < Cc ? (krow * 16 * Cc + col) * 2 : OOR;
+            } else {
+                const bool colok = col < p.Ng;
+                const int tap = colok ? col / Cc : 0;
+                const int r = tap >> 2, sx = tap & 3;
+                wg_c[i] = col - tap * Cc;
+                wg_cst[i] = wg_s2 ? (r - 1) * W + (sx - 1) : r * 4 + sx;
+                wg_ybad[i] = !wg_s2 ? -1 : (r == 0 ? 0 : (r == 3 ? Ho - 1 : -1));
+                wg_xbad[i] = !wg_s2 ? -1 : (sx == 0 ? 0 : (sx == 3 ? Wo - 1 : -1));
+                wg_colbad[i] = colok ? 0 : -1;
+                wg_krow[i] = krow;
+            }
         }
     }
 
@@ -203,7 +230,8 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     // FWD / DGRAD_S2 walk the reduction in 64-channel chunks, the taps of a chunk (r, s in the order 0, 2, 1, 3 / the 2x2 taps
     // of the parity class) inside, and the chunk's FOUR 16-channel K-tiles innermost: a k-contiguous row gives a K-tile only
     // 32 bytes, so the four tiles that share a 128-byte line run back to back (the line is fetched once), while the taps of
-    // a chunk still re-use the same input pixels.  Channel counts that are not a multiple of 64 walk 16-channel chunks (the
+    // a chunk still re-use the same input pixels (same-box A/B against 16-channel chunks with the taps inside: forward
+    // 216 -> 233 TFLOP/s at 128 -> 256 channels, 88 -> 100 on the 256 x 128 tile).  Channel counts that are not a multiple of 64 walk 16-channel chunks (the
     // order of igemm.hip's K-tile 16).  WGRAD walks pixel tiles.
     constexpr int NTAP = MODE == MODE_FWD ? 16 : 4;
     const int SUB = (MODE == MODE_WGRAD) ? 1 : (((MODE == MODE_FWD ? Cc : K) & 63) == 0 ? 4 : 1);
@@ -240,46 +268,51 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
                      : "v"(voff), "s"(r), "s"(dst)
                      : "memory");
     };
-    // the per-lane source offset of this wave's A / B piece of tile `dt` (the same in every plane)
-    auto a_voff = [&]() -> int {
+    // the per-lane source offset of this wave's i-th A / B piece of tile `dt` (the same in every plane)
+    auto a_voff = [&](int i) -> int {
         if (MODE == MODE_FWD) {
             const int r = fwd_r(), sx = fwd_s();
             const int soff = ((r * W + sx) * Cc + coff()) * 2;                 // wave-uniform
-            return (a_ob + soff) | -((a_inv >> (r * 4 + sx)) & 1);
+            return (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1);
         } else if (MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
             const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
             const int soff = ((dyo * Wo + dxo) * K + coff()) * 2;
-            return (a_ob + soff) | -((a_inv >> tap) & 1);
+            return (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1);
         }
-        return a_ob + dt * (KT * 2) * K;
+        return a_ob[i] + dt * (KT * 2) * K;
     };
-    auto b_voff = [&]() -> int {
+    auto b_voff = [&](int i) -> int {
         if (MODE == MODE_FWD) {
             const int red = (fwd_r() * 4 + fwd_s()) * Cc + coff();        // first reduction element of the tile
-            return BT ? b_ob + red * K * 2 : b_ob + red * 2;
+            return BT ? b_ob[i] + red * K * 2 : b_ob[i] + red * 2;
         } else if (MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
             const int sx = pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
-            return b_ob + ((coff() * 16 + r * 4 + sx) * Cc) * 2;
+            return b_ob[i] + ((coff() * 16 + r * 4 + sx) * Cc) * 2;
         }
         // reduction row = output pixel mrow = (n, oy, ox) packed; see igemm.hip load_B (WGRAD)
-        const int mrow = dt * KT + km_row;
+        const int mrow = dt * KT + wg_krow[i];
         const int oxv = mrow & (Wo - 1), oyv = (mrow >> lgWo) & (Ho - 1);
-        const int bad = (oyv == wg_ybad) | (oxv == wg_xbad) | (mrow >= p.R);
-        const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst;
-        return ((pix * Cc + wg_c) * 2) | wg_colbad | -bad;
+        const int bad = (oyv == wg_ybad[i]) | (oxv == wg_xbad[i]) | (mrow >= p.R);
+        const int pix = (mrow << wg_lpm) - ((oxv << 1) & wg_pxm) + wg_cst[i];
+        return ((pix * Cc + wg_c[i]) * 2) | wg_colbad[i] | -bad;
     };
-    // piece k (0..2: A planes, 3..5: B planes) of tile `dt` into LDS stage `stage`
-    int va = 0, vb = 0;
+    // piece k of tile `dt` into LDS stage `stage`: k = 3 i + plane for the A pieces (i < NPA), then the B pieces the same way
+    int vcur = 0;
     auto issue = [&](int stage, int k) {
-        if (k == 0) va = a_voff();
-        if (k == 3) vb = b_voff();
-        const int lds_off = stage * STAGE + k * PL + wave * 1024;
-        if (k < 3) dma(rA[k], lds_off, va);
-        else dma(rB[k - 3], lds_off, vb);
+        const int pl = k % 3;
+        if (k < 3 * NPA) {
+            const int i = k / 3;
+            if (pl == 0) vcur = a_voff(i);
+            dma(rA[pl], stage * STAGE + pl * PLA + (wave * NPA + i) * 1024, vcur);
+        } else {
+            const int i = (k - 3 * NPA) / 3;
+            if (pl == 0) vcur = b_voff(i);
+            dma(rB[pl], stage * STAGE + OPA + pl * PLB + (wave * NPB + i) * 1024, vcur);
+        }
     };
 
     // ---- fragment reads: plane pl of 32-row block (k-contiguous) / 32-column block (reduction-major) -----------------
@@ -287,24 +320,24 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     auto frag_kc = [&](const char* img, int row) -> bf16x8 {
         return *(const bf16x8*)(img + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
     };
-    auto frag_km = [&](const char* img, int c0) -> bf16x8 {
+    auto frag_km = [&](const char* img, int rowb, int c0) -> bf16x8 {
         const int kr = 8 * lh + tr_q, col = c0 + tr_c;
-        const char* p0 = img + kr * 512 + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
+        const char* p0 = img + kr * rowb + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * 512));     // kr + 4: same swizzle
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * rowb));     // kr + 4: same swizzle
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     bf16x8 fa[3][FM];            // [plane][row block]
     bf16x8 fb[2][FN], fbh[2][FN];   // mid / lo planes [plane - 1][column block]; hi plane [tile parity][column block]
     auto fetchA = [&](int stage, int pl, int i) {
-        const char* img = smem + stage * STAGE + pl * PL;
+        const char* img = smem + stage * STAGE + pl * PLA;
         const int row = wm * (32 * FM) + i * 32;
-        fa[pl][i] = A_KM ? frag_km(img, row) : frag_kc(img, row + l31);
+        fa[pl][i] = A_KM ? frag_km(img, BM * 2, row) : frag_kc(img, row + l31);
     };
     auto fetchB = [&](int stage, int pl, int j) {
-        const char* img = smem + stage * STAGE + OPB + pl * PL;
+        const char* img = smem + stage * STAGE + OPA + pl * PLB;
         const int col = wn * (32 * FN) + j * 32;
-        const bf16x8 v = B_KM ? frag_km(img, col) : frag_kc(img, col + l31);
+        const bf16x8 v = B_KM ? frag_km(img, BN * 2, col) : frag_kc(img, col + l31);
         if (pl == 0) fbh[stage][j] = v;
         else fb[pl - 1][j] = v;
     };
@@ -320,12 +353,12 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     // ---- prologue: tiles 0 and 1 --------------------------------------------------------------------------------------
     if (it_begin < it_end) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) issue(0, k);
+        for (int k = 0; k < NPC; ++k) issue(0, k);
         advance();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) issue(1, k);
+        for (int k = 0; k < NPC; ++k) issue(1, k);
         advance();
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile 0 has landed (this wave's pieces)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");      // tile 0 has landed (this wave's pieces)
     }
     __builtin_amdgcn_s_barrier();
     if (stp) stp[2] = clock64();
@@ -343,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     // (other register set) right behind the barrier.
     constexpr int QB = DG_X3_QB;
     static_assert(QB >= 1 && QB <= 12, "the tile barrier precedes the first read of tile t+1");
+    static_assert(QB + 2 * NPC <= 48, "the DMA of tile t+2 is issued inside tile t");
     auto body = [&](auto ST_) {
         constexpr int ST = decltype(ST_)::value;
         dg_x3_static_for(std::make_integer_sequence<int, 48>{}, [&](auto Q_) {
@@ -368,8 +402,8 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
             if constexpr (PB[pr] == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fbh[ST][j], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr] > 0 ? PB[pr] - 1 : 0][j], acc[i][j], 0, 0, 0);
             // DMA of tile t+2 into the stage tile t has left: one piece behind every second MFMA after the barrier
-            if constexpr (q >= QB && q < QB + 12 && (q - QB) % 2 == 0) issue(ST, (q - QB) / 2);
-            if constexpr (q == QB + 11) advance();
+            if constexpr (q >= QB && q < QB + 2 * NPC && (q - QB) % 2 == 0) issue(ST, (q - QB) / 2);
+            if constexpr (q == QB + 2 * NPC - 1) advance();
         });
         __builtin_amdgcn_sched_barrier(0);
         fetchA(ST ^ 1, 0, 3);
@@ -431,18 +465,28 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_x3_kernel(const IgemmArgs p)
     }
 }
 
-// host: launch the plane kernel for a plan made by igemm.hip (mode, args); returns 0 when there is no instantiation
-int dg_igemm_dma_x3_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st) {
-    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+// host: launch the plane kernel for a plan made by igemm.hip (mode, args, wm x wn waves); returns 0 when there is no instantiation
+template <int WM, int WN>
+static int x3_launch_tile(int mode, const IgemmArgs& a, int grid, hipStream_t st) {
+    const dim3 blk(64 * WM * WN);
     switch (mode) {
         case MODE_FWD:
-            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true>), dim3(grid), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false>), dim3(grid), dim3(512), 0, st, a);
+            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true, WM, WN>), dim3(grid), blk, 0, st, a);
+            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false, WM, WN>), dim3(grid), blk, 0, st, a);
             return 1;
-        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false>), dim3(grid), dim3(512), 0, st, a); return 1;
-        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false>), dim3(grid), dim3(512), 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false, WM, WN>), dim3(grid), blk, 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, WM, WN>), dim3(grid), blk, 0, st, a); return 1;
         default: return 0;
     }
+}
+int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st) {
+    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    if (wm == 2 && wn == 4) return x3_launch_tile<2, 4>(mode, a, grid, st);
+    if (wm == 1 && wn == 4 && mode == MODE_WGRAD) {
+        hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4>), dim3(grid), dim3(256), 0, st, a);
+        return 1;
+    }
+    return 0;
 }
 
 // ---- transposed weight planes for the forward form -------------------------------------------------------------------------

@@ -226,6 +226,8 @@ def test_conv_f32x3_is_fp32_accurate(N, C, K, H):
 X3_SHAPES = DMA_SHAPES + [
     (5, 224, 288, 16),     # C = 14 chunks of 16, K = 18 chunks: neither is a multiple of 64 (the bf16 LDS-DMA kernel refuses these)
     (32, 192, 512, 8),     # 512 rows, 192 input-grad columns (a 3/4 used tile)
+    (4, 64, 128, 32),      # weight gradient of 128 rows: the 128 x 256 tile (4 waves); forward / input-grad stay on the register-staged tiles
+    (2, 96, 160, 32),      # 160 weight-grad rows (two ragged 128-row tiles), 1536 columns
 ]
 
 
@@ -247,21 +249,25 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
     _lib.set_option("splitk", splitk)
     try:
         yreg, dxreg, dwreg = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
-        assert all(L.dg_conv_x3_planes_ok(op, N, H, H, C, K, 2, 1) == 1 for op in (0, 2))       # input-grad: where C >= 192
+        M = N * (H // 2) ** 2
+        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == int(K >= 192 and M >= 192)
+        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == int(C >= 192 and M >= 192)
+        assert L.dg_conv_x3_planes_ok(2, N, H, H, C, K, 2, 1) == 1
         ops.X3 = True
         y, dx, dw = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
         dw2 = ops.conv_wgrad(dyg, xg, 2, 1, out=dw.clone(), accumulate=True)
         torch.cuda.synchronize()
-        assert len(ops._PLANE_TAB) == 2 and hasattr(wg, "_dg_x3")       # x and dy were split once each, the weight once
+        assert len(ops._PLANE_TAB) == 2                                  # x and dy were split once each
         # the forward form on the TRANSPOSED weight planes (what a weight of a flat Adam group gets): the same MFMAs in the
         # same order, only the weight tile's path into LDS differs -> bit-identical
-        buf = wg._dg_x3[0]
-        wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
-        yt = ops.conv_fwd(xg, wg, 2, 1)
-        assert ops.weight_planes(wg, transposed=True)[2] == 1
-        t_ref = buf.view(3, K, 16 * C).transpose(1, 2).reshape(3, -1)
-        assert torch.equal(wg._dg_x3[2], t_ref), "dg_x3_transpose_planes"
-        assert torch.equal(yt, y), "forward on transposed weight planes"
+        if L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1):
+            buf = wg._dg_x3[0]
+            wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
+            yt = ops.conv_fwd(xg, wg, 2, 1)
+            assert ops.weight_planes(wg, transposed=True)[2] == 1
+            t_ref = buf.view(3, K, 16 * C).transpose(1, 2).reshape(3, -1)
+            assert torch.equal(wg._dg_x3[2], t_ref), "dg_x3_transpose_planes"
+            assert torch.equal(yt, y), "forward on transposed weight planes"
         # the triple reproduces the fp32 tensor exactly
         t3 = ops._PLANE_TAB[xg.data_ptr()][1].float().sum(0)
         assert torch.equal(t3, xg.permute(0, 2, 3, 1).reshape(-1))
