@@ -299,8 +299,9 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
         res["roofline"] = dict(
             bound="mfma",
             kernel=("igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv family)" if bf else
-                    "igemm_kernel<*,PREC=2> (fp32 operands as three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product block; "
-                    "peak = dense bf16 peak / 6; the exact-fp32 MFMA peak is 157.3)" if x3 else
+                    "igemm_dma_x3_kernel<*> + igemm_kernel<*,PREC=2> (fp32 operands as three bf16 planes -- written once per tensor and staged by "
+                    "LDS-DMA where the GEMM is at least 192 wide, split in the conv kernel elsewhere --, six v_mfma_f32_32x32x16_bf16 per "
+                    "product block; peak = dense bf16 peak / 6; the exact-fp32 MFMA peak is 157.3)" if x3 else
                     "igemm_kernel<*> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv family)"),
             achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
             launches_per_cycle=nlaunch, algorithmic_gflop_per_cycle=round(flops / 1e9, 2),
@@ -421,8 +422,10 @@ def main():
                                   "size, so data parallelism below 256 px defaults to graph replay + exchange behind it.")
         extra["note_side"] = ("side measurements, NOT the headline value; bf16 = conv operands rounded to bf16 on the bf16 MFMA path, fp32 "
                               "accumulate/BatchNorm/weights/Adam (configs[4] arithmetic); f32x3 = fp32-ACCURATE conv products on the bf16 "
-                              "MFMA path: each fp32 operand split into three bf16 planes (24 significand bits), six MFMAs per block, fp32 "
-                              "accumulate -- measured closer to fp64 than the exact-fp32 MFMA chain (tests/test_ops_gpu.py::test_conv_f32x3_is_fp32_accurate); "
+                              "MFMA path: each fp32 operand split into three bf16 planes (24 significand bits; by the tensor's producer / once per tensor, "
+                              "csrc/igemm_dma_x3.hip), six MFMAs per block, fp32 "
+                              "accumulate -- measured closer to fp64 than the exact-fp32 MFMA chain (tests/test_ops_gpu.py::test_conv_f32x3_is_fp32_accurate, "
+                              "::test_conv_f32x3_plane_kernel), the training step passes the exact path's fp32 bounds (test_teacher_forced_iterations_f32x3); "
                               "*_bf16_mfma_bf16_activations = BASELINE configs[4]'s arithmetic in full: bf16 MFMA (LDS-DMA conv kernel, bf16-MFMA edge "
                               "kernels), feature maps and their gradients STORED in bf16, fp32 BatchNorm statistics / parameters / parameter gradients / "
                               "losses / master weights / Adam (tests: test_bf16_path_vs_reference_golden_512_n2, test_bf16_activation_storage_training_step)")

@@ -252,12 +252,13 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
 }
 
 typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
-// TI / TO: element types of y and z.  Z16 (fp32 z only): also write a bf16 (RNE) shadow of z for the bf16 matrix path
-template <typename TI, typename TO, bool Z16>
+// TI / TO: element types of y and z.  Z16 (fp32 z only) = 1: also write a bf16 (RNE) shadow of z for the bf16 matrix path;
+// = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart)
+template <typename TI, typename TO, int Z16>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ y, TO* __restrict__ z, long totalv,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope, __bf16* __restrict__ z16) {
+                                                         int act, float slope, __bf16* __restrict__ z16, long pstride) {
     constexpr int V = BnV<TI>::V;
     static_assert(BnV<TI>::V == BnV<TO>::V, "same storage type on both sides");
     const int cvn = C / V;
@@ -272,7 +273,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
         bn_st(z + idx * V, o);
-        if constexpr (Z16) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (Z16 == 1) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (Z16 == 3) {
+            dg_bf16x4_t h, md, l;
+            dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
+            *(dg_bf16x4_t*)(z16 + idx * 4) = h;
+            *(dg_bf16x4_t*)(z16 + pstride + idx * 4) = md;
+            *(dg_bf16x4_t*)(z16 + 2 * pstride + idx * 4) = l;
+        }
     }
 }
 
@@ -533,13 +541,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const __bf16* __res
     }
 }
 
-// T: element type of dz / y / dy.  D16 (fp32 only): also write a bf16 shadow of dy
-template <typename T, bool D16>
+// T: element type of dz / y / dy.  D16 (fp32 only) = 1: also write a bf16 shadow of dy; = 3: its three bf16 planes
+template <typename T, int D16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
                                                            T* __restrict__ dy, long totalv, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ coef,
-                                                           int act, float slope, __bf16* __restrict__ dy16) {
+                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride) {
     constexpr int V = BnV<T>::V;
     const int cvn = C / V;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
@@ -560,7 +568,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             o[j] = (float)((double)g[j] * (double)istd[j] * (gg - coef[c + j] - xhat * coef[C + c + j]));
         }
         bn_st(dy + idx * V, o);
-        if constexpr (D16) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (D16 == 1) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (D16 == 3) {
+            dg_bf16x4_t h, md, l;
+            dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
+            *(dg_bf16x4_t*)(dy16 + idx * 4) = h;
+            *(dg_bf16x4_t*)(dy16 + pstride + idx * 4) = md;
+            *(dg_bf16x4_t*)(dy16 + 2 * pstride + idx * 4) = l;
+        }
     }
 }
 
@@ -673,7 +688,7 @@ extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C,
 
 template <typename T>
 static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const float* saved, const float* gamma,
-                           const float* beta, int act, float slope, dg_stream_t stream) {
+                           const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
@@ -687,15 +702,21 @@ static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const floa
         return DG_OK;
     }
     if constexpr (V == 4) {
+        if (z16 && pstride > 0) {
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
+                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride);
+            DG_CHECK_LAUNCH("bn_act_fwd");
+            return DG_OK;
+        }
         if (z16) {
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, true>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16);
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
+                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
     }
-    hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, false>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                       saved, gamma, beta, act, slope, (__bf16*)nullptr);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
+                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
@@ -708,6 +729,13 @@ extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M,
     DG_CHECK_ARG(z_bf16, "dg_bn_act_fwd_bf16: null shadow pointer");
     return bn_act_fwd_impl<float>(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
 }
+// the same pass, also writing the three bf16 planes of z (plane_elems elements apart, >= M * C, % 8 == 0) for the f32x3 matrix path
+extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int M, int C, const float* saved,
+                                const float* gamma, const float* beta, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(z_planes, "dg_bn_act_fwd_x3: null plane pointer");
+    DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_fwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
+    return bn_act_fwd_impl<float>(y, z, z_planes, M, C, saved, gamma, beta, act, slope, stream, (long)plane_elems);
+}
 extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C, const float* saved, const float* gamma,
                                const float* beta, int act, float slope, dg_stream_t stream) {
     if (io_bf16) return bn_act_fwd_impl<__bf16>((const __bf16*)y, (__bf16*)z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
@@ -717,7 +745,7 @@ extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C
 template <typename T>
 static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, int C, const float* saved,
                            const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
-                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
@@ -736,9 +764,15 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long totalv = (long)M * C / V;
     if constexpr (V == 4) {
+        if (dy16 && pstride > 0) {
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride);
+            DG_CHECK_LAUNCH("bn_bwd_apply");
+            return DG_OK;
+        }
         if (dy16) {
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
@@ -748,8 +782,8 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
         DG_CHECK_LAUNCH("bn_bwd_apply16");
         return DG_OK;
     }
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                       beta, (const double*)coef, act, slope, (__bf16*)nullptr);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
+                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
 }
@@ -763,6 +797,14 @@ extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, vo
                                   int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_bf16, "dg_bn_act_bwd_bf16: null shadow pointer");
     return bn_act_bwd_impl<float>(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+}
+extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int M, int C,
+                                const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
+                                float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(dy_planes, "dg_bn_act_bwd_x3: null plane pointer");
+    DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_bwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
+    return bn_act_bwd_impl<float>(dz, y, dy, dy_planes, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream,
+                                  (long)plane_elems);
 }
 extern "C" int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_bf16, int M, int C, const float* saved,
                                const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,

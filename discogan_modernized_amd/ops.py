@@ -624,6 +624,13 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
                                                    act, slope, _stream()), "dg_bn_act_fwd_t")
         return z
     z = empty_nhwc(n, c, h, w, y.device)
+    if X3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
+        z3 = torch.empty((3, z.numel()), device=y.device, dtype=torch.bfloat16)
+        with _hbm("bn_apply", 14.0 * n * h * w * c):
+            _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), _ptr(z), _ptr(z3), z3.stride(0), n * h * w, c, _ptr(saved), _ptr(gamma),
+                                                    _ptr(beta), act, slope, _stream()), "dg_bn_act_fwd_x3")
+        planes_put(z, z3)
+        return z
     if SHADOW and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
         with _hbm("bn_apply", 10.0 * n * h * w * c):
@@ -661,6 +668,13 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
                                          slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_t")
         return dy, dgamma, dbeta
     dy = empty_nhwc(n, c, h, w, y.device)
+    if X3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
+        dy3 = torch.empty((3, dy.numel()), device=y.device, dtype=torch.bfloat16)
+        with _hbm("bn_backward", 26.0 * m * c):
+            _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy3), dy3.stride(0), m, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+                                          act, slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_x3")
+        planes_put(dy, dy3)
+        return dy, dgamma, dbeta
     if SHADOW and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)
         with _hbm("bn_backward", 22.0 * m * c):

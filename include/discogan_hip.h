@@ -307,6 +307,11 @@ int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n,
                          void* p_planes, size_t plane_elems, dg_stream_t s);
 int dg_x3_transpose_planes(const void* src_planes, void* dst_planes, size_t plane_elems, const int64_t* w_off, const int* w_K,
                            const int* w_J, int n, dg_stream_t s);
+int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int M, int C, const float* saved,
+                     const float* gamma, const float* beta, int act, float slope, dg_stream_t stream);
+int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int M, int C,
+                     const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
+                     float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
 int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, int w_transposed, float* y,
                    int N, int H, int W, int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);

@@ -369,6 +369,23 @@ def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, 
     return table
 
 
+@pytest.mark.parametrize("fixture,N,tol", [("ref_s512_n2.json", 2, 1e-2), ("ref_s512_n2_gstep.json", 2, 1e-2),
+                                           ("ref_s512_n32_dstep.json", 32, 2e-3), ("ref_s512_n32_gstep.json", 32, 5e-3)])
+def test_f32x3_plane_path_vs_reference_golden_512(fixture, N, tol):
+    """mfma_dtype="f32x3" with plane operands (csrc/igemm_dma_x3.hip where the GEMM is at least 192 wide, the register-staged
+    split elsewhere) against outputs of the TRUE reference at 512 px, batch 2 and BASELINE configs[3]'s batch 32: a D-step and
+    a G-step from the seeded init, held to EXACTLY the bounds of the exact-fp32 MFMA path in the three tests above (losses
+    1e-4, D outputs 1e-3, image sums 1e-4, first Adam step, BatchNorm buffers, the same gradient tolerances)."""
+    fix = _load(fixture)
+    assert fix["meta"]["source"].startswith("reference")
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234, mfma_dtype="f32x3")
+    assert tr.x3_planes
+    _, worst, worst_norm = run_and_compare(fix, 512, N, grad_tol=tol, init_fix=_load("ref_s512_n2.json"), tr=tr)
+    print(f"f32x3 512px N={N} {fixture}: worst sampled grad dev {worst:.2e}, worst norm dev {worst_norm:.2e}")
+    tr.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("S,N", [(16, 4), (64, 4), (128, 2)])
 def test_teacher_forced_iterations_vs_oracle(S, N):
     """Losses, D outputs, per-tensor gradients, BN buffers and the Adam update op-wise on the oracle's gradients,

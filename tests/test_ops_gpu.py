@@ -509,6 +509,32 @@ def test_conv_fused_bn_statistics(N, C, K, H):
     close(a, b, rtol=2e-6, atol=1e-7, what="dgrad fused stats")
 
 
+@pytest.mark.parametrize("N,C,H,act", [(4, 64, 16, "leaky"), (3, 256, 8, "relu"), (2, 72, 4, "none")])
+def test_batchnorm_writes_plane_triples(N, C, H, act):
+    """f32x3 path: the BatchNorm apply kernels also write the three bf16 planes of what they produce (dg_bn_act_fwd_x3 /
+    dg_bn_act_bwd_x3).  The fp32 results are those of the plain kernels bit for bit, the planes are those of dg_f32_to_bf16x3
+    on the fp32 result, and hi + mid + lo reproduces it exactly."""
+    code = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act]
+    yg, dzg = nhwc(rnd(N, C, H, H, seed=1, scale=2.0) + 0.3), nhwc(rnd(N, C, H, H, seed=4))
+    gg, bg = (rnd(C, seed=2) + 1.5).to(DEV), rnd(C, seed=3).to(DEV)
+    saved = ops.bn_train_stats(yg, None, None, None, 1e-5, 0.1)
+    z0 = ops.bn_act_fwd(yg, saved, gg, bg, code, 0.2)
+    dy0, dg0, db0 = ops.bn_act_bwd(dzg, yg, saved, gg, bg, code, 0.2)
+    ops.X3 = True
+    try:
+        z = ops.bn_act_fwd(yg, saved, gg, bg, code, 0.2)
+        dy, dg, db = ops.bn_act_bwd(dzg, yg, saved, gg, bg, code, 0.2)
+        z3, dy3 = ops._PLANE_TAB[z.data_ptr()][1], ops._PLANE_TAB[dy.data_ptr()][1]
+        ref = lambda t: ops.f32_to_bf16x3(t, torch.empty((3, t.numel()), device=DEV, dtype=torch.bfloat16))
+        assert torch.equal(z, z0) and torch.equal(dy, dy0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+        assert torch.equal(z3, ref(z)) and torch.equal(dy3, ref(dy))
+        mem = lambda t: t.permute(0, 2, 3, 1).reshape(-1)
+        assert torch.equal(z3.float().sum(0), mem(z)) and torch.equal(dy3.float().sum(0), mem(dy))
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+
+
 def test_bn_needs_two_values():
     y = nhwc(rnd(1, 100, 1, 1))
     with pytest.raises(_lib.DiscoganHipError, match="more than 1 value"):
