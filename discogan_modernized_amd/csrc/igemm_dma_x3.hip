@@ -48,7 +48,10 @@ __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...
 // WM x WN waves of 128 x 64: 2 x 4 = the 256 x 256 tile (8 waves, 96 KB of LDS, one workgroup per CU); 1 x 4 = 128 x 256 for a
 // weight gradient of 96..191 rows (4 waves, 72 KB, TWO workgroups per CU).  2 x 2 = 256 x 128 also compiles; igemm.hip does
 // not plan it (measured slower than the register-staged tiles: see make_plan).
-template <int MODE, bool BT, int WM, int WN>
+// NS: LDS stages (2 or 3).  With 3 the DMA of a tile has TWO tile periods to land (the 256 x 256 tile: 144 KB of LDS, 246-254
+// VGPRs); same-box A/B at 512 px / batch 32: 223-225 / 220-221 / 250 TFLOP/s forward / input-grad / weight-grad with either
+// -- the loop waits for the (power-limited) matrix cores, not for the DMA -- so two stages are what is instantiated.
+template <int MODE, bool BT, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
     static_assert(!BT || MODE == MODE_FWD, "the transposed weight copy serves the forward form");
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     constexpr int NPA = PLA / 1024 / NW, NPB = PLB / 1024 / NW;     // 1-KiB DMA pieces per wave, plane and tile
     static_assert(NPA * NW * 1024 == PLA && NPB * NW * 1024 == PLB, "pieces must divide over the waves");
     constexpr int NPC = 3 * (NPA + NPB);
-    constexpr int LDS_BYTES = 2 * STAGE;
+    constexpr int LDS_BYTES = NS * STAGE;
+    static_assert((NS == 2 || NS == 3) && LDS_BYTES <= 160 * 1024, "LDS");
     constexpr int EPI_BYTES = NW * 32 * 68 * 4;
     static_assert(EPI_BYTES <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
@@ -334,11 +338,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         const int row = wm * (32 * FM) + i * 32;
         fa[pl][i] = A_KM ? frag_km(img, BM * 2, row) : frag_kc(img, row + l31);
     };
-    auto fetchB = [&](int stage, int pl, int j) {
+    auto fetchB = [&](int stage, int pl, int j, int hset) {       // hset: which B hi set (the parity of the tile) when pl == 0
         const char* img = smem + stage * STAGE + OPA + pl * PLB;
         const int col = wn * (32 * FN) + j * 32;
         const bf16x8 v = B_KM ? frag_km(img, BN * 2, col) : frag_kc(img, col + l31);
-        if (pl == 0) fbh[stage][j] = v;
+        if (pl == 0) fbh[hset][j] = v;
         else fb[pl - 1][j] = v;
     };
 
@@ -350,69 +354,74 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- prologue: tiles 0 and 1 --------------------------------------------------------------------------------------
+    // ---- prologue: tiles 0 .. NS-1 --------------------------------------------------------------------------------------
     if (it_begin < it_end) {
+        dg_x3_static_for(std::make_integer_sequence<int, NS>{}, [&](auto S_) {
+            constexpr int sg = decltype(S_)::value;
 #pragma unroll
-        for (int k = 0; k < NPC; ++k) issue(0, k);
-        advance();
-#pragma unroll
-        for (int k = 0; k < NPC; ++k) issue(1, k);
-        advance();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");      // tile 0 has landed (this wave's pieces)
+            for (int k = 0; k < NPC; ++k) issue(sg, k);
+            advance();
+        });
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC * (NS - 1)) : "memory");      // tile 0 has landed (this wave's pieces)
     }
     __builtin_amdgcn_s_barrier();
     if (stp) stp[2] = clock64();
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fetchB(0, pl, j);
+        for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
 #pragma unroll
         for (int i = 0; i < FM; ++i) fetchA(0, pl, i);
     }
 
     // ---- one K-tile: 48 MFMAs per wave, row of blocks i = q / 12, plane pair (q % 12) / 2, column block q % 2 -------------
-    // ST = LDS stage of the current tile t.  Fragment replacement (tile t+1, stage ST ^ 1), always one MFMA behind the last
-    // reader: A row i-1 in front of MFMA 12 i + 1; B lo in front of MFMA 41, B mid in front of 47, A row 3 at the end; B hi
-    // (other register set) right behind the barrier.
+    // ST = LDS stage of the current tile t, PAR = t & 1 (which B hi register set holds tile t).  Fragment replacement (tile
+    // t+1, stage NX = (ST + 1) % NS), always one MFMA behind the last reader: A row i-1 in front of MFMA 12 i + 1; B lo in
+    // front of MFMA 41, B mid in front of 47, A row 3 at the end; B hi (other register set) right behind the barrier.
     constexpr int QB = DG_X3_QB;
     static_assert(QB >= 1 && QB <= 12, "the tile barrier precedes the first read of tile t+1");
-    static_assert(QB + 2 * NPC <= 48, "the DMA of tile t+2 is issued inside tile t");
-    auto body = [&](auto ST_) {
-        constexpr int ST = decltype(ST_)::value;
+    static_assert(QB + 2 * NPC <= 48, "the DMA of tile t+NS is issued inside tile t");
+    auto body = [&](auto ST_, auto PAR_) {
+        constexpr int ST = decltype(ST_)::value, PAR = decltype(PAR_)::value, NX = (ST + 1) % NS;
         dg_x3_static_for(std::make_integer_sequence<int, 48>{}, [&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
             constexpr int i = q / 12, pr = (q % 12) / 2, j = q % 2;
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (q == QB) {
-                // this wave's DMA pieces of tile t+1 have landed and its fragment reads of tile t are complete; behind the
-                // barrier that holds for every wave: tile t+1 may be read, tile t's stage may be overwritten
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // this wave's DMA pieces of tile t+1 have landed (tiles t+2 .. t+NS-1 may still be in flight) and its
+                // fragment reads of tile t are complete; behind the barrier that holds for every wave: tile t+1 may be read,
+                // tile t's stage may be overwritten
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC * (NS - 2)) : "memory");
                 __builtin_amdgcn_s_barrier();
-                fetchB(ST ^ 1, 0, 0);
-                fetchB(ST ^ 1, 0, 1);
+                fetchB(NX, 0, 0, PAR ^ 1);
+                fetchB(NX, 0, 1, PAR ^ 1);
             }
             if constexpr (q % 12 == 1 && i > 0 && q > QB) {
-                fetchA(ST ^ 1, 0, i - 1);
-                fetchA(ST ^ 1, 1, i - 1);
-                fetchA(ST ^ 1, 2, i - 1);
+                fetchA(NX, 0, i - 1);
+                fetchA(NX, 1, i - 1);
+                fetchA(NX, 2, i - 1);
             }
-            if constexpr (q == 41) { fetchB(ST ^ 1, 2, 0); fetchB(ST ^ 1, 2, 1); }
-            if constexpr (q == 47) { fetchB(ST ^ 1, 1, 0); fetchB(ST ^ 1, 1, 1); }
-            if constexpr (PB[pr] == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fbh[ST][j], acc[i][j], 0, 0, 0);
+            if constexpr (q == 41) { fetchB(NX, 2, 0, 0); fetchB(NX, 2, 1, 0); }
+            if constexpr (q == 47) { fetchB(NX, 1, 0, 0); fetchB(NX, 1, 1, 0); }
+            if constexpr (PB[pr] == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fbh[PAR][j], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr] > 0 ? PB[pr] - 1 : 0][j], acc[i][j], 0, 0, 0);
-            // DMA of tile t+2 into the stage tile t has left: one piece behind every second MFMA after the barrier
+            // DMA of tile t+NS into the stage tile t has left: one piece behind every second MFMA after the barrier
             if constexpr (q >= QB && q < QB + 2 * NPC && (q - QB) % 2 == 0) issue(ST, (q - QB) / 2);
             if constexpr (q == QB + 2 * NPC - 1) advance();
         });
         __builtin_amdgcn_sched_barrier(0);
-        fetchA(ST ^ 1, 0, 3);
-        fetchA(ST ^ 1, 1, 3);
-        fetchA(ST ^ 1, 2, 3);
+        fetchA(NX, 0, 3);
+        fetchA(NX, 1, 3);
+        fetchA(NX, 2, 3);
     };
-    for (int it = it_begin; it < it_end; it += 2) {
-        body(std::integral_constant<int, 0>{});
-        if (it + 1 < it_end) body(std::integral_constant<int, 1>{});
+    // the bodies cycle through (stage, parity): 2 stages -> 2 bodies, 3 stages -> 6
+    constexpr int NB = NS == 2 ? 2 : 6;
+    for (int it = it_begin; it < it_end; it += NB) {
+        dg_x3_static_for(std::make_integer_sequence<int, NB>{}, [&](auto B_) {
+            constexpr int bi = decltype(B_)::value;
+            if (it + bi < it_end) body(std::integral_constant<int, bi % NS>{}, std::integral_constant<int, bi & 1>{});
+        });
     }
     // the clamped re-loads of the last tile and the fragment prefetch behind the last barrier still touch LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -466,24 +475,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
 }
 
 // host: launch the plane kernel for a plan made by igemm.hip (mode, args, wm x wn waves); returns 0 when there is no instantiation
-template <int WM, int WN>
+template <int WM, int WN, int NS>
 static int x3_launch_tile(int mode, const IgemmArgs& a, int grid, hipStream_t st) {
     const dim3 blk(64 * WM * WN);
     switch (mode) {
         case MODE_FWD:
-            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true, WM, WN>), dim3(grid), blk, 0, st, a);
-            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false, WM, WN>), dim3(grid), blk, 0, st, a);
+            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true, WM, WN, NS>), dim3(grid), blk, 0, st, a);
+            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false, WM, WN, NS>), dim3(grid), blk, 0, st, a);
             return 1;
-        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false, WM, WN>), dim3(grid), blk, 0, st, a); return 1;
-        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, WM, WN>), dim3(grid), blk, 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false, WM, WN, NS>), dim3(grid), blk, 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, WM, WN, NS>), dim3(grid), blk, 0, st, a); return 1;
         default: return 0;
     }
 }
 int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    if (wm == 2 && wn == 4) return x3_launch_tile<2, 4>(mode, a, grid, st);
+    if (wm == 2 && wn == 4) return x3_launch_tile<2, 4, 2>(mode, a, grid, st);
     if (wm == 1 && wn == 4 && mode == MODE_WGRAD) {
-        hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4, 2>), dim3(grid), dim3(256), 0, st, a);
         return 1;
     }
     return 0;
