@@ -60,6 +60,8 @@ def parse(argv=None):
                          "configs[4] arithmetic; f32x3: fp32-accurate products from three bf16 planes per operand")
     ap.add_argument("--act_dtype", default="f32", choices=["f32", "bf16"],
                     help="with --mfma_dtype bf16: feature maps and their gradients STORED in bf16 (fp32 BatchNorm statistics / arithmetic)")
+    ap.add_argument("--no_x3_planes", action="store_true", help="with --mfma_dtype f32x3: split the operands inside every conv kernel "
+                    "(register-staged tiles) instead of reading plane triples written once per tensor (A/B)")
     ap.add_argument("--async_wgrad", action="store_true", help="experiment: weight-gradient kernels on a third HIP stream")
     ap.add_argument("--mfma_turns", action="store_true", help="experiment: the two chains take turns on the matrix cores")
     ap.add_argument("--skew_steps", type=int, default=0, help="experiment: hold the B-side chain back by this many layer groups of the A-side chain")
@@ -250,7 +252,7 @@ def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=No
               use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
               mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov,
               act_dtype=act_dtype or (a.act_dtype if (mfma_dtype or a.mfma_dtype) == "bf16" else "f32"), skew_steps=a.skew_steps,
-              async_wgrad=a.async_wgrad, mfma_turns=a.mfma_turns)
+              async_wgrad=a.async_wgrad, mfma_turns=a.mfma_turns, x3_planes=False if a.no_x3_planes else None)
     want = comm or a.comm
     if pg is None or want == "c10d":
         return DiscoGANTrainer(default_args(), comm=want, **kw)

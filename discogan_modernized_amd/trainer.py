@@ -54,7 +54,7 @@ class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
                  cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
-                 bucket_mb=128.0, act_dtype="f32", x3_planes=True):
+                 bucket_mb=128.0, act_dtype="f32", x3_planes=None):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -129,7 +129,11 @@ class DiscoGANTrainer:
             self.optim_dis.enable_bf16_shadow()
         # f32x3 path: the conv kernels read the three bf16 PLANES of their operands, written once per tensor (Adam: weights;
         # ops.planes_of: activations and gradients) instead of splitting every fp32 value in every conv (ops.X3,
-        # csrc/igemm_dma_x3.hip); x3_planes=False keeps the register-staged split everywhere
+        # csrc/igemm_dma_x3.hip); x3_planes=False keeps the register-staged split everywhere.  None = by size: the planes cost
+        # 6 B/element of extra BatchNorm output and a weight transpose per Adam step, which the faster conv kernels repay at
+        # 512 px / batch 32 (257 -> 275 images/s) and do not at 64 px / batch 256 (25.0 k -> 23.0 k, same-box A/B) -> on from 256 px
+        if x3_planes is None:
+            x3_planes = image_size >= 256
         self.x3_planes = mfma_dtype == "f32x3" and bool(x3_planes)
         if self.x3_planes:
             self.optim_gen.enable_x3_planes()

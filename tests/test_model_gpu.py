@@ -393,12 +393,33 @@ def test_teacher_forced_iterations_vs_oracle(S, N):
     _teacher_forced(S, N, 4)
 
 
-@pytest.mark.parametrize("S,N", [(64, 4), (128, 2)])
-def test_teacher_forced_iterations_f32x3(S, N):
+@pytest.mark.parametrize("S,N,planes", [(64, 4, False), (128, 2, False), (128, 2, True)])
+def test_teacher_forced_iterations_f32x3(S, N, planes):
     """mfma_dtype="f32x3" (fp32 operands as three bf16 planes on the bf16 matrix path) is held to EXACTLY the fp32
     bounds of test_teacher_forced_iterations_vs_oracle: losses 2e-4, D outputs 2e-3, every gradient tensor within
-    max(1e-4, 4 x the reference's own fp32 error) of the fp64 oracle on the same activation pattern, BN buffers, Adam."""
-    _teacher_forced(S, N, 4, mfma_dtype="f32x3")
+    max(1e-4, 4 x the reference's own fp32 error) of the fp64 oracle on the same activation pattern, BN buffers, Adam.
+    planes: the split inside every conv kernel (the default below 256 px) / plane triples written once per tensor."""
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=S, seed=1234, mfma_dtype="f32x3", x3_planes=planes)
+    assert tr.x3_planes == planes
+    _teacher_forced(S, N, 4, tr=tr, mfma_dtype="f32x3")
+
+
+def test_f32x3_plane_step_is_graph_neutral_and_deterministic():
+    """The plane path under hipGraph replay (Adam writes the weight planes and their transposed copy inside the captured step;
+    activation planes live in the graph's private pool): 9 iterations eager, eager again and replayed end bitwise identical."""
+    A, B = synthetic_batch(4, 64, 7, DEV)
+    runs = []
+    for graph in (False, False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="f32x3", x3_planes=True, use_graph=graph)
+        vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(9)]
+        tr.finish()
+        torch.cuda.synchronize()
+        runs.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone(), tr.optim_gen.flat_p3.clone(), tr.optim_gen.flat_p3t.clone()))
+        tr.close()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and all(torch.equal(a, b) for a, b in zip(r[1:], runs[0][1:])), "plane path: not deterministic / graph-neutral"
+    # the weight planes track the weights: hi + mid + lo == the fp32 parameters after the last step
+    assert torch.equal(runs[0][3].float().sum(0), runs[0][1])
 
 
 def test_masked_fp64_gradient_parity_512():
