@@ -627,9 +627,11 @@ class _GradBuckets:
                 g = opt.param_groups[0]
                 from . import ops
                 p16 = getattr(opt, "flat_p16", None)
+                p3 = getattr(opt, "flat_p3", None)          # f32x3 plane path: the slice's plane triples with the update
                 ops.adam_step_flat(opt.flat_p[sl], opt.flat_g[sl], opt.exp_avg[sl], opt.exp_avg_sq[sl], opt.state,
                                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                   float(scale), p16=None if p16 is None else p16[sl])
+                                   float(scale), p16=None if p16 is None else p16[sl],
+                                   p3=None if p3 is None else (p3.data_ptr() + 2 * b["begin"], opt.numel))
         if early:
             self.launched += 1
 
@@ -640,6 +642,11 @@ class _GradBuckets:
         for b in self.buckets:
             if not b["done"]:
                 self._launch(b, main, early=False, active=active)
+        opt = tr.optim_gen
+        if getattr(opt, "flat_p3t", None) is not None:      # every bucket's planes are written: the transposed weight copy follows
+            from . import ops
+            with torch.cuda.stream(tr.comm_stream):
+                ops.x3_transpose_planes(opt.flat_p3, opt.flat_p3t, opt._x3t_table)
         main.wait_stream(tr.comm_stream)
 
 

@@ -306,6 +306,31 @@ def test_bucketed_gstep_exchange_is_bitwise_neutral(arch):
         assert torch.equal(a, b)
 
 
+def test_bucketed_exchange_keeps_the_f32x3_weight_planes_current():
+    """mfma_dtype="f32x3" with plane operands under overlap_comm: every bucket's Adam slice also writes its slice of the weight
+    planes, and the transposed copy is rewritten once all buckets are in -- weights, planes and transposed planes equal the
+    plain path's bit for bit, and the planes ARE the weights (hi + mid + lo)."""
+    A, B = synthetic_batch(4, 64, 0, DEV)
+    res = []
+    for overlap in (False, True):
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, overlap_comm=overlap, comm="capi", bucket_mb=0.5,
+                             mfma_dtype="f32x3", x3_planes=True)
+        try:
+            vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(6)]
+            tr.finish()
+            torch.cuda.synchronize()
+            if overlap:
+                assert len(tr._buckets.buckets) >= 4 and tr._buckets.launched > 0
+            res.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_gen.flat_p3.clone(), tr.optim_gen.flat_p3t.clone(),
+                        tr.optim_dis.flat_p3.clone(), tr.optim_dis.flat_p3t.clone()))
+        finally:
+            tr.close()
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][2].float().sum(0), res[1][1])
+
+
 def test_lazy_d_steps_change_only_generator_bn_buffers():
     """need_losses=False (--skip_log_only_passes): weights, optimiser state and D buffers are bitwise the full run's;
     the generators' BatchNorm running statistics are NOT (one forward per D-step instead of two) -- documented."""
