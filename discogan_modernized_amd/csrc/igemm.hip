@@ -1078,10 +1078,14 @@ struct Plan {
     int stat_rows;   // partial rows the fused BatchNorm statistics would produce (0: not supported)
     int dma;         // 1: igemm_dma.hip (both operands bf16 in HBM, LDS-DMA staging, 256 x 256 tile, 512 threads)
                      // 2: igemm_dma_x3.hip (both operands as three bf16 planes in HBM; same tile, K-tile 16)
+                     // 3: igemm_dma_x3_dgw.hip (plane operands, input-grad with few output channels: `ncls` parity classes per
+                     //    workgroup, gradient window in LDS)
+    int ncls;
 };
 
 int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);      // igemm_dma.hip
 int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
+int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st);                              // igemm_dma_x3_dgw.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
     const int cch = (Ng + 127) / 128;
@@ -1190,11 +1194,20 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         ((pl->mode == MODE_FWD && g.C % 16 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 16 == 0) || pl->mode == MODE_WGRAD)) {
         if (a.Ng >= 192 && a.M >= 192) { pl->dma = 2; pl->wm = 2; pl->wn = 4; }
         else if (pl->mode == MODE_WGRAD && a.M >= 96 && a.Ng >= 192) { pl->dma = 2; pl->wm = 1; pl->wn = 4; }
+        // input-grad with <= 128 output channels: all parity classes of a 256-pixel tile in one workgroup, the gradient window in
+        // LDS (igemm_dma_x3_dgw.hip); whole image rows per tile, a 32-pixel block inside one row
+        else if (pl->mode == MODE_DGRAD_S2 && g.C <= 128 && g.Wo >= 32 && g.Wo <= 128 && g.Ho * g.Wo >= 256 &&
+                 dg_get_option(DG_OPT_DMA_MFMA) != 1) {
+            pl->dma = 3;
+            pl->ncls = g.C <= 64 ? 4 : 2;
+            a.nIt = g.K / 16;                       // the split unit is a 16-channel chunk (4 tap steps)
+        }
     }
-    const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm), BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma ? 256 : 64 * pl->wn);
+    const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm);
+    const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma == 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
-    const int base = a.tilesM * a.tilesN * zmul;
+    const int base = a.tilesM * a.tilesN * (pl->dma == 3 ? 4 / pl->ncls : zmul);
     a.splits = choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
@@ -1258,7 +1271,8 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     if (pl.dma) {
-        const int ok = pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
+        const int ok = pl.dma == 3 ? dg_igemm_x3_dgw_launch(pl.ncls, a, st)
+                     : pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
         if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
         DG_CHECK_LAUNCH(who);
     } else {
@@ -1482,7 +1496,7 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no plane form", who);
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
-    if (pl.dma != 2) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
+    if (pl.dma != 2 && pl.dma != 3) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
     DG_CHECK_ARG(a_plane >= (long)pl.a.abytes && b_plane >= (long)pl.a.bbytes && a_plane % 16 == 0 && b_plane % 16 == 0,
                  "%s: plane distances %ld / %ld (operands are %u / %u bytes per plane)", who, a_plane, b_plane, pl.a.abytes, pl.a.bbytes);
     pl.a.A = (const float*)a3; pl.a.B = (const float*)b3; pl.a.C = out; pl.a.accumulate = accumulate;
@@ -1511,7 +1525,7 @@ extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, i
     if (dg_get_option(DG_OPT_BF16) != 2) return 0;
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
-    return pl.dma == 2 ? 1 : 0;
+    return (pl.dma == 2 || pl.dma == 3) ? 1 : 0;
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

@@ -1,0 +1,335 @@
+// Input-gradient of Conv2d(k4,s2,p1) / forward of ConvTranspose2d(k4,s2,p1) for layers with FEW output channels (C <= 128), f32x3
+// plane operands: ALL parity classes of a pixel tile in one workgroup, the gradient tile fetched ONCE per 16-channel chunk into
+// an LDS WINDOW and re-used by every tap ("dgw" = input-grad with window).
+//
+// Replaces (reference file:line) nn.Conv2d(k4,s2,p1) input-grad (model.py:11-31,83-103 via autograd) and
+// nn.ConvTranspose2d(k4,s2,p1) forward (model.py:118-140) where igemm_dma_x3.hip's DGRAD_S2 form does not apply.
+//
+// Why: out pixel (2a+ph, 2b+pw) sums dy[a+dyo][b+dxo] . w[k][r][s][c] over the 2x2 taps of its parity class (ph, pw); the
+// four classes together use the NINE shifts (dyo, dxo) in {-1,0,1}^2 of the same gradient pixels, sixteen (shift, class) pairs.
+// The per-class kernels fetch a shifted 256-pixel tile for every one of them: each gradient element crosses the fabric sixteen
+// times, and with C <= 128 output columns there is too little MFMA work per fetched byte (the register-staged f32x3 tiles run
+// these layers at 150-190 TFLOP/s, a 256 x 128 plane tile was HBM-bound at 100).  Here
+//   * a workgroup owns 256 consecutive gradient pixels (R = 256 / Wo rows of one image) and NCLS parity classes: 4 classes x 64
+//     columns (C <= 64) or 2 classes x 128 (C <= 128; ph comes from blockIdx) -- the 256 x 256 accumulator layout of
+//     igemm_dma_x3.hip, a wave column (pair) per class;
+//   * per 16-channel chunk the (R + 2) x (Wo + 2) pixel window around the tile goes to LDS once per plane (<= 17 KB; halo pixels
+//     outside the image are out-of-range DMA offsets = zeros); a tap's A fragment is a ds_read_b128 at row
+//     `window row of the pixel + dyo (Wo + 2) + dxo` -- the swizzle `slot = half ^ ((row >> 3) & 1)` is conflict-free for any row
+//     offset; A traffic per MFMA drops 7.7x (C <= 64) / 3.9x;
+//   * the K loop walks (chunk, tap t = 0..3): step (c, t) multiplies, for every class, the class's t-th tap; its weight tile is
+//     [16 k][NCLS x CW columns] with the (r, s) of (class, t) baked into the per-lane DMA offsets;
+//   * LDS: 2 window stages (one per chunk parity) + 2 weight stages (one per step parity) <= 150 KB; the window of chunk c+1
+//     is fetched one plane per step during steps 0..2 of chunk c; barrier / fragment-replacement scheme of igemm_dma_x3.hip.
+// Same six MFMAs per product block; the reduction order per output element is (chunk, tap) like the per-class kernels.
+#include "igemm_args.h"
+#include <type_traits>
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf4_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <int... Q, typename F>
+__device__ __forceinline__ void dgw_static_for(std::integer_sequence<int, Q...>, F&& f) {
+    (f(std::integral_constant<int, Q>{}), ...);
+}
+
+// NCLS: parity classes per workgroup (4: 64 columns each, 2: 128 columns each, ph = blockIdx parity)
+template <int NCLS>
+__global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p) {
+    constexpr int WN = 4, FM = 4, FN = 2, KT = 16;      // 2 x 4 waves of 128 x 64
+    constexpr int CW = 256 / NCLS;                      // columns per class
+    constexpr int WPMAX = 17;                           // window pieces (32 rows each) per plane: (R + 2)(Wo + 2) <= 544 rows
+    constexpr int WPB = WPMAX * 1024;                   // bytes per window plane
+    constexpr int AST = 3 * WPB;                        // window stage
+    constexpr int PLB = 256 * KT * 2, BST = 3 * PLB;    // weight tile plane / stage
+    constexpr int B_OFF = 0, A_OFF = 2 * BST;           // weight stages first: their fragment reads then fit ds_read's 16-bit offsets
+    constexpr int LDS_BYTES = 2 * AST + 2 * BST;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(8 * 32 * 68 * 4 <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long* const stp = (p.stamps != nullptr && tid == 0) ? p.stamps + (long)blockIdx.x * 8 : nullptr;
+    if (stp) {
+        stp[0] = wall_clock64();
+        stp[1] = clock64();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stp[6] = ((long long)xcc << 32) | hwid;
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- blockIdx -> (pixel tile, ph for NCLS == 2, split) ----------------------------------------------------------
+    constexpr int ZM = 4 / NCLS;
+    int bid = blockIdx.x;
+    const int tm = bid % p.tilesM;
+    bid /= p.tilesM;
+    const int zph = bid % ZM;
+    const int split = bid / ZM;
+    const int m0 = tm * 256;
+    const int cb = split * p.itPerSplit;                       // chunk range of this split
+    const int ce = min(p.nIt, cb + p.itPerSplit);
+
+    const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
+    const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
+    // tile = R rows x Wo pixels of image n, rows a0 .. a0 + R - 1; window = rows a0 - 1 .. a0 + R, columns -1 .. Wo
+    const int WW = Wo + 2;
+    const int n_img = m0 >> lgHW, a0 = (m0 >> lgWo) & (Ho - 1);
+    const int WR = (256 / Wo + 2) * WW;                       // window rows
+    const int wpieces = (WR + 31) >> 5;
+
+    constexpr int OOR = (int)0x80000000;
+    __amdgpu_buffer_rsrc_t rA[3], rB[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        rA[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + pl * p.a_plane), 0, (p.dbg_zero & 1) ? 0 : (int)p.abytes, 0x00020000);
+        rB[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + pl * p.b_plane), 0, (p.dbg_zero & 2) ? 0 : (int)p.bbytes, 0x00020000);
+    }
+    auto kmswz = [](int k) -> int { return (k & 3) << 2; };
+
+    // ---- window DMA descriptors: this wave's pieces w, w + 8, w + 16 of every plane (the third only where it exists) ----
+    // piece pc covers window rows 32 pc .. 32 pc + 31; lane L lands in (row 32 pc + L / 2, slot L % 2), fetches granule
+    // slot ^ ((row >> 3) & 1) of gradient pixel (a0 - 1 + row / WW, row % WW - 1); outside the image or the window: zeros
+    int w_ob[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pc = wave + 8 * j;
+        const int row = pc * 32 + (lane >> 1);
+        const int g = (lane & 1) ^ ((row >> 3) & 1);
+        const int wr = row / WW, wc = row - wr * WW;
+        const int a = a0 - 1 + wr, b = wc - 1;
+        const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
+        w_ob[j] = ok ? ((((n_img * Ho + a) * Wo + b) * K) + g * 8) * 2 : OOR;
+    }
+    // ---- weight DMA descriptors: tile [16 k][256 columns], column = class-local-index * CW + c; one piece per plane ----
+    // piece = k rows 2 w, 2 w + 1; lane L lands in (k row 2 w + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
+    // the tap (r, s) of (class, t) is part of the per-lane offset: one offset per t
+    int b_base, b_ph, b_pw;
+    {
+        const int krow = wave * 2 + (lane >> 5);
+        const int gc = (lane & 31) ^ kmswz(krow);
+        const int col = gc * 8;
+        const int bcls = col / CW, cc = col - bcls * CW;
+        b_ph = NCLS == 4 ? (bcls >> 1) : zph;
+        b_pw = NCLS == 4 ? (bcls & 1) : bcls;
+        b_base = cc < Cc ? (krow * 16 * Cc + cc) * 2 : OOR;
+    }
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int lds_off, int voff) {
+        unsigned keep;
+        const unsigned dst = lds_base + (unsigned)lds_off;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(r), "s"(dst)
+                     : "memory");
+    };
+    // plane pl of the window of chunk `c` into window stage `ast`
+    auto issue_window = [&](int ast, int pl, int c) {
+        const int coff = c * KT * 2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (wave + 8 * j < wpieces)                                   // wave-uniform
+                dma(rA[pl], A_OFF + ast * AST + pl * WPB + (wave + 8 * j) * 1024, w_ob[j] + coff);
+        }
+    };
+    // weight tile of step (chunk c, tap t) into weight stage `bst` (three planes)
+    auto issue_weights = [&](int bst, int c, int t) {
+        const int ty = t >> 1, tx = t & 1;                                  // wave-uniform
+        const int r = b_ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);    // per lane (the lane's class)
+        const int sx = b_pw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
+        const int voff = b_base + ((r * 4 + sx) * Cc + c * (KT * 16) * Cc) * 2;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dma(rB[pl], B_OFF + bst * BST + pl * PLB + wave * 1024, voff);
+    };
+
+    // ---- fragment reads ----------------------------------------------------------------------------------------------
+    // class of this wave's columns and, per tap t, the window-row shift dyo * WW + dxo of that class
+    const int cls = NCLS == 4 ? wn : (wn >> 1);
+    const int ph = NCLS == 4 ? (cls >> 1) : zph, pw = NCLS == 4 ? (cls & 1) : cls;
+    int shift[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ty = t >> 1, tx = t & 1;
+        const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+        const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+        shift[t] = dyo * WW + dxo;
+    }
+    // window row of lane 0's pixel in the wave's 32-pixel block i (wave-uniform; a block never straddles an image row: Wo >= 32)
+    int srow[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int ml = wm * (32 * FM) + i * 32;
+        srow[i] = ((ml >> lgWo) + 1) * WW + (ml & (Wo - 1)) + 1;
+    }
+    const int tr_q = (lane >> 2) & 3, tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    auto frag_kc = [&](const char* img, int row) -> bf16x8 {
+        return *(const bf16x8*)(img + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
+    };
+    auto frag_km = [&](const char* img, int c0) -> bf16x8 {
+        const int kr = 8 * lh + tr_q, col = c0 + tr_c;
+        const char* p0 = img + kr * 512 + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * 512));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 fa[3][FM];
+    bf16x8 fb[2][FN], fbh[2][FN];
+    // (the window row is recomputed at every fetch: hoisted out of the K loop, the 16 (block, tap) addresses x 2 stages cost more
+    // registers than the kernel has -- the opaque asm keeps the compiler from doing that)
+    auto fetchA = [&](int ast, int pl, int i, int t) {
+        int lv = l31;
+        asm volatile("" : "+v"(lv));
+        fa[pl][i] = frag_kc(smem + A_OFF + ast * AST + pl * WPB, lv + (srow[i] + shift[t]));
+    };
+    auto fetchB = [&](int bst, int pl, int j, int hset) {
+        const bf16x8 v = frag_km(smem + B_OFF + bst * BST + pl * PLB, wn * (32 * FN) + j * 32);
+        if (pl == 0) fbh[hset][j] = v;
+        else fb[pl - 1][j] = v;
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- DMA-side state: the step (wc, wt) whose weight tile is issued next; clamped to the last step -------------------
+    int wc = cb, wt = 0;
+    auto advance = [&]() {
+        const int last = (wc == ce - 1 && wt == 3) ? 1 : 0;
+        wt += 1 - last;
+        const int wrap = wt == 4 ? 1 : 0;
+        wt = wrap ? 0 : wt;
+        wc += wrap;
+    };
+
+    // ---- prologue: window of the first chunk, weight tiles of steps 0 and 1 ----------------------------------------------
+    if (cb < ce) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) issue_window(0, pl, cb);
+        issue_weights(0, wc, wt);
+        advance();
+        issue_weights(1, wc, wt);
+        advance();
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // all but the second weight tile
+    }
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[2] = clock64();
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fetchA(0, pl, i, 0);
+    }
+
+    // ---- one step (chunk c in window stage AS, tap T; weight stage T & 1): 48 MFMAs per wave, schedule of igemm_dma_x3.hip ----
+    // next step: tap T + 1 of the same window, or tap 0 of the next chunk's window (stage AS ^ 1, complete since the
+    // barrier of this step: its planes were issued in steps 0, 1, 2)
+    auto body = [&](auto AS_, auto T_, int c) {
+        constexpr int AS = decltype(AS_)::value, T = decltype(T_)::value;
+        constexpr int BS = T & 1, NT = (T + 1) & 3, NAS = T == 3 ? AS ^ 1 : AS, NBS = BS ^ 1;
+        constexpr int QB = 8;
+        dgw_static_for(std::make_integer_sequence<int, 48>{}, [&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            constexpr int i = q / 12, pr = (q % 12) / 2, j = q % 2;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q == QB) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fetchB(NBS, 0, 0, BS ^ 1);
+                fetchB(NBS, 0, 1, BS ^ 1);
+            }
+            if constexpr (q % 12 == 1 && i > 0 && q > QB) {
+                fetchA(NAS, 0, i - 1, NT);
+                fetchA(NAS, 1, i - 1, NT);
+                fetchA(NAS, 2, i - 1, NT);
+            }
+            if constexpr (q == 41) { fetchB(NBS, 2, 0, 0); fetchB(NBS, 2, 1, 0); }
+            if constexpr (q == 47) { fetchB(NBS, 1, 0, 0); fetchB(NBS, 1, 1, 0); }
+            if constexpr (PB[pr] == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fbh[BS][j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr] > 0 ? PB[pr] - 1 : 0][j], acc[i][j], 0, 0, 0);
+            // behind the barrier: the weight tile of step + 2 into the stage this step is leaving, and (steps 0..2) plane T of
+            // the next chunk's window into the other window stage
+            if constexpr (q == QB + 1) {
+                issue_weights(BS, wc, wt);
+                advance();
+            }
+            if constexpr (q == QB + 9 && T < 3) issue_window(AS ^ 1, T, min(c + 1, ce - 1));
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fetchA(NAS, 0, 3, NT);
+        fetchA(NAS, 1, 3, NT);
+        fetchA(NAS, 2, 3, NT);
+    };
+    for (int c = cb; c < ce; c += 2) {
+        dgw_static_for(std::make_integer_sequence<int, 8>{}, [&](auto B_) {
+            constexpr int bi = decltype(B_)::value;
+            if (c + bi / 4 < ce) body(std::integral_constant<int, bi / 4>{}, std::integral_constant<int, bi % 4>{}, c + bi / 4);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (stp) stp[3] = clock64();
+
+    // ---- epilogue: the wave's 128 pixels x 64 columns of class (ph, pw); rows -> out pixel (2a + ph, 2b + pw) -----------------
+    const bool to_part = p.part != nullptr;
+    float* const eps = (float*)smem + wave * (32 * 68);
+    const int erow = lane >> 4, ec4 = (lane & 15) * 4;
+    const int ccol = (NCLS == 4 ? 0 : (wn & 1) * 64) + ec4;            // column inside the class
+    const int parity = ph * 2 + pw;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            eps[lr * 68 + l31] = acc[i][0][r];
+            eps[lr * 68 + 32 + l31] = acc[i][1][r];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + erow;
+            f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
+            const int m = m0 + wm * (32 * FM) + i * 32 + row;
+            if (m >= p.M || ccol >= Cc) continue;
+            float* dst;
+            long eoff;
+            if (to_part) {
+                dst = p.part;
+                eoff = (((long)split * 4 + parity) * p.M + m) * Cc + ccol;
+            } else {
+                const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                dst = p.C;
+                eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ccol;
+            }
+            if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
+            *(f32x4*)(dst + eoff) = v;
+        }
+    }
+    if (stp) {
+        stp[4] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[5] = wall_clock64();
+        stp[7] = clock64();
+    }
+}
+
+// host: launch for a plan made by igemm.hip (ncls = 4 / 2); grid = pixel tiles x (4 / ncls) x splits
+int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st) {
+    const int grid = a.tilesM * (4 / ncls) * a.splits;
+    if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4>), dim3(grid), dim3(512), 0, st, a);
+    else if (ncls == 2) hipLaunchKernelGGL((igemm_x3_dgw_kernel<2>), dim3(grid), dim3(512), 0, st, a);
+    else return 0;
+    return 1;
+}

@@ -295,6 +295,48 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
             assert torch.equal(dx, dxreg), "plane kernel vs register-staged split: input gradient"
 
 
+# (N, C, K, H): input-grad shapes of the window kernel (igemm_dma_x3_dgw.hip): C <= 128 output channels, gradient maps 32..128 wide
+X3_DGW_SHAPES = [
+    (2, 64, 128, 64),      # 4 classes x 64 columns, Wo = 32: 8 image rows per tile, 8 tiles
+    (1, 64, 128, 256),     # Wo = 128: two image rows per tile, 520-row window (17 pieces)
+    (3, 40, 64, 128),      # ragged: 40 of 64 columns per class; Wo = 64, 4 chunks
+    (1, 128, 256, 128),    # 2 classes x 128 columns, ph from the block index; 16 chunks
+    (2, 96, 96, 64),       # 2 classes, 96 of 128 columns; K = 96 = 6 chunks
+    (1, 8, 32, 64),        # 8 columns per class, two chunks
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", X3_DGW_SHAPES)
+@pytest.mark.parametrize("splitk", [0, 1, 2])
+def test_conv_f32x3_input_grad_window_kernel(N, C, K, H, splitk):
+    """Input-grad with few output channels on plane operands: all parity classes of a pixel tile in one workgroup, the gradient
+    window in LDS (csrc/igemm_dma_x3_dgw.hip).  Same products and the same (chunk, tap) reduction order per output element as
+    the per-class kernels: bit-identical to the register-staged f32x3 form on an unsplit GEMM, fp32 tolerance against fp64,
+    borders (zero halo) and ragged channel counts included."""
+    w, dy = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    dx64 = TF.conv_transpose2d(dy.double(), w.double(), stride=2, padding=1)
+    wg, dyg = krsc(w), nhwc(dy)
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    _lib.set_option("splitk", splitk)
+    try:
+        dxreg = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == 1
+        ops.X3 = True
+        dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        torch.cuda.synchronize()
+        assert len(ops._PLANE_TAB) == 1
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("splitk", 0)
+        _lib.set_option("bf16", 0)
+    close(dx, dx64.float(), rtol=2e-4, what="window input-grad")
+    close(dx, dxreg, rtol=2e-4, what="window vs register-staged input-grad")
+    if splitk == 1:
+        assert torch.equal(dx, dxreg), "window kernel vs register-staged split"
+
+
 def test_x3_transpose_planes_group():
     """dg_x3_transpose_planes over a flat plane buffer holding several weights: [K][J] images -> [J][K] at the same offsets
     (16-byte path for K % 8 == 0 and J % 8 == 0, element path otherwise, ragged 64 x 64 tiles); the rest of dst is untouched."""
