@@ -295,7 +295,8 @@ int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, 
  * bf16 MFMAs per product block and the same reduction order as the fp32-pointer entry points under option "bf16" = 2
  * (bit-identical on an unsplit GEMM), without the per-element split in the conv kernel: csrc/igemm_dma_x3.hip, operand
  * planes global -> LDS by `buffer_load ... lds`, 256x256 tile.  dg_conv_x3_planes_ok: 1 = the shape has the plane kernel
- * (GEMM of at least 192 rows and columns, C % 16 == 0 forward / K % 16 == 0 input-grad), 0 = use dg_conv_fwd / _dgrad /
+ * (GEMM of at least 192 rows and columns, C % 16 == 0 forward / K % 16 == 0 input-grad; weight gradients from 96 rows; stride-2
+ * input-grads with C <= 128 and a 32..128 pixel wide gradient map: csrc/igemm_dma_x3_dgw.hip), 0 = use dg_conv_fwd / _dgrad /
  * _wgrad.  Outputs are fp32; the caller keeps the fp32 tensors for BatchNorm and the element-wise kernels.
  * dg_conv_fwd_x3 with w_transposed != 0 reads the weight planes as wT[(r, s, c)][k] (k contiguous): a K-tile of the weight
  * operand is then 16 rows of 512 contiguous bytes instead of 256 pieces of 32 bytes (forward K loop 49-81 % -> ~90 % of the
