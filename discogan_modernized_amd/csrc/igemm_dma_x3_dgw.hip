@@ -20,8 +20,7 @@
 //   * the K loop walks (chunk, tap t = 0..3): step (c, t) multiplies, for every class, the class's t-th tap; its weight tile is
 //     [16 k][NCLS x CW columns] with the (r, s) of (class, t) baked into the per-lane DMA offsets;
 //   * LDS: 2 window stages (one per chunk parity) + 2 weight stages (one per step parity) <= 150 KB; the window of chunk c+1
-//     is fetched during steps 0 and 1 of chunk c (two steps to land; the per-step wait only covers the next weight tile);
-//     barrier / fragment-replacement scheme of igemm_dma_x3.hip.
+//     is fetched one plane per step during steps 0..2 of chunk c; barrier / fragment-replacement scheme of igemm_dma_x3.hip.
 // Same six MFMAs per product block; the reduction order per output element is (chunk, tap) like the per-class kernels.
 #include "igemm_args.h"
 #include <type_traits>
@@ -247,11 +246,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (q == QB) {
-                // the weight tile of the next step has landed (issued one step ago, BEFORE that step's window pieces: the
-                // in-order counter lets the younger window pieces -- 4 from step 0, 2 from step 1; wave 0 has up to 6 / 3 --
-                // stay in flight); the whole window only before the chunk's last step
-                constexpr int VM = T == 1 ? 4 : (T == 2 ? 2 : 0);
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 fetchB(NBS, 0, 0, BS ^ 1);
                 fetchB(NBS, 0, 1, BS ^ 1);
@@ -271,10 +266,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
                 issue_weights(BS, wc, wt);
                 advance();
             }
-            // the next chunk's window: planes 0 and 1 in step 0, plane 2 in step 1 -- every piece has two steps to land
-            if constexpr (q == QB + 9 && T == 0) issue_window(AS ^ 1, 0, min(c + 1, ce - 1));
-            if constexpr (q == QB + 15 && T == 0) issue_window(AS ^ 1, 1, min(c + 1, ce - 1));
-            if constexpr (q == QB + 9 && T == 1) issue_window(AS ^ 1, 2, min(c + 1, ce - 1));
+            if constexpr (q == QB + 9 && T < 3) issue_window(AS ^ 1, T, min(c + 1, ce - 1));
         });
         __builtin_amdgcn_sched_barrier(0);
         fetchA(NAS, 0, 3, NT);
