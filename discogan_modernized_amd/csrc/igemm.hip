@@ -1080,12 +1080,14 @@ struct Plan {
                      // 2: igemm_dma_x3.hip (both operands as three bf16 planes in HBM; same tile, K-tile 16)
                      // 3: igemm_dma_x3_dgw.hip (plane operands, input-grad with few output channels: `ncls` parity classes per
                      //    workgroup, gradient window in LDS)
+                     // 4: igemm_dma_dgw.hip (bf16 operands, the same input-grad scheme with a 32-deep K-step)
     int ncls;
 };
 
 int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);      // igemm_dma.hip
 int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
 int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st);                              // igemm_dma_x3_dgw.hip
+int dg_igemm_bf16_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st);                            // igemm_dma_dgw.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
     const int cch = (Ng + 127) / 128;
@@ -1186,6 +1188,13 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         ((pl->mode == MODE_FWD && g.C % 64 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 64 == 0) || pl->mode == MODE_WGRAD))
         pl->dma = 1;
     // plane kernel (igemm_dma_x3.hip): the same tile and grid rules with 16-deep K-tiles
+    // bf16 operands, input-grad with <= 128 output channels: the window kernel (igemm_dma_dgw.hip; see the plane form below)
+    if (a.prec == 1 && a16 == 1 && b16 == 1 && dg_get_option(DG_OPT_NO_DMA) == 0 && pl->mode == MODE_DGRAD_S2 && g.C <= 128 &&
+        g.C % 8 == 0 && g.K % 32 == 0 && g.Wo >= 32 && g.Wo <= 128 && g.Ho * g.Wo >= 256 && dg_get_option(DG_OPT_DMA_MFMA) != 1) {
+        pl->dma = 4;
+        pl->ncls = g.C <= 64 ? 4 : 2;
+        a.nIt = g.K / 32;                           // the split unit is a 32-channel chunk (4 tap steps)
+    }
     // wm x wn waves of 128 x 64: the 256 x 256 tile (8 waves, one workgroup per CU); 128 x 256 for a weight gradient of 96..191
     // rows (4 waves, two workgroups per CU: 184 -> 218 TFLOP/s on 64 -> 128 channels).  A 256 x 128 tile for 96..191 COLUMNS was
     // built and measured slower than the register-staged tiles (109 vs 146 forward, 102 vs 188 TFLOP/s input-grad at 512 px):
@@ -1204,10 +1213,10 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         }
     }
     const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm);
-    const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma == 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
+    const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma >= 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
-    const int base = a.tilesM * a.tilesN * (pl->dma == 3 ? 4 / pl->ncls : zmul);
+    const int base = a.tilesM * a.tilesN * (pl->dma >= 3 ? 4 / pl->ncls : zmul);
     a.splits = choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
@@ -1271,7 +1280,8 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     if (pl.dma) {
-        const int ok = pl.dma == 3 ? dg_igemm_x3_dgw_launch(pl.ncls, a, st)
+        const int ok = pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
+                     : pl.dma == 3 ? dg_igemm_x3_dgw_launch(pl.ncls, a, st)
                      : pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
         if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
         DG_CHECK_LAUNCH(who);

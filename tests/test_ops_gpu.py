@@ -171,6 +171,57 @@ def test_conv_bf16_lds_dma_kernel(N, C, K, H, splitk, mfma):
         _lib.set_option("bf16", 0)
 
 
+# (N, C, K, H): input-grad shapes of the bf16 window kernel (igemm_dma_dgw.hip): C <= 128, K % 64 == 0 (the bf16 tiles' rule), gradient maps 32..128 wide
+BF16_DGW_SHAPES = [
+    (2, 64, 128, 64),      # 4 classes x 64 columns, Wo = 32: 8 image rows per tile; 4 chunks
+    (1, 64, 128, 256),     # Wo = 128: two image rows per tile, 520-row window (33 pieces)
+    (3, 40, 64, 128),      # ragged: 40 of 64 columns per class; Wo = 64, 2 chunks
+    (1, 128, 256, 128),    # 2 classes x 128 columns, ph from the block index; 8 chunks
+    (2, 96, 192, 64),      # 2 classes, 96 of 128 columns; 6 chunks
+    (1, 8, 64, 64),        # 8 columns per class, two chunks
+    (3, 64, 320, 64),      # 10 chunks; three images, 12 tiles
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", BF16_DGW_SHAPES)
+@pytest.mark.parametrize("splitk,out16", [(0, False), (1, False), (2, False), (0, True)])
+def test_conv_bf16_input_grad_window_kernel(N, C, K, H, splitk, out16):
+    """bf16 matrix path, input-grad with few output channels: all parity classes of a pixel tile in one workgroup, the gradient
+    window in LDS (csrc/igemm_dma_dgw.hip).  bf16 x bf16 products are exact in fp32: the result must equal the fp64 convolution
+    of the ROUNDED operands at fp32 tolerance and agree with the register-staged bf16 tiles; bf16 output = RNE of that."""
+    r = lambda t_: t_.bfloat16().float()
+    w, dy = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    dxr = TF.conv_transpose2d(r(dy).double(), r(w).double(), stride=2, padding=1).float()
+    L = _lib.load()
+    _lib.set_option("bf16", 1)
+    _lib.set_option("splitk", splitk)
+    ops.SHADOW = True
+    ops.ACT16 = out16
+    try:
+        wg = _with_shadow(krsc(w))
+        dyg = nhwc16(dy) if out16 else _with_shadow(nhwc(dy))
+        assert L.dg_conv_bf16_operands_ok(1, N, H, H, C, K, 2, 1) == 2
+        dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        assert dx.dtype == (torch.bfloat16 if out16 else torch.float32)
+        _lib.set_option("no_dma", 1)
+        dxreg = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        torch.cuda.synchronize()
+    finally:
+        ops.SHADOW = False
+        ops.ACT16 = False
+        ops.shadow_clear()
+        _lib.set_option("no_dma", 0)
+        _lib.set_option("splitk", 0)
+        _lib.set_option("bf16", 0)
+    if out16:
+        close16(dx, dxr, what="bf16 window input-grad, bf16 out")
+        # (two roundings of fp32 sums that differ in their last bits: one bf16 step apart at most)
+        close16(dx, dxreg.float(), extra=2e-3, what="window vs register-staged, bf16 out")
+    else:
+        close(dx, dxr, rtol=2e-4, what="bf16 window input-grad")
+        close(dx, dxreg, rtol=2e-4, what="window vs register-staged input-grad")
+
+
 @pytest.mark.parametrize("N,C,K", [(5, 512, 100), (32, 2048, 100), (3, 128, 100)])
 def test_conv_head_bf16_operands(N, C, K):
     """The 4x4 heads (plain GEMMs: FWD / DGRAD_PLAIN / WGRAD with ragged K = 100) on the bf16 tile kernels."""
