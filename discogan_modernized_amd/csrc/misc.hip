@@ -27,7 +27,7 @@ extern "C" int dg_set_option(const char* name, int value) {
     else if (!strcmp(name, "bf16")) g_options[DG_OPT_BF16] = value;   // 1: interior conv GEMMs on bf16 MFMA, fp32 accumulate; 2: fp32 operands as three bf16 planes
     else if (!strcmp(name, "dbg_zero")) g_options[DG_OPT_DBG_ZERO] = value;   // timing experiments only: drop operand loads (wrong results)
     else if (!strcmp(name, "no_dma")) g_options[DG_OPT_NO_DMA] = value;   // 1: bf16-operand convs stay on the register-staged tiles (igemm.hip) instead of the LDS-DMA kernel
-    else if (!strcmp(name, "dma_mfma")) g_options[DG_OPT_DMA_MFMA] = value;   // 32: the LDS-DMA kernel's 32x32x16 body instead of 16x16x32
+    else if (!strcmp(name, "dma_mfma")) g_options[DG_OPT_DMA_MFMA] = value;   // 32: the LDS-DMA kernel's 32x32x16 body instead of 16x16x32; 1: no window kernels (A/B)
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)
     else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);
     return DG_OK;

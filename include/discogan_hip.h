@@ -59,7 +59,8 @@ const char* dg_last_error(void);
  * 3-channel edge layers also round their operands and run on the bf16 MFMA ("kt" 16 keeps their fp32-MFMA kernels);
  * "bf16" 2: fp32-accurate products from three bf16 planes per operand (f32x3);
  * "no_dma" 1: convolutions with two bf16 operands stay on the register-staged tiles instead of the LDS-DMA kernel;
- * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one;
+ * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one; 1: keep the input-grads with <= 128
+ *   output channels on the register-staged tiles instead of the window kernels (same-box A/B);
  * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results). */
 int dg_set_option(const char* name, int value);
 
