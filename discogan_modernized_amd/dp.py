@@ -87,7 +87,8 @@ class ExchangeGroup:
 
     def broadcast_(self, flat: torch.Tensor, src: int = 0):
         """Initial replica sync (DDP constructor broadcast): only needed after rank 0 loaded
-        checkpoints; replicas built from the shared seed are already identical."""
+        checkpoints; replicas built from the shared seed are already identical.  A flat PARAMETER buffer written this way needs ``optim.Adam.refresh_derived()`` afterwards
+        (bf16 shadow / f32x3 planes are derived from it)."""
         if self.world == 1 and self.transport != "capi":
             return
         if self.transport == "capi":

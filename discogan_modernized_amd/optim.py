@@ -80,6 +80,17 @@ class Adam:
         if convs:
             ops.x3_transpose_planes(self.flat_p3, self.flat_p3t, self._x3t_table)
 
+    def refresh_derived(self):
+        """Recompute everything derived from ``flat_p`` (bf16 shadow, f32x3 plane triples and their transposed copy) after the
+        flat buffer was written from outside the optimiser -- e.g. ``ExchangeGroup.broadcast_(opt.flat_p)``; writes through the
+        parameters themselves (``load_state_dict``) are noticed per weight by their version counters."""
+        if getattr(self, "flat_p16", None) is not None:
+            ops.f32_to_bf16(self.flat_p, self.flat_p16)
+        if getattr(self, "flat_p3", None) is not None:
+            ops.f32_to_bf16x3(self.flat_p, self.flat_p3)
+            if self.flat_p3t is not None:
+                ops.x3_transpose_planes(self.flat_p3, self.flat_p3t, self._x3t_table)
+
     # -- torch.optim.Optimizer surface used by the reference loop ------------------------------------
     def zero_grad(self, set_to_none: bool = True):
         self.flat_g.zero_()

@@ -331,6 +331,24 @@ def test_bucketed_exchange_keeps_the_f32x3_weight_planes_current():
     assert torch.equal(res[1][2].float().sum(0), res[1][1])
 
 
+def test_refresh_derived_after_an_outside_write_to_the_flat_parameters():
+    """optim.Adam.refresh_derived: the bf16 shadow / the f32x3 plane triples and their transposed copy follow a write to flat_p
+    that went around the parameters (what ExchangeGroup.broadcast_(opt.flat_p) does)."""
+    g = model.Generator(extra_layers=True, image_size=16).to(DEV)
+    opt = optim.Adam(g.parameters(), lr=2e-4)
+    opt.enable_bf16_shadow()
+    opt.enable_x3_planes()
+    opt.flat_p.mul_(1.5).add_(0.01)
+    opt.refresh_derived()
+    assert torch.equal(opt.flat_p16, opt.flat_p.bfloat16())
+    assert torch.equal(opt.flat_p3.float().sum(0), opt.flat_p)
+    for p_, off in zip(opt.params, opt.offsets):
+        if p_._dg_x3[2] is not None:
+            k, j = p_.shape[0], 16 * p_.shape[1]
+            src = opt.flat_p3[:, off:off + k * j].view(3, k, j).transpose(1, 2).reshape(3, -1)
+            assert torch.equal(opt.flat_p3t[:, off:off + k * j], src)
+
+
 def test_lazy_d_steps_change_only_generator_bn_buffers():
     """need_losses=False (--skip_log_only_passes): weights, optimiser state and D buffers are bitwise the full run's;
     the generators' BatchNorm running statistics are NOT (one forward per D-step instead of two) -- documented."""
