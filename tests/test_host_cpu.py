@@ -127,6 +127,36 @@ def test_loss_helper_signatures():
     assert list(inspect.signature(losses.get_gan_loss).parameters)[:4] == ["dis_real", "dis_fake", "criterion", "device"]
 
 
+def test_conv_planner_dispatch_at_512px_batch32():
+    """Host-side planning only (no kernel runs): which conv kernel every stride-2 layer of the 512 px nets gets on the two fast
+    matrix paths at batch 32 -- the dispatch DESIGN.md section 3.1 describes.  op 0 forward, 1 input-grad, 2 weight-grad."""
+    from discogan_modernized_amd import _lib
+    from discogan_modernized_amd.model import stage_channels
+    L = _lib.load()
+    ch = stage_channels(512)                 # 64, 128, 256, 512, 1024, 2048, 2048
+    layers = [(ch[i - 1], ch[i], 512 >> i) for i in range(1, len(ch))]           # (C, K, H of the layer input)
+    try:
+        _lib.set_option("bf16", 2)           # f32x3: plane kernels (igemm_dma_x3.hip; narrow input-grads: igemm_dma_x3_dgw.hip)
+        for C, K, H in layers:
+            got = [L.dg_conv_x3_planes_ok(op, 32, H, H, C, K, 2, 1) for op in (0, 1, 2)]
+            want = [int(K >= 192), 1, 1]     # forward with < 192 columns stays on the register-staged split; every input-grad
+            assert got == want, (C, K, H, got, want)     # (>= 192 columns: 256 x 256 tile, <= 128: window kernel) and weight-grad has one
+        _lib.set_option("bf16", 1)           # bf16: 2 = LDS-DMA kernel (igemm_dma.hip) or the window kernel, 1 = register-staged tiles
+        for C, K, H in layers:
+            got = [L.dg_conv_bf16_operands_ok(op, 32, H, H, C, K, 2, 1) for op in (0, 1, 2)]
+            want = [2 if K >= 192 else 1, 2, 2 if K >= 192 else 1]
+            assert got == want, (C, K, H, got, want)
+        _lib.set_option("dma_mfma", 1)       # A/B switch: no window kernels
+        assert L.dg_conv_bf16_operands_ok(1, 32, 256, 256, 64, 128, 2, 1) == 1
+        _lib.set_option("bf16", 2)
+        assert L.dg_conv_x3_planes_ok(1, 32, 256, 256, 64, 128, 2, 1) == 0
+        _lib.set_option("bf16", 0)           # exact fp32: neither operand form applies
+        assert L.dg_conv_x3_planes_ok(0, 32, 64, 64, 256, 512, 2, 1) == 0 and L.dg_conv_bf16_operands_ok(0, 32, 64, 64, 256, 512, 2, 1) == 0
+    finally:
+        _lib.set_option("dma_mfma", 0)
+        _lib.set_option("bf16", 0)
+
+
 def test_graft_entry_build():
     import __graft_entry__ as g
     g.build()
