@@ -55,9 +55,10 @@ def parse(argv=None):
     ap.add_argument("--no_extra", action="store_true", help="headline + roofline only")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--single_stream", action="store_true", help="do not overlap the A/B chains on two HIP streams")
-    ap.add_argument("--mfma_dtype", default="f32", choices=["f32", "bf16", "f32x3"],
-                    help="arithmetic of the MAIN run (the JSON's dtype follows it). f32: exact fp32 MFMA (default); bf16: BASELINE "
-                         "configs[4] arithmetic; f32x3: fp32-accurate products from three bf16 planes per operand")
+    ap.add_argument("--mfma_dtype", default="f32x3", choices=["f32", "bf16", "f32x3"],
+                    help="arithmetic of the MAIN run (the JSON's dtype follows it). f32x3 (default): fp32-accurate products from three "
+                         "bf16 planes per operand (24 significand bits, exact products, fp32 accumulation); f32: the exact fp32 MFMA "
+                         "(reported under extra with its own roofline when it is not the main run); bf16: BASELINE configs[4] arithmetic")
     ap.add_argument("--act_dtype", default="f32", choices=["f32", "bf16"],
                     help="with --mfma_dtype bf16: feature maps and their gradients STORED in bf16 (fp32 BatchNorm statistics / arithmetic)")
     ap.add_argument("--no_x3_planes", action="store_true", help="with --mfma_dtype f32x3: split the operands inside every conv kernel "
@@ -109,12 +110,17 @@ def self_launch(a, argv):
     return rc if rc != 0 or line else 1
 
 
-def barrier_sync(world):
+def barrier_sync(world, xg=None):
+    """Device barrier over the ranks.  On the capi transport it goes through the library's own communicator
+    (dg_dp_barrier), so the timed run has ONE RCCL instance; torch.distributed's is never created."""
     import torch
     import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        if xg is not None and xg.transport == "capi":
+            xg.barrier()
+        else:
+            dist.barrier()
     torch.cuda.synchronize()
 
 
@@ -126,18 +132,17 @@ def timed_run(trainer, A, B, steps, warmup, world, start_iter=0, need_losses=Tru
         trainer.train_iteration(A, B, it, need_losses=need_losses)
         it += 1
     trainer.finish()
-    barrier_sync(world)
+    barrier_sync(world, trainer.xg)
     t0 = time.perf_counter()
     for _ in range(steps):
         trainer.train_iteration(A, B, it, need_losses=need_losses)
         it += 1
     trainer.finish()
-    barrier_sync(world)
+    barrier_sync(world, trainer.xg)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # max over ranks
-        dt = float(t.item())
+        from discogan_modernized_amd import dp
+        dt = max(dp.host_allgather(dt))                            # max over ranks (host-side, through the c10d store)
     return dt, it
 
 
@@ -184,21 +189,29 @@ def roofline_pass(trainer, A, B, start_iter):
     return flops, ms, len(fam), by, hbm, start_iter + ui
 
 
-def pmc_traffic(image_size, batch):
-    """HBM-side bytes per launch of the dominant instantiation (the stride-2 forward igemm) from the committed rocprofv3
-    PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see profiles/README.md); only for the profiled workloads."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_per_launch_{image_size}px_bs{batch}.json")
+PMC_KERNEL = {   # dominant instantiation (most launches x bytes) of each arithmetic's conv family, by kernel-name prefix
+    "f32": ("", "void igemm_kernel<0,"),
+    "f32x3": ("_f32x3", "void igemm_dma_x3_kernel<"),
+    "bf16": ("_bf16", "void igemm_dma_kernel<"),
+}
+
+
+def pmc_traffic(image_size, batch, mfma_dtype="f32"):
+    """HBM-side bytes per launch of the dominant instantiation of the conv family from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see profiles/README.md); only for the profiled workloads."""
+    tag, prefix = PMC_KERNEL[mfma_dtype]
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_per_launch_{image_size}px_bs{batch}{tag}.json")
         if not os.path.exists(path):
             continue
         try:
             ks = json.load(open(path))["kernels"]
-            cand = [(k, v) for k, v in ks.items() if k.startswith("void igemm_kernel<0,")]
+            cand = [(k, v) for k, v in ks.items() if k.startswith(prefix)]
             k, v = max(cand, key=lambda kv: kv[1]["launches"] * kv[1]["hbm_MB_per_launch"])
             return int(v["hbm_MB_per_launch"] * 1024 * 1024), f"bytes/launch beyond L2 for {k} from profiles/{os.path.basename(path)} (PMC, offline)"
         except Exception:
             continue
-    return None, "no PMC profile committed for this workload"
+    return None, f"no PMC profile committed for this workload ({mfma_dtype})"
 
 
 def step_split_ms(trainer, A, B, start_iter, cycles):
@@ -254,31 +267,20 @@ def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=No
               act_dtype=act_dtype or (a.act_dtype if (mfma_dtype or a.mfma_dtype) == "bf16" else "f32"), skew_steps=a.skew_steps,
               async_wgrad=a.async_wgrad, mfma_turns=a.mfma_turns, x3_planes=False if a.no_x3_planes else None)
     want = comm or a.comm
-    if pg is None or want == "c10d":
-        return DiscoGANTrainer(default_args(), comm=want, **kw)
-    # Multi-rank run: the library's own RCCL communicator is the default transport.  Should its bootstrap fail on ANY rank
-    # (it has only been exercised with one rank on the builder's 1-GPU boxes), every rank falls back to torch.distributed's
-    # RCCL together and the JSON says so -- a benchmark harness decision, visible, never silent.
-    import torch
-    import torch.distributed as dist
-    tr, err = None, ""
-    try:
-        tr = DiscoGANTrainer(default_args(), comm=want, **kw)
-    except Exception as e:            # noqa: BLE001
-        err = f"{type(e).__name__}: {e}"
-    ok = torch.tensor([1 if tr is not None else 0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        return tr
-    if tr is not None:
-        tr.close()
-    COMM_NOTE.append(f"capi transport unavailable on at least one rank ({err or 'another rank failed'}); all ranks use c10d")
-    log(COMM_NOTE[-1])
-    return DiscoGANTrainer(default_args(), comm="c10d", **kw)
+    # Multi-rank run: "auto" = the library's own RCCL communicator.  dp.ExchangeGroup votes on every rank's readiness BEFORE
+    # the collective init (store keys, no collective) and runs the init under a deadline: a failed vote moves ALL ranks to
+    # torch.distributed's RCCL together (tr.xg.note, copied into the JSON), a blocked init exits non-zero -- never a hang.
+    tr = DiscoGANTrainer(default_args(), comm=want, **kw)
+    if tr.xg is not None and tr.xg.note:
+        COMM_NOTE.append(tr.xg.note)
+        log(tr.xg.note)
+    return tr
 
 
-def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycles=0, image_size=None):
-    """value + optional roofline leg + optional D/G split for one trainer; returns a dict."""
+def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycles=0, image_size=None, exposed=False):
+    """value + optional roofline leg + optional D/G split for one trainer; returns a dict.
+    exposed (N > 1): the same timed window once more with the collectives stubbed (every rank keeps its own sum; the
+    exchange path, buckets, events and Adam slices still run) -- the difference is the exchange time the step actually pays."""
     ui = tr.args.update_interval
     # K a multiple of the cycle: start on a D-step (whole D,G,G cycles, exact).  Otherwise start right AFTER a D-step, so
     # the partial cycle at the end holds G-steps only: the window then has the fewest cheap D-steps a K-step window can
@@ -291,6 +293,14 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
     live = LIVE_GFLOP_PER_IMAGE.get(image_size or tr.image_size)
     if live:
         res["whole_step_tflops"] = round(batch * steps / dt * live / 1e3, 2)
+    if exposed and tr.xg is not None:
+        tr.xg.noop = True
+        try:
+            dt0, it = timed_run(tr, A, B, steps, (phase - it) % ui + ui, world, start_iter=it)
+        finally:
+            tr.xg.noop = False
+        res["ms_per_step_exchange_stubbed"] = round(dt0 / steps * 1e3, 3)
+        res["exposed_ms_per_step"] = round((dt - dt0) / steps * 1e3, 3)
     if roofline:
         flops, ms, nlaunch, by, hbm, it = roofline_pass(tr, A, B, it)
         bf = tr.mfma_dtype == "bf16"
@@ -300,7 +310,8 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
         ach = flops / (ms * 1e-3) / 1e12
         res["roofline"] = dict(
             bound="mfma",
-            kernel=("igemm_kernel<*,PREC=1> (v_mfma_f32_32x32x16_bf16 implicit-GEMM conv family)" if bf else
+            kernel=("igemm_dma_kernel<*> + igemm_bf16_dgw_kernel<*> + igemm_kernel<*,PREC=1> (bf16 implicit-GEMM conv family: LDS-DMA tiles on "
+                    "v_mfma_f32_16x16x32_bf16 where the GEMM is at least 192 wide, register-staged v_mfma_f32_32x32x16_bf16 tiles elsewhere)" if bf else
                     "igemm_dma_x3_kernel<*> + igemm_kernel<*,PREC=2> (fp32 operands as three bf16 planes -- written once per tensor and staged by "
                     "LDS-DMA where the GEMM is at least 192 wide, split in the conv kernel elsewhere --, six v_mfma_f32_32x32x16_bf16 per "
                     "product block; peak = dense bf16 peak / 6; the exact-fp32 MFMA peak is 157.3)" if x3 else
@@ -358,7 +369,7 @@ def main():
     A, B = synthetic_batch(N, S, 1000 + rank, dev)
     log(f"models built; {a.warmup} warm-up + {a.steps} timed steps @{S}px batch {N} x {world} GPU")
     head = measure(a, tr, A, B, N, world, a.steps, a.warmup, roofline=not a.no_roofline,
-                   split_cycles=0 if a.no_extra else (2 if S == 512 else 4))
+                   split_cycles=0 if a.no_extra else (2 if S == 512 else 4), exposed=world > 1)
     log(f"timed region done: {head['ms_per_step']:.3f} ms/step, {head['images_per_sec']:.1f} img/s")
     comm = None
     if world > 1:
@@ -368,6 +379,12 @@ def main():
         comm = dict(transport=tr.xg.describe(), backend=backend, world_size=dist.get_world_size(), rccl_world_size=rccl_ws,
                     allreduce_ms_per_D_step=round(ms.get("D", 0.0), 3), allreduce_ms_per_G_step=None,
                     allreduce_overlap=bool(tr.overlap_comm), exchanges=tr.xg.calls,
+                    exposed_ms_per_step=head.get("exposed_ms_per_step"),
+                    ms_per_step_exchange_stubbed=head.get("ms_per_step_exchange_stubbed"),
+                    note_times=("allreduce_ms_per_*_step = summed HIP-event durations of the collectives on the stream they run on "
+                                "(with overlap: occupancy of the communication stream, not time the step waits); exposed_ms_per_step = "
+                                "ms_per_step minus the same window with the collectives stubbed = what the exchange costs the step"),
+                    rccl_instances=(1 if tr.xg.transport == "capi" else None),
                     payload_MB=dict(D=round(tr.optim_dis.numel * 4 / 1e6, 1), G=round(tr.optim_gen.numel * 4 / 1e6, 1)),
                     note=(COMM_NOTE[-1] if COMM_NOTE else None))
         if "G" in ms:
@@ -375,8 +392,7 @@ def main():
             comm["G_step_buckets"] = len(tr._buckets.buckets) if tr._buckets is not None else 1
     roof = head.get("roofline")
     if roof is not None:
-        traffic, note = pmc_traffic(S, N) if a.mfma_dtype == "f32" else (None, "not profiled for bf16")
-        roof["traffic"], roof["traffic_note"] = traffic, note
+        roof["traffic"], roof["traffic_note"] = pmc_traffic(S, N, a.mfma_dtype)
     extra = {k: v for k, v in head.items() if k in ("ms_D_step", "ms_G_step", "ms_per_step_whole_cycles", "whole_step_tflops",
                                                     "hbm_bound_families")}
     if "hbm_bound_families" in extra:
@@ -395,8 +411,11 @@ def main():
             r = measure(a, t, x, y, batch, 1, steps, warmup, roofline=kw.get("roofline", False), image_size=image_size)
             r.pop("_next_iter", None)
             if "roofline" in r:
-                r["roofline"].pop("by_op", None)
-            r.pop("hbm_bound_families", None)
+                if not kw.get("keep_by_op"):
+                    r["roofline"].pop("by_op", None)
+                r["roofline"]["traffic"], r["roofline"]["traffic_note"] = pmc_traffic(image_size, batch, kw.get("mfma_dtype") or a.mfma_dtype)
+            if not kw.get("keep_by_op"):
+                r.pop("hbm_bound_families", None)
             t.close()
             del t, x, y
             torch.cuda.empty_cache()
@@ -405,7 +424,8 @@ def main():
 
         for other in ("f32", "bf16", "f32x3"):
             if other != a.mfma_dtype:
-                side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True, act_dtype="f32")
+                side(f"{S}px_bs{N}_{other}_mfma", S, N, a.steps, a.warmup, mfma_dtype=other, roofline=True, act_dtype="f32",
+                     keep_by_op=(other == "f32"))
         if not (a.mfma_dtype == "bf16" and a.act_dtype == "bf16"):
             side(f"{S}px_bs{N}_bf16_mfma_bf16_activations", S, N, a.steps, a.warmup, mfma_dtype="bf16", act_dtype="bf16", roofline=True)
         if S == 512:
@@ -452,7 +472,10 @@ def main():
                     n_gpus=world, steps=a.steps, warmup=head["warmup"], ms_per_step=head["ms_per_step"],
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.mfma_dtype, data="synthetic",
                     config=dict(workload=WORKLOADS[S].format(b=N) + "; D,G,G cycle, fwd+bwd+Adam, dead backward work skipped"
-                                + ("" if a.mfma_dtype == "f32" else "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)")
+                                + {"f32": "; exact fp32 MFMA",
+                                   "f32x3": "; fp32-accurate conv products on the bf16 matrix path: every fp32 operand carried as three bf16 "
+                                            "planes (24 significand bits), exact bf16 x bf16 products, fp32 accumulation (no operand rounding)",
+                                   "bf16": "; conv operands rounded to bf16 (bf16 MFMA, fp32 accumulate)"}[a.mfma_dtype]
                                 + ("; feature maps stored in bf16, fp32 BatchNorm statistics" if (a.mfma_dtype == "bf16" and a.act_dtype == "bf16") else ""),
                                 image_size=S, global_batch=N * world, parallelism=f"dp{world}",
                                 hipgraph=head["hipgraph"], hip_streams=1 if a.single_stream else 2,
@@ -465,7 +488,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
-        dist.barrier()
+        from discogan_modernized_amd import dp
+        dp.host_barrier()                 # store keys, not a device collective: no second RCCL communicator at exit either
         dist.destroy_process_group()
 
 

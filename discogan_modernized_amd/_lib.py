@@ -80,12 +80,14 @@ SIGNATURES = {
     "dg_bce_target_bwd": (_i, [_p, _p, _i, _p, _p, _p]),
     "dg_hinge_fwd": (_i, [_p, _p, _z, _f, _p, _p, _z, _p]),
     "dg_hinge_bwd": (_i, [_p, _p, _z, _f, _p, _p, _p]),
+    "dg_dp_ready": (_i, [_p]),
     "dg_dp_unique_id_bytes": (_i, []),
     "dg_dp_get_unique_id": (_i, [_p, _z]),
     "dg_dp_init": (_i, [_i, _i, _p, _z]),
     "dg_dp_world_size": (_i, []),
     "dg_dp_rank": (_i, []),
     "dg_dp_allreduce_sum": (_i, [_p, _z, _p]),
+    "dg_dp_allreduce_max": (_i, [_p, _z, _p]),
     "dg_dp_broadcast": (_i, [_p, _z, _i, _p]),
     "dg_dp_barrier": (_i, [_p, _p]),
     "dg_dp_destroy": (_i, []),

@@ -59,6 +59,19 @@ int nccl_fail(const char* who, ncclResult_t r) {
 
 extern "C" int dg_dp_unique_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
 
+// Local readiness probe, nothing collective: everything that can fail on ONE rank before ncclCommInitRank is checked
+// here, so the ranks can agree on the outcome before any of them enters the blocking collective.
+extern "C" int dg_dp_ready(int* device_out) {
+    if (g_comm) return dg_fail(DG_ERR_INVALID, "dg_dp_ready: a communicator already exists (call dg_dp_destroy first)");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return dg_fail(DG_ERR_HIP, "dg_dp_ready: no current HIP device: %s", hipGetErrorString(e));
+    if (device_out) *device_out = dev;
+    return DG_OK;
+}
+
 extern "C" int dg_dp_get_unique_id(void* id_out, size_t bytes) {
     DG_CHECK_ARG(id_out && bytes >= NCCL_UNIQUE_ID_BYTES, "dg_dp_get_unique_id: need a %d-byte host buffer", NCCL_UNIQUE_ID_BYTES);
     int rc = bind_rccl();
@@ -95,13 +108,19 @@ extern "C" int dg_dp_world_size(void) {
 }
 extern "C" int dg_dp_rank(void) { return g_comm ? g_rank : -1; }
 
-extern "C" int dg_dp_allreduce_sum(float* buf, size_t n, dg_stream_t stream) {
-    DG_CHECK_ARG(buf || n == 0, "dg_dp_allreduce_sum: null buffer");
-    if (!g_comm) return dg_fail(DG_ERR_INVALID, "dg_dp_allreduce_sum: no communicator (dg_dp_init)");
+static int allreduce_f32(const char* who, float* buf, size_t n, ncclRedOp_t op, dg_stream_t stream) {
+    if (!buf && n) return dg_fail(DG_ERR_INVALID, "%s: null buffer", who);
+    if (!g_comm) return dg_fail(DG_ERR_INVALID, "%s: no communicator (dg_dp_init)", who);
     if (n == 0) return DG_OK;
-    ncclResult_t r = R.AllReduce(buf, buf, n, ncclFloat32, ncclSum, g_comm, (hipStream_t)stream);
+    ncclResult_t r = R.AllReduce(buf, buf, n, ncclFloat32, op, g_comm, (hipStream_t)stream);
     if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
     return DG_OK;
+}
+extern "C" int dg_dp_allreduce_sum(float* buf, size_t n, dg_stream_t stream) {
+    return allreduce_f32("dg_dp_allreduce_sum", buf, n, ncclSum, stream);
+}
+extern "C" int dg_dp_allreduce_max(float* buf, size_t n, dg_stream_t stream) {
+    return allreduce_f32("dg_dp_allreduce_max", buf, n, ncclMax, stream);
 }
 
 extern "C" int dg_dp_broadcast(float* buf, size_t n, int root, dg_stream_t stream) {

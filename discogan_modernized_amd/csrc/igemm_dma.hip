@@ -42,14 +42,10 @@ template <int... Q, typename F>
 __device__ __forceinline__ void dg_static_for(std::integer_sequence<int, Q...>, F&& f) {
     (f(std::integral_constant<int, Q>{}), ...);
 }
-#ifndef DG_M16_FD
-#define DG_M16_FD 4
-#define DG_M16_BB 4
-#define DG_M16_B0 4
-#endif
-#ifndef DG_DMA_SPREAD_FETCH
-#define DG_DMA_SPREAD_FETCH 0
-#endif
+// Fetch schedule of the 16x16x32 body: A blocks fetched M16_FD blocks ahead, the tile barrier M16_BB row groups before the end
+// of the tile, the next step's B blocks M16_B0 MFMAs into the step.  Six variants of (4..6, 16..24 MFMAs, early / late) measured
+// within +-1 % of each other (same-box A/B, round 2); these are the kept values.
+constexpr int M16_FD = 4, M16_BB = 4, M16_B0 = 4;
 
 // M16: the MFMA shape.  false: v_mfma_f32_32x32x16_bf16 (4 x 2 accumulator blocks of 32x32 per wave); true:
 // v_mfma_f32_16x16x32_bf16 (8 x 4 blocks of 16x16, the same 128 accumulator registers, the same LDS traffic).  The loop is
@@ -417,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
 #pragma unroll
         for (int j = 0; j < BNB; ++j) fetchB16(0, 0, 0, j);
 #pragma unroll
-        for (int i = 0; i < DG_M16_FD; ++i) fetchA16(0, 0, i);
+        for (int i = 0; i < M16_FD; ++i) fetchA16(0, 0, i);
     } else {
         fetch(0, 0, 0);
     }
@@ -439,12 +435,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
                 __builtin_amdgcn_s_barrier();
             }
             // the next k16 step's fragments (behind the barrier: the next tile's first step), one fragment per MFMA gap
-#if DG_DMA_SPREAD_FETCH
-            if (w < FM + FN) fetch1(s + 1 < 4 ? ST : ST ^ 1, s + 1 < 4 ? s + 1 : 0, (s + 1) & 1, w);
-#else
+            // (one fragment per MFMA gap instead of a whole step's worth here made the weight gradient 25 % slower: round 2 A/B)
             if (q == QB) fetch(ST ^ 1, 0, 0);
             if (w == 1 && s + 1 < 4) fetch(ST, s + 1, (s + 1) & 1);
-#endif
             acc[w / FN][w % FN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][w / FN], fb[s & 1][w % FN], acc[w / FN][w % FN], 0, 0, 0);
             // DMA pieces: the second half of tile t+1 behind the first PER MFMAs, the first half of tile t+2 behind the
             // last PER (after the barrier: into the stage tile t is leaving)
@@ -476,7 +469,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     // last one, A(1, 7), is fetched in block (1, 7 - FD) < BB), B0 = the block of step 0 that starts fetching step 1's B blocks.
     auto body16 = [&](auto ST_) {
         constexpr int ST = decltype(ST_)::value;
-        constexpr int FD = DG_M16_FD, BB = DG_M16_BB, B0 = DG_M16_B0;
+        constexpr int FD = M16_FD, BB = M16_BB, B0 = M16_B0;
         static_assert(FD >= 1 && FD <= 7 && 7 - FD < BB && BB <= 6 && B0 <= 6, "M16 schedule");
         constexpr int NMF16 = 2 * AM * BNB, QB16 = AM * BNB + BB * BNB;
         dg_static_for(std::make_integer_sequence<int, NMF16>{}, [&](auto Q_) {

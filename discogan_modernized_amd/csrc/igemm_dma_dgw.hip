@@ -13,8 +13,9 @@
 //     fragment is a read at `window row + dyo (Wo + 2) + dxo`; halo pixels outside the image: out-of-range DMA offsets = zeros;
 //   * weight tile of step (chunk c, tap t): [32 k][NCLS x CW columns] = 16 KB, the (r, s) of (class, t) in the per-lane DMA
 //     offsets; THREE stages (a step is only 16 MFMAs per wave: a weight tile gets two steps to land);
-//   * every wave issues the SAME number of DMA instructions per step (2 weight pieces; 3 / 2 / 0 / 0 window pieces in steps 0..3,
-//     absent pieces are zero-fills of unused LDS), so the counted wait in front of the step barrier is exact for every wave;
+//   * every wave issues the SAME number of DMA instructions per step (WPS = 2 weight pieces; NWIN = 3 / 2 / 0 / 0 window pieces in
+//     taps 0..3, absent pieces are zero-fills of unused LDS), so the counted wait in front of the step barrier is exact for every
+//     wave; the counts are compile-time constants, the waits are computed from them and static_asserts tie the issue sites to them;
 //   * step = 2 k16 steps x 8 accumulator blocks (v_mfma_f32_32x32x16_bf16); fragments double-buffered over the k16 steps, the
 //     barrier in front of the second one, the next step's first fragments behind it (igemm_dma.hip's 32x32 body).
 // Epilogue: fp32 or bf16 output (RNE), split-K slabs in igemm.hip's layout.
@@ -37,6 +38,15 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
     constexpr int WN = 4, FM = 4, FN = 2, KT = 32;      // 2 x 4 waves of 128 x 64
     constexpr int CW = 256 / NCLS;                      // columns per class
     constexpr int NWP = 5;                              // window pieces (16 rows of 64 B each) per wave: 40 pieces >= 33
+    // DMA schedule, the basis of the counted `vmcnt` waits.  EVERY wave issues, unconditionally (no lane- or wave-dependent
+    // branch around a `dma()`: absent window rows / weight columns are out-of-range offsets = zero-fills), exactly
+    //   WPS weight pieces in every step, and NWIN[T] window pieces of the next chunk in tap T of a chunk.
+    // The waits below are derived from these constants; the asserts tie the issue sites to them.
+    constexpr int WPS = 2;                              // weight pieces per wave and step (16 pieces x 1 KiB = one 16 KB stage)
+    constexpr int NWIN[4] = {3, 2, 0, 0};               // window pieces per wave issued in taps 0..3
+    static_assert(NWIN[0] + NWIN[1] + NWIN[2] + NWIN[3] == NWP, "the four taps of a chunk must issue the whole next window");
+    static_assert(8 * WPS * 1024 == 256 * KT * 2, "8 waves x WPS pieces must cover one weight stage");
+    static_assert(NWIN[2] == 0 && NWIN[3] == 0, "the window of chunk c + 1 must be complete two barriers before its first read (tap 3's barrier)");
     constexpr int AST = 8 * NWP * 1024;                 // window stage: 40 KB
     constexpr int BST = 256 * KT * 2;                   // weight stage: 16 KB
     constexpr int B_OFF = 0, A_OFF = 3 * BST;           // weight stages first
@@ -100,9 +110,9 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
     // ---- weight DMA descriptors: tile [32 k][256 columns], column = class-local-index * CW + c; pieces 2 w, 2 w + 1 ------------
     // piece pq = k rows 2 pq, 2 pq + 1; lane L lands in (k row 2 pq + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
     // the tap (r, s) of (class, t) is added per step from the lane's class bits
-    int b_base[2], b_cls[2];              // b_cls: the lane's class bits (ph << 1 | pw) -- per piece: the swizzle moves a lane between classes
+    int b_base[WPS], b_cls[WPS];          // b_cls: the lane's class bits (ph << 1 | pw) -- per piece: the swizzle moves a lane between classes
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WPS; ++i) {
         const int krow = (wave * 2 + i) * 2 + (lane >> 5);
         const int gc = (lane & 31) ^ kmswz(krow);
         const int col = gc * 8;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
     auto issue_weights = [&](int bst, int c, int t) {
         const int ty = t >> 1, tx = t & 1;                                  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WPS; ++i) {
             const int lph = b_cls[i] >> 1, lpw = b_cls[i] & 1;              // per lane (the lane's class)
             const int r = lph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
             const int sx = lpw == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 2 : 0);
@@ -209,7 +219,8 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
             issue_weights(st, wc, wt);
             advance();
         }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // window and the first weight tile
+        // issued so far per wave: NWP window pieces, then 3 x WPS weight pieces; all but the last two weight tiles have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPS) : "memory");      // window and the first weight tile
     }
     __builtin_amdgcn_s_barrier();
     if (stp) stp[2] = clock64();
@@ -222,12 +233,10 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
     auto body = [&](auto AS_, auto T_, int c) {
         constexpr int AS = decltype(AS_)::value, T = decltype(T_)::value;
         constexpr int NT = (T + 1) & 3, NAS = T == 3 ? AS ^ 1 : AS;
-        constexpr int NWIN[4] = {3, 2, 0, 0};                       // window pieces issued in step T (j = 0..2 / 3..4)
-#ifdef DGWB_VM0
-        constexpr int VM = 0;
-#else
-        constexpr int VM = 2 + NWIN[(T + 3) & 3];
-#endif
+        // in flight and allowed to stay so across this step's barrier: what the PREVIOUS step issued (its WPS weight pieces and
+        // its NWIN window pieces); everything older -- this step's successor's weight tile, the whole next window in front of
+        // tap 3 -- has landed when the counter is down to that number, in EVERY wave, because every wave issued the same count
+        constexpr int VM = WPS + NWIN[(T + 3) & 3];
         const int bnext = bcur == 2 ? 0 : bcur + 1;
         dgwb_static_for(std::make_integer_sequence<int, 16>{}, [&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
@@ -244,8 +253,9 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
                 issue_weights(bcur, wc, wt);
                 advance();
             }
-            if constexpr (T == 0 && q >= 10 && q <= 12) issue_window(AS ^ 1, q - 10, min(c + 1, ce - 1));
-            if constexpr (T == 1 && q >= 10 && q <= 11) issue_window(AS ^ 1, q - 10 + 3, min(c + 1, ce - 1));
+            static_assert(10 + NWIN[0] <= 16 && 10 + NWIN[1] <= 16, "window pieces ride behind MFMAs 10.. of the step");
+            if constexpr (T == 0 && q >= 10 && q < 10 + NWIN[0]) issue_window(AS ^ 1, q - 10, min(c + 1, ce - 1));
+            if constexpr (T == 1 && q >= 10 && q < 10 + NWIN[1]) issue_window(AS ^ 1, q - 10 + NWIN[0], min(c + 1, ce - 1));
         });
         __builtin_amdgcn_sched_barrier(0);
         bcur = bnext;

@@ -38,9 +38,6 @@ template <int... Q, typename F>
 __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...>, F&& f) {
     (f(std::integral_constant<int, Q>{}), ...);
 }
-#ifndef DG_X3_QB
-#define DG_X3_QB 8
-#endif
 #define DG_X3T_MAX 48
 
 // BT (FWD only): the weight planes are the TRANSPOSED copy wT[(r, s, c)][k] (dg_x3_transpose_planes): the B tile of a K-tile is
@@ -378,7 +375,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     // ST = LDS stage of the current tile t, PAR = t & 1 (which B hi register set holds tile t).  Fragment replacement (tile
     // t+1, stage NX = (ST + 1) % NS), always one MFMA behind the last reader: A row i-1 in front of MFMA 12 i + 1; B lo in
     // front of MFMA 41, B mid in front of 47, A row 3 at the end; B hi (other register set) right behind the barrier.
-    constexpr int QB = DG_X3_QB;
+    constexpr int QB = 8;
     static_assert(QB >= 1 && QB <= 12, "the tile barrier precedes the first read of tile t+1");
     static_assert(QB + 2 * NPC <= 48, "the DMA of tile t+NS is issued inside tile t");
     auto body = [&](auto ST_, auto PAR_) {

@@ -70,14 +70,16 @@ def main_worker(local_rank, args):
                                   mfma_dtype=getattr(args, "mfma_dtype", "f32"), act_dtype=getattr(args, "act_dtype", "f32"),
                                   comm=getattr(args, "comm", "auto"))
         load_checkpoints(args, trainer)
-        if args.distributed:
-            dist.barrier()
+        # barriers go through the transport the gradients use (capi: the library's communicator -- the process then holds ONE
+        # RCCL instance; torch.distributed's is created lazily by its first device collective and never is)
+        sync = (trainer.xg.barrier if trainer.xg is not None else (lambda: None))
+        sync()
         if rank == 0 and trainer.xg is not None:
             print("data-parallel exchange:", trainer.xg.describe(), flush=True)
         try:
             it.train(args, trainer=trainer, rank=rank, world_size=world, is_main=(rank == 0), process_group=pg)
-            if args.distributed:
-                dist.barrier()
+            trainer.finish()
+            sync()
         finally:
             trainer.close()                       # dg_dp_destroy before the process group goes away
     finally:

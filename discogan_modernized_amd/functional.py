@@ -60,6 +60,21 @@ def _launch_wgrad(fn, *tensors):
         t.record_stream(aux)
 
 
+def _release_unless_wgrad(ctx, x):
+    """Forward of an interior conv: the layer input's bf16 shadow / plane triple is read again only by this layer's weight
+    gradient.  No weight gradient coming (no_grad generator passes of a D-step, frozen discriminators of a G-step) -> the
+    derived copy is dropped right here instead of at the end of the iteration."""
+    if not ctx.needs_input_grad[1]:
+        ops.derived_release(x)
+
+
+def _release_after_backward(dy, x):
+    """Backward of an interior conv: input-grad and weight-grad were the last readers of dy's and x's derived copies (with
+    the weight gradient on a third stream the copies stay until the trainer clears the tables)."""
+    if WGRAD_STREAM is None:
+        ops.derived_release(dy, x)
+
+
 class ConvFn(Function):
     """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
 
@@ -71,8 +86,11 @@ class ConvFn(Function):
         ctx.wref = w
         ctx.final = FINAL_PASS
         if not want_stats:
-            return ops.conv_fwd(x, w, stride, pad)
+            y = ops.conv_fwd(x, w, stride, pad)
+            _release_unless_wgrad(ctx, x)
+            return y
         y, stat = ops.conv_fwd(x, w, stride, pad, want_stats=want_stats)
+        _release_unless_wgrad(ctx, x)
         if stat is None:
             stat = torch.empty(0, device=y.device)
         ctx.mark_non_differentiable(stat)
@@ -93,6 +111,7 @@ class ConvFn(Function):
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(dy, x, stride, pad)
+        _release_after_backward(dy, x)
         return dx, dw, None, None, None
 
 
@@ -111,8 +130,11 @@ class ConvTransposeFn(Function):
         hout, wout = (hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4
         ctx.out_hw = (hout, wout)
         if not want_stats:
-            return ops.conv_dgrad(x, w, (hout, wout), stride, pad)
+            y = ops.conv_dgrad(x, w, (hout, wout), stride, pad)
+            _release_unless_wgrad(ctx, x)
+            return y
         y, stat = ops.conv_dgrad(x, w, (hout, wout), stride, pad, want_stats=want_stats)
+        _release_unless_wgrad(ctx, x)
         if stat is None:
             stat = torch.empty(0, device=y.device)
         ctx.mark_non_differentiable(stat)
@@ -134,6 +156,7 @@ class ConvTransposeFn(Function):
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(x, dy, stride, pad)
+        _release_after_backward(dy, x)
         return dx, dw, None, None, None
 
 

@@ -44,7 +44,9 @@ def build_command(argv, environ=None):
         gpus = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
     if gpus is None:
         import torch
-        gpus = ",".join(str(i) for i in range(max(torch.cuda.device_count(), 1)))   # device_count() does not initialise HIP
+        # Counting devices may initialise the HIP runtime in THIS process (it can on ROCm builds).  That is harmless here only
+        # because the ranks are started as CHILD processes below (subprocess), never by replacing this process with exec.
+        gpus = ",".join(str(i) for i in range(max(torch.cuda.device_count(), 1)))
     world = len([g for g in gpus.split(",") if g != ""])
     env["HIP_VISIBLE_DEVICES"] = gpus
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -96,15 +96,18 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def _check_dev(*ts):
+def _check_dev(*ts, allow16=False):
+    """fp32 HIP tensors only.  allow16: the wrapper dispatches on the storage type itself (bf16 activation storage: the
+    ``*_t`` / ``*_mixed`` entry points); every other wrapper calls an fp32-only kernel with numel() elements, where a bf16
+    tensor would be read as floats past its end -- refused here instead."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise _lib.DiscoganHipError(
                 "discogan_modernized_amd ops need CUDA/HIP tensors (no CPU fallback exists); got a CPU tensor")
-        if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
-            raise _lib.DiscoganHipError(f"fp32 (or, with bf16 activation storage, bf16) tensors required, got {t.dtype}")
+        if t.dtype != torch.float32 and not (allow16 and t.dtype == torch.bfloat16):
+            raise _lib.DiscoganHipError(("fp32 or bf16" if allow16 else "fp32") + f" tensors required, got {t.dtype}")
 
 
 # ---- layout helpers -------------------------------------------------------------------------------------
@@ -209,6 +212,20 @@ def shadow_clear():
 
 def shadow_put(t, t16):
     _SHADOW_TAB[t.data_ptr()] = (t, t16)
+
+
+def derived_release(*tensors):
+    """Drop the bf16 shadow / plane triple of tensors whose conv consumers have all been issued (functional.py calls this
+    after a layer's input-grad and weight-grad): the fp32 tensor and its copies then die with autograd's own references
+    instead of living to the end of the iteration (or, under hipGraph capture, forever in the graph's pool)."""
+    for t in tensors:
+        if t is None:
+            continue
+        key = t.data_ptr()
+        for tab in (_SHADOW_TAB, _PLANE_TAB):
+            e = tab.get(key)
+            if e is not None and e[0].shape == t.shape:
+                del tab[key]
 
 
 def shadow_get(t):
@@ -345,7 +362,8 @@ def _mixed_operand(t, allow_shadow=True):
 def conv_fwd(x, w, stride, pad, want_stats=False):
     """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC.
     want_stats: also return the BatchNorm partial-statistics rows of y (None if the layer has no fused path)."""
-    _check_dev(x, w)
+    _check_dev(x, allow16=True)
+    _check_dev(w)
     x = as_nhwc(x)
     w = _krsc(w)
     n, c, h, wd = x.shape
@@ -398,7 +416,8 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
 def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     """Input-gradient of that Conv2d == ConvTranspose2d forward. dy [N,K,Ho,Wo]; returns [N,C,H,W]
     (and, with want_stats, the BatchNorm partial-statistics rows of the result or None)."""
-    _check_dev(dy, w)
+    _check_dev(dy, allow16=True)
+    _check_dev(w)
     dy = as_nhwc(dy)
     w = _krsc(w)
     n, k = dy.shape[0], dy.shape[1]
@@ -481,7 +500,7 @@ def conv_dgrad_bias_act(x, w, bias, out_hw, stride, pad, act=ACT_NONE, slope=0.0
 
 def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     """Weight-gradient of that Conv2d: returns logical [K,C,4,4] (KRSC memory)."""
-    _check_dev(dy, x)
+    _check_dev(dy, x, allow16=True)
     dy = as_nhwc(dy)
     x = as_nhwc(x)
     n, c, h, wd = x.shape
@@ -540,7 +559,8 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
 
 def c3_dgrad(dy, w, act=ACT_NONE):
     """dy NHWC-memory [N,K,Ho,Wo], w contiguous [K,3,4,4] -> contiguous NCHW [N,3,2Ho,2Wo] (act fused)."""
-    _check_dev(dy, w)
+    _check_dev(dy, allow16=True)
+    _check_dev(w)
     dy = as_nhwc(dy)
     w = w.contiguous()
     n, k, ho, wo = dy.shape
@@ -560,7 +580,8 @@ def c3_dgrad(dy, w, act=ACT_NONE):
 def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE, slope=0.0):
     """dw [K,3,4,4] contiguous from dy NHWC-memory [N,K,Ho,Wo] and x NCHW [N,3,H,W].  With ``act_out`` (the saved
     output of the layer's fused LeakyReLU/ReLU) dy is taken through the activation backward on the fly."""
-    _check_dev(dy, x_nchw)
+    _check_dev(dy, act_out, allow16=True)
+    _check_dev(x_nchw)
     dy = as_nhwc(dy)
     x = x_nchw.contiguous()
     n, k, ho, wo = dy.shape
@@ -591,7 +612,7 @@ def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE,
 
 # ---- BatchNorm + activation -----------------------------------------------------------------------------
 def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
-    _check_dev(y)
+    _check_dev(y, allow16=True)
     y = as_nhwc(y)
     n, c, h, w = y.shape
     m = n * h * w
@@ -606,6 +627,7 @@ def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
 
 def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentum):
     """Same result as bn_train_stats(y, ...) from the partial rows a conv kernel emitted for y."""
+    _check_dev(stat)
     n, c, h, w = y.shape
     saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
     _lib.check(_lib.load().dg_bn_stats_from_partials(_ptr(stat), stat.shape[0], n * h * w, c, eps, momentum,
@@ -615,6 +637,7 @@ def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentu
 
 
 def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
+    _check_dev(y, allow16=True)
     y = as_nhwc(y)
     n, c, h, w = y.shape
     if _is16(y):                      # bf16 activation storage: bf16 in, bf16 out, nothing else is written
@@ -646,6 +669,7 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
 
 def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None):
     """out_grads=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into those buffers in place."""
+    _check_dev(dz, y, allow16=True)
     dz = as_nhwc(dz)
     y = as_nhwc(y)
     n, c, h, w = y.shape
@@ -709,7 +733,7 @@ def act_fwd(x, act, slope=0.2):
 
 def act_bwd(dy, out, act, slope=0.2):
     """Elementwise; dy is brought to out's memory layout first."""
-    _check_dev(dy, out)
+    _check_dev(dy, out, allow16=True)
     out = _dense(out)
     if dy.stride() != out.stride():
         dyl = _dense_like(out)
@@ -751,6 +775,7 @@ def mse_fwd(x, t, out=None):
 
 
 def mse_bwd(x, t, gout):
+    _check_dev(x, t, gout)
     dx = _dense_like(x)
     _lib.check(_lib.load().dg_mse_bwd(_ptr(x), _ptr(t), x.numel(), _ptr(gout), _ptr(dx), _stream()), "dg_mse_bwd")
     return dx
@@ -803,7 +828,7 @@ def hinge_bwd(x, y, margin, gout):
 
 def fm_fwd(real, fake, out=None):
     """One layer of get_fm_loss; real/fake logical [N,C,H,W] with identical dense layouts."""
-    _check_dev(real, fake)
+    _check_dev(real, fake, allow16=True)
     real, fake = same_layout_pair(real, fake)
     n = real.shape[0]
     j = real.numel() // n

@@ -454,7 +454,7 @@ class DiscoGANTrainer:
         if self.time_comm:
             self.comm_steps["D" if dstep else "G"] += 1
         if bucketed:
-            self._buckets.begin(opt)
+            self._buckets.begin(opt, self.active_ranges(dstep))
         try:
             if self.use_graph and iters >= self._eager_until:       # first cycle (and the first after a resume) runs eagerly
                 out = self._fwd_bwd_graphed(A, B, iters, need_losses)
@@ -464,7 +464,7 @@ class DiscoGANTrainer:
             if bucketed:
                 F_.FINAL_HOOK = None
         if bucketed:
-            self._buckets.finish(self.active_ranges(dstep))
+            self._buckets.finish()
             return out
         # gradients of the stepped side only: one flat message, summed; the /W rides in the Adam kernel
         if self.overlap_comm and dstep and do_step:
@@ -580,9 +580,14 @@ class _GradBuckets:
                 self.of_param[id(p)] = cur
         self.opt = opt
         self.launched = 0
+        self.active = None
 
-    def begin(self, opt):
+    def begin(self, opt, active=None):
+        """``active``: the flat ranges that receive gradients in this step (trainer.active_ranges; None = all).  The same
+        ranges gate the Adam slice of EVERY bucket, whether it is launched early from the backward or flushed afterwards --
+        exactly what the one-message path's ``opt.step(active=...)`` does."""
         assert opt is self.opt
+        self.active = active
         tr = self.tr
         main = torch.cuda.current_stream(tr.device)
         for b in self.buckets:
@@ -601,9 +606,13 @@ class _GradBuckets:
         b = self.of_param.get(id(param))
         if b is None or b["done"]:
             return
+        # the kernels accumulated into the flat gradient view; a .grad replaced during the backward would not be exchanged
+        if param.grad is not param._dg_flat_grad:
+            raise RuntimeError("bucketed exchange: a parameter's .grad was replaced during the backward pass "
+                               "(it must stay the view of the optimiser's flat gradient buffer)")
         b["pending"] -= 1
         if b["pending"] == 0:
-            self._launch(b, torch.cuda.current_stream(self.tr.device), early=True)
+            self._launch(b, torch.cuda.current_stream(self.tr.device), early=True, active=self.active)
 
     def _launch(self, b, producer_stream, early, active=None):
         tr, opt = self.tr, self.opt
@@ -635,13 +644,13 @@ class _GradBuckets:
         if early:
             self.launched += 1
 
-    def finish(self, active):
+    def finish(self):
         """After the backward: flush the buckets that did not report, then make the main stream wait for the updates."""
         tr = self.tr
         main = torch.cuda.current_stream(tr.device)
         for b in self.buckets:
             if not b["done"]:
-                self._launch(b, main, early=False, active=active)
+                self._launch(b, main, early=False, active=self.active)
         opt = tr.optim_gen
         if getattr(opt, "flat_p3t", None) is not None:      # every bucket's planes are written: the transposed weight copy follows
             from . import ops

@@ -244,13 +244,19 @@ int dg_hinge_bwd(const float* x, const float* y, size_t n, float margin, const f
  * other ranks out of band (the host layer uses the c10d TCP store), every rank calls dg_dp_init with it.
  * Collectives are in place, fp32, enqueued on the CALLER's stream (no internal stream, no synchronisation);
  * all-reduce is a SUM -- DDP's division by the world size is folded into dg_adam_step_flat's grad_scale.
- * The communicator handle is the only state the library keeps between calls.  RCCL is dlopen'ed on first use. */
+ * The communicator handle is the only state the library keeps between calls.  RCCL is dlopen'ed on first use.
+ * dg_dp_init is COLLECTIVE (ncclCommInitRank blocks until every rank has entered it): the host layer therefore first
+ * calls dg_dp_ready on every rank -- purely local: binds RCCL, checks that a HIP device is current and that no
+ * communicator exists -- and lets the ranks VOTE on the outcome out of band (dp.guarded_bootstrap: c10d store keys, no
+ * collective) before any rank enters dg_dp_init, which it runs under a deadline (DG_COMM_INIT_TIMEOUT_S). */
+int dg_dp_ready(int* device_out /* the current HIP device ordinal; may be NULL */);
 int dg_dp_unique_id_bytes(void);
 int dg_dp_get_unique_id(void* id_out_host, size_t bytes);
 int dg_dp_init(int rank, int world, const void* unique_id_host, size_t bytes);
 int dg_dp_world_size(void);   /* ranks in the communicator; 0 before dg_dp_init */
 int dg_dp_rank(void);         /* -1 before dg_dp_init */
 int dg_dp_allreduce_sum(float* buf, size_t n, dg_stream_t stream);
+int dg_dp_allreduce_max(float* buf, size_t n, dg_stream_t stream);   /* in place, fp32 MAX (max-over-ranks timings) */
 int dg_dp_broadcast(float* buf, size_t n, int root, dg_stream_t stream);
 int dg_dp_barrier(float* scratch1 /* one device float owned by the caller */, dg_stream_t stream);
 int dg_dp_destroy(void);

@@ -35,6 +35,7 @@ def _worker(rank, world, initfile, outdir):
     try:
         st = O.build_state(image_size=S, seed=1234)                # identical replicas from the seed
         A, B = O.synthetic_batch(N, S, seed=dp.rank_data_seed(rank))
+        xg = dp.ExchangeGroup(dist.group.WORLD)
         res = []
         for it in range(3):
             dstep = O.is_dis_step(it, st.args)
@@ -45,7 +46,7 @@ def _worker(rank, world, initfile, outdir):
             flat = _flat_views(params)                              # .grad = views of one flat buffer
             out = O.forward_losses(st, A, B, it)
             (out.dis_loss if dstep else out.gen_loss).backward()
-            scale, _ = dp.all_reduce_flat(flat, None)
+            scale = xg.all_reduce_sum_(flat)                       # the transport object the GPU trainer uses
             assert scale == 1.0 / world
             flat.mul_(scale)                                        # the GPU path folds this into Adam
             (st.optim_dis if dstep else st.optim_gen).step()
@@ -169,6 +170,121 @@ def test_launcher_command_line():
 
 def test_single_process_is_identity():
     flat = torch.arange(8.0)
-    scale, work = dp.all_reduce_flat(flat.clone(), None)
-    assert scale == 1.0 and work is None
+    xg = dp.ExchangeGroup(None)                                      # no process group: world 1, c10d, nothing moves
+    assert xg.transport == "c10d" and xg.all_reduce_sum_(flat) == 1.0 and torch.equal(flat, torch.arange(8.0))
+    assert dp.host_allgather(2.5) == [2.5]
     assert dp.rank_data_seed(3) == 1003
+
+
+# ---- guarded bootstrap of a communicator whose init is a blocking collective (dp.guarded_bootstrap) -----------------
+# The real init (ncclCommInitRank via dg_dp_init) needs one GPU per rank; what is rehearsed here, over gloo's FileStore with
+# stand-in prepare / init callables, is the protocol around it: the vote before the collective, the deadline inside it,
+# and that every rank leaves non-zero when one of them fails or blocks.
+def _boot_worker(rank, world, initfile, outdir, scenario):
+    import time
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    entered = os.path.join(outdir, f"entered{rank}")
+
+    def prepare():
+        if scenario == "prepare_fails" and rank == 1:
+            raise RuntimeError("cannot load librccl on this rank")
+        return b"\x07" * 128 if rank == 0 else None
+
+    def init(uid):
+        open(entered, "w").write("1")
+        assert uid == b"\x07" * 128
+        if scenario == "init_hangs" and rank == 1:
+            time.sleep(600)                                              # a rank blocked inside the collective
+        if scenario == "init_raises" and rank == 1:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        return "comm"
+
+    try:
+        got = dp.guarded_bootstrap(dp.store_of(None), rank, world, prepare, init, tag=f"t/{scenario}", timeout_s=4.0)
+        open(os.path.join(outdir, f"result{rank}"), "w").write(f"ok {got}")
+        assert dp.host_allgather(10.0 + rank) == [10.0, 11.0]           # the store-based host collective, same run
+    except dp.BootstrapVoteFailed as e:
+        open(os.path.join(outdir, f"result{rank}"), "w").write(f"vote {e}")
+        raise SystemExit(5)
+    except dp._lib.DiscoganHipError as e:
+        open(os.path.join(outdir, f"result{rank}"), "w").write(f"initerr {e}")
+        raise SystemExit(6)
+    dist.destroy_process_group()
+
+
+def _run_boot(scenario):
+    import time
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.time()
+        ps = [ctx.Process(target=_boot_worker, args=(r, W, os.path.join(d, "init"), d, scenario)) for r in range(W)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(60)
+        alive = [p.is_alive() for p in ps]
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+        files = {f: open(os.path.join(d, f)).read() for f in os.listdir(d) if f.startswith(("result", "entered"))}
+        return [p.exitcode for p in ps], alive, files, time.time() - t0
+
+
+@pytest.mark.timeout(120)
+def test_guarded_bootstrap_all_ranks_ready():
+    codes, alive, files, _ = _run_boot("ok")
+    assert codes == [0, 0] and not any(alive)
+    assert files["result0"] == files["result1"] == "ok comm" and "entered0" in files and "entered1" in files
+
+
+@pytest.mark.timeout(120)
+def test_guarded_bootstrap_one_rank_not_ready_nobody_enters_the_collective():
+    codes, alive, files, _ = _run_boot("prepare_fails")
+    assert codes == [5, 5] and not any(alive)                           # the SAME verdict on every rank, non-zero
+    assert "entered0" not in files and "entered1" not in files          # no rank entered the blocking init
+    for r in range(W):
+        assert files[f"result{r}"].startswith("vote") and "rank 1: RuntimeError: cannot load librccl" in files[f"result{r}"]
+
+
+@pytest.mark.timeout(120)
+def test_guarded_bootstrap_blocked_collective_exits_nonzero_within_the_deadline():
+    codes, alive, files, dt = _run_boot("init_hangs")
+    assert not any(alive) and dt < 40                                   # 4 s deadline per phase, not 600 s
+    assert codes == [dp.HANG_EXIT_CODE, dp.HANG_EXIT_CODE]              # blocked rank AND the rank waiting for it
+    assert "result0" not in files and "result1" not in files
+
+
+@pytest.mark.timeout(120)
+def test_guarded_bootstrap_init_error_is_raised_on_every_rank():
+    codes, alive, files, _ = _run_boot("init_raises")
+    assert codes == [6, 6] and not any(alive)
+    for r in range(W):
+        assert "rank 1: RuntimeError: ncclCommInitRank" in files[f"result{r}"]
+
+
+def _capi_vote_worker(rank, world, initfile, outdir):
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        # no GPU in this process: dg_dp_ready fails on every rank -> the vote fails identically everywhere
+        try:
+            dp.ExchangeGroup(dist.group.WORLD, transport="capi")
+            out = "built"
+        except dp.BootstrapVoteFailed as e:
+            out = f"vote {e}"
+        open(os.path.join(outdir, f"r{rank}"), "w").write(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_exchange_group_capi_vote_fails_cleanly_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("needs a process without a HIP device")
+    os.environ["DG_COMM_INIT_TIMEOUT_S"] = "20"
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_capi_vote_worker, args=(W, os.path.join(d, "init"), d), nprocs=W, join=True)
+            r = [open(os.path.join(d, f"r{k}")).read() for k in range(W)]
+    finally:
+        os.environ.pop("DG_COMM_INIT_TIMEOUT_S", None)
+    assert all(x.startswith("vote") and "2 of 2 ranks not ready" in x for x in r), r
