@@ -77,3 +77,70 @@ def test_two_rank_trainer_on_one_gpu_matches_ddp_emulation():
         rtol = 1e-4 if it == 0 else 3e-2          # free-running after the first Adam steps (see test_model_gpu)
         for k, v in ref.items():
             assert abs(got[k] - v) <= rtol * abs(v) + 1e-6, f"iter {it} {k}: {got[k]} vs {v}"
+
+
+# ---- the guarded bootstrap of the library's RCCL communicator on hardware (dp.guarded_bootstrap) -------------------------------
+def _capi_worker(rank, world, initfile, outdir, fail_rank):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["DG_COMM_INIT_TIMEOUT_S"] = "45"
+    if fail_rank is not None:
+        os.environ["DG_COMM_TEST_FAIL_RANK"] = str(fail_rank)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    from discogan_modernized_amd import _lib, dp
+    torch.cuda.set_device(0)
+    try:
+        xg = dp.ExchangeGroup(dist.group.WORLD, transport="capi", device=torch.device("cuda:0"))
+        out = f"built {_lib.load().dg_dp_world_size()}"
+        xg.close()
+    except dp.BootstrapVoteFailed as e:
+        out = f"vote {e}"
+    except _lib.DiscoganHipError as e:
+        out = f"initerr {e}"
+    open(os.path.join(outdir, f"r{rank}"), "w").write(out)
+    assert _lib.load().dg_dp_world_size() == 0 or out.startswith("built")
+    dist.destroy_process_group()
+
+
+def _run_capi(fail_rank):
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        ps = [ctx.Process(target=_capi_worker, args=(r, W, os.path.join(d, "init"), d, fail_rank)) for r in range(W)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(240)
+        alive = [p.is_alive() for p in ps]
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+        return [p.exitcode for p in ps], alive, {f: open(os.path.join(d, f)).read() for f in os.listdir(d) if f.startswith("r")}
+
+
+@pytest.mark.timeout(600)
+def test_capi_bootstrap_vote_on_hardware_one_rank_not_ready():
+    """Two ranks, real library: dg_dp_ready (dlopen RCCL, HIP device check) and dg_dp_get_unique_id run on the GPU box; rank 1
+    then reports "not ready" (test hook).  Both ranks must raise the SAME BootstrapVoteFailed and no rank may have entered
+    ncclCommInitRank (no communicator exists afterwards)."""
+    codes, alive, files = _run_capi(fail_rank=1)
+    assert not any(alive) and codes == [0, 0], (codes, alive, files)
+    for r in range(W):
+        assert files[f"r{r}"].startswith("vote") and "rank 1: DiscoganHipError: DG_COMM_TEST_FAIL_RANK" in files[f"r{r}"], files
+
+
+@pytest.mark.timeout(600)
+def test_capi_bootstrap_two_ranks_sharing_one_gpu_never_hangs():
+    """Two ranks that both own cuda:0 enter the REAL ncclCommInitRank.  RCCL cannot build that communicator (duplicate GPU);
+    whatever it does -- an error on every rank, an error on one rank and a block on the other, or a communicator after all --
+    the bootstrap must end on every rank within the deadline: a result, an init error raised on EVERY rank, or exit code
+    dp.HANG_EXIT_CODE.  A rank still alive after the deadline is the failure this guards against."""
+    from discogan_modernized_amd import dp
+    codes, alive, files = _run_capi(fail_rank=None)
+    print("two ranks on one GPU:", codes, {k: v[:200] for k, v in files.items()})
+    assert not any(alive), f"a rank is still blocked in the bootstrap: {codes} {files}"
+    for r in range(W):
+        ok = codes[r] == dp.HANG_EXIT_CODE or (codes[r] == 0 and files.get(f"r{r}", "").startswith(("built 2", "initerr")))
+        assert ok, (codes, files)
+    if all(c == 0 for c in codes):
+        kinds = {files[f"r{r}"].split()[0] for r in range(W)}
+        assert len(kinds) == 1, f"ranks disagree on the outcome: {files}"

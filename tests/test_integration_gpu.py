@@ -386,3 +386,7 @@ def test_bench_starts_its_own_ranks_gloo_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["steps"] == 6 and d["value"] > 0
     assert d["comm"]["world_size"] == 2 and d["comm"]["allreduce_ms_per_D_step"] > 0 and d["comm"]["allreduce_ms_per_G_step"] > 0
     assert d["config"]["hipgraph"] is True and d["comm"]["allreduce_overlap"] is False   # 64 px: graph replay + exchange behind it
+    # exposed exchange time: the same window with the collectives stubbed, next to the per-collective event sums
+    assert d["comm"]["ms_per_step_exchange_stubbed"] > 0 and d["comm"]["exposed_ms_per_step"] is not None
+    assert abs(d["comm"]["exposed_ms_per_step"] - (d["ms_per_step"] - d["comm"]["ms_per_step_exchange_stubbed"])) < 2e-3
+    assert d["dtype"] == "f32x3" and "three bf16 planes" in d["config"]["workload"]
