@@ -92,6 +92,7 @@ SIGNATURES = {
     "dg_dp_barrier": (_i, [_p, _p]),
     "dg_dp_destroy": (_i, []),
     "dg_u8hwc_to_f32chw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dg_image_prep": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dg_adam_step_flat_bf16": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p, _p]),
     "dg_f32_to_bf16": (_i, [_p, _p, _z, _p]),
     "dg_bn_act_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
@@ -100,12 +101,12 @@ SIGNATURES = {
     "dg_f32_to_bf16x3": (_i, [_p, _p, _z, _z, _p]),
     "dg_adam_step_flat_x3": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p, _z, _p]),
     "dg_conv_x3_planes_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "dg_bn_act_fwd_x3": (_i, [_p, _p, _p, _z, _i, _i, _p, _p, _p, _i, _f, _p]),
-    "dg_bn_act_bwd_x3": (_i, [_p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
+    "dg_bn_act_fwd_x3": (_i, [_p, _p, _p, _z, _i, _i, _i, _p, _p, _p, _i, _f, _p]),
+    "dg_bn_act_bwd_x3": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
     "dg_conv_fwd_x3": (_i, [_p, _l, _p, _l, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_x3_transpose_planes": (_i, [_p, _p, _z, _p, _p, _p, _i, _p]),
-    "dg_conv_dgrad_x3": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "dg_conv_wgrad_x3": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_dgrad_x3": (_i, [_p, _l, _i, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_wgrad_x3": (_i, [_p, _l, _i, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_bn_train_stats_t": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
             const int krow = pq * RP + lane / GR;
             const int gc = (lane % GR) ^ kmswz(krow);
             const int col = m0 + gc * 8;
-            a_ob[i] = col < K ? (krow * K + col) * 2 : OOR;     // pixel rows >= R run off the end of the plane: zeros
+            // pixel-major dy[pixel][K]: pixel rows >= R run off the end of the plane (zeros).  Chunk-major [K / 16][R][16]
+            // (a_cm): a row past R would land in the next chunk, so it is masked in a_voff (a_inv keeps the piece's pixel row)
+            a_ob[i] = col < K ? (p.a_cm ? (((col >> 4) * p.R + krow) * 16 + (col & 15)) * 2 : (krow * K + col) * 2) : OOR;
+            a_inv[i] = krow;
         }
     }
     int b_ob[NPB];
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
             const int soff = ((dyo * Wo + dxo) * K + coff()) * 2;
             return (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1);
         }
+        if (p.a_cm) return (a_ob[i] + dt * (KT * 2) * 16) | -((dt * KT + a_inv[i]) >= p.R ? 1 : 0);
         return a_ob[i] + dt * (KT * 2) * K;
     };
     auto b_voff = [&](int i) -> int {

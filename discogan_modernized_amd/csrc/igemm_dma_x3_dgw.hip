@@ -67,12 +67,25 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     const int l31 = lane & 31, lh = lane >> 5;
 
     // ---- blockIdx -> (pixel tile, ph for NCLS == 2, split) ----------------------------------------------------------
+    // Vertically adjacent pixel tiles share two of their (R + 2) window rows and the ZM workgroups of a tile share the whole
+    // window: workgroups are dealt to the 8 XCDs round robin, so XCD x takes the tiles [x tilesM / 8, (x + 1) tilesM / 8) in
+    // order (the ph workgroups of a tile back to back) and the shared rows are L2 hits instead of a second fabric fetch.
     constexpr int ZM = 4 / NCLS;
     int bid = blockIdx.x;
-    const int tm = bid % p.tilesM;
-    bid /= p.tilesM;
-    const int zph = bid % ZM;
-    const int split = bid / ZM;
+    int tm, zph, split;
+    if ((p.tilesM & 7) == 0) {
+        const int per = p.tilesM >> 3, x = bid & 7;
+        int j = bid >> 3;
+        zph = j % ZM;
+        j /= ZM;
+        tm = x * per + j % per;
+        split = j / per;
+    } else {
+        tm = bid % p.tilesM;
+        bid /= p.tilesM;
+        zph = bid % ZM;
+        split = bid / ZM;
+    }
     const int m0 = tm * 256;
     const int cb = split * p.itPerSplit;                       // chunk range of this split
     const int ce = min(p.nIt, cb + p.itPerSplit);
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     const int n_img = m0 >> lgHW, a0 = (m0 >> lgWo) & (Ho - 1);
     const int WR = (256 / Wo + 2) * WW;                       // window rows
     const int wpieces = (WR + 31) >> 5;
+    const int a_chunk_bytes = (p.N << lgHW) * (KT * 2);        // chunk-major planes: bytes of one 16-channel chunk of all pixels
 
     constexpr int OOR = (int)0x80000000;
     __amdgpu_buffer_rsrc_t rA[3], rB[3];
@@ -106,7 +120,9 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
         const int wr = row / WW, wc = row - wr * WW;
         const int a = a0 - 1 + wr, b = wc - 1;
         const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
-        w_ob[j] = ok ? ((((n_img * Ho + a) * Wo + b) * K) + g * 8) * 2 : OOR;
+        const int pix = (n_img * Ho + a) * Wo + b;
+        // chunk-major planes [K / 16][pixels][16]: a window row of a chunk is 32 contiguous bytes of a contiguous run of pixels
+        w_ob[j] = ok ? (p.a_cm ? (pix * 16 + g * 8) * 2 : (pix * K + g * 8) * 2) : OOR;
     }
     // ---- weight DMA descriptors: tile [16 k][256 columns], column = class-local-index * CW + c; one piece per plane ----
     // piece = k rows 2 w, 2 w + 1; lane L lands in (k row 2 w + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     };
     // plane pl of the window of chunk `c` into window stage `ast`
     auto issue_window = [&](int ast, int pl, int c) {
-        const int coff = c * KT * 2;
+        const int coff = p.a_cm ? c * a_chunk_bytes : c * KT * 2;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (wave + 8 * j < wpieces)                                   // wave-uniform

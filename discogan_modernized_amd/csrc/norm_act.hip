@@ -253,12 +253,19 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
 
 typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
 // TI / TO: element types of y and z.  Z16 (fp32 z only) = 1: also write a bf16 (RNE) shadow of z for the bf16 matrix path;
-// = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart)
+// = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart).  cmM > 0 (= M, the
+// pixel count): the planes are CHUNK-MAJOR [C / 16][M][16] instead of pixel-major [M][C] -- the layout the window input-grad
+// kernel (igemm_dma_x3_dgw.hip) wants: a 16-channel chunk of consecutive pixels is one contiguous run of 32-byte rows.
+__device__ __forceinline__ long bn_plane_index(long idx4, int c, int cvn, long cmM) {
+    if (cmM == 0) return idx4 * 4;
+    const long pix = idx4 / cvn;
+    return ((long)(c >> 4) * cmM + pix) * 16 + (c & 15);
+}
 template <typename TI, typename TO, int Z16>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ y, TO* __restrict__ z, long totalv,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope, __bf16* __restrict__ z16, long pstride) {
+                                                         int act, float slope, __bf16* __restrict__ z16, long pstride, long cmM) {
     constexpr int V = BnV<TI>::V;
     static_assert(BnV<TI>::V == BnV<TO>::V, "same storage type on both sides");
     const int cvn = C / V;
@@ -277,9 +284,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
         if constexpr (Z16 == 3) {
             dg_bf16x4_t h, md, l;
             dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
-            *(dg_bf16x4_t*)(z16 + idx * 4) = h;
-            *(dg_bf16x4_t*)(z16 + pstride + idx * 4) = md;
-            *(dg_bf16x4_t*)(z16 + 2 * pstride + idx * 4) = l;
+            const long pi = bn_plane_index(idx, c, cvn, cmM);
+            *(dg_bf16x4_t*)(z16 + pi) = h;
+            *(dg_bf16x4_t*)(z16 + pstride + pi) = md;
+            *(dg_bf16x4_t*)(z16 + 2 * pstride + pi) = l;
         }
     }
 }
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dy, long totalv, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ coef,
-                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride) {
+                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride, long cmM) {
     constexpr int V = BnV<T>::V;
     const int cvn = C / V;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
@@ -572,9 +580,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if constexpr (D16 == 3) {
             dg_bf16x4_t h, md, l;
             dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
-            *(dg_bf16x4_t*)(dy16 + idx * 4) = h;
-            *(dg_bf16x4_t*)(dy16 + pstride + idx * 4) = md;
-            *(dg_bf16x4_t*)(dy16 + 2 * pstride + idx * 4) = l;
+            const long pi = bn_plane_index(idx, c, cvn, cmM);
+            *(dg_bf16x4_t*)(dy16 + pi) = h;
+            *(dg_bf16x4_t*)(dy16 + pstride + pi) = md;
+            *(dg_bf16x4_t*)(dy16 + 2 * pstride + pi) = l;
         }
     }
 }
@@ -688,9 +697,10 @@ extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C,
 
 template <typename T>
 static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const float* saved, const float* gamma,
-                           const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0) {
+                           const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
+    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 16 == 0), "dg_bn_act_fwd: chunk-major planes need plane operands and C %% 16 == 0 (C=%d)", C);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
     const long totalv = (long)M * C / V;
@@ -704,19 +714,19 @@ static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const floa
     if constexpr (V == 4) {
         if (z16 && pstride > 0) {
             hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride);
+                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride, plane_cm ? (long)M : 0L);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
         if (z16) {
             hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L);
+                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L, 0L);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
     }
     hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L);
+                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L, 0L);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
@@ -730,11 +740,12 @@ extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M,
     return bn_act_fwd_impl<float>(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
 }
 // the same pass, also writing the three bf16 planes of z (plane_elems elements apart, >= M * C, % 8 == 0) for the f32x3 matrix path
-extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int M, int C, const float* saved,
+extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int plane_layout, int M, int C, const float* saved,
                                 const float* gamma, const float* beta, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_fwd_x3: plane_layout 0 (pixel-major) or 1 (16-channel chunk-major)");
     DG_CHECK_ARG(z_planes, "dg_bn_act_fwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_fwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
-    return bn_act_fwd_impl<float>(y, z, z_planes, M, C, saved, gamma, beta, act, slope, stream, (long)plane_elems);
+    return bn_act_fwd_impl<float>(y, z, z_planes, M, C, saved, gamma, beta, act, slope, stream, (long)plane_elems, plane_layout);
 }
 extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C, const float* saved, const float* gamma,
                                const float* beta, int act, float slope, dg_stream_t stream) {
@@ -745,9 +756,10 @@ extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C
 template <typename T>
 static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, int C, const float* saved,
                            const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
-                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0) {
+                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
+    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 16 == 0), "dg_bn_act_bwd: chunk-major planes need plane operands and C %% 16 == 0 (C=%d)", C);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
@@ -766,13 +778,13 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
     if constexpr (V == 4) {
         if (dy16 && pstride > 0) {
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride);
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride, plane_cm ? (long)M : 0L);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
         if (dy16) {
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L);
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L, 0L);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
@@ -783,7 +795,7 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
         return DG_OK;
     }
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L);
+                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L, 0L);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
 }
@@ -798,13 +810,14 @@ extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, vo
     DG_CHECK_ARG(dy_bf16, "dg_bn_act_bwd_bf16: null shadow pointer");
     return bn_act_bwd_impl<float>(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
 }
-extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int M, int C,
+extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,
                                 const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
                                 float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_bwd_x3: plane_layout 0 (pixel-major) or 1 (16-channel chunk-major)");
     DG_CHECK_ARG(dy_planes, "dg_bn_act_bwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_bwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
     return bn_act_bwd_impl<float>(dz, y, dy, dy_planes, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream,
-                                  (long)plane_elems);
+                                  (long)plane_elems, plane_layout);
 }
 extern "C" int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_bf16, int M, int C, const float* saved,
                                const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,

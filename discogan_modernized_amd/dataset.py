@@ -1,0 +1,365 @@
+"""Image-file side of the training path (reference dataset.py:24-73, 76-261; loader use distributed_image_translation.py:203-216,462-463).
+
+The reference decodes with PIL and then does everything else per image on the host -- crop of the edges2* halves, the
+3x3 dilate, ``cv2.resize``, ``/255``, CHW -- and ships float32 batches of the OUTPUT size over PCIe.  Here the host only
+decodes (PIL, worker threads) into pinned uint8 staging buffers of the SOURCE size; the batch crosses PCIe as uint8 on a copy
+stream, double-buffered against the training step, and ONE kernel per domain (csrc/ingest.hip, ``dg_image_prep``) does crop +
+erosion + bilinear resize + normalise + CHW on the device.
+
+  file lists     get_celebA_files / get_edge2photo_files / get_facescrub_files / get_custom_data / get_data -- same names,
+                 arguments, ordering and train / test split rules as dataset.py:76-192 and image_translation.py:83-133
+  domain rule    task_domains(task_name): edges2* -> ('A', 'B'), handbags2shoes -> ('B', 'B'), else (None, None)
+                 (image_translation.py:322-331)
+  read_images    same name / arguments as dataset.py:37; returns the float [n,3,S,S] batch ON THE DEVICE
+  DiscoGANDataset  __len__ / index pairing of dataset.py:194-222 (A_i with B_i, modulo the shorter list); items are decoded
+                 uint8 arrays, batches are made by DeviceLoader
+  DeviceLoader   iterable of (A, B) device batches for one epoch: index order from the caller (independent shuffles,
+                 dataset.py:24-35, or the DistributedSampler shard, dp.distributed_indices), decode in a thread pool, pinned
+                 double buffer, H2D on a copy stream, device preparation; the next batch is staged while the current one trains
+  shards         write_shard / ShardSource: pre-decoded uint8 [n,H,W,3] .npy files, memory-mapped (no decode at train time)
+
+There is no CPU fallback: batches are produced by the HIP kernel or not at all.
+"""
+from __future__ import annotations
+
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# dataset roots, adjustable like the reference's module-level paths (dataset.py:14-22)
+dataset_path = Path("./datasets")
+celebA_path = dataset_path / "celebA"
+handbag_path = dataset_path / "edges2handbags"
+shoe_path = dataset_path / "edges2shoes"
+facescrub_path = dataset_path / "facescrub"
+
+IMAGE_EXTS = ("*.jpg", "*.png")
+
+
+# ---- file lists -------------------------------------------------------------------------------------------------------
+def read_attr_file(attr_path, image_dir):
+    """CelebA ``list_attr_celeba.txt`` (line 0: count, line 1: attribute names, then ``file v1 v2 ...``) ->
+    (paths, {attribute: list of '1' / '-1' strings}); dataset.py:75-86 builds a DataFrame of the same columns."""
+    with open(attr_path, "r") as f:
+        lines = [ln.strip() for ln in f]
+    names = lines[1].split()
+    paths, cols = [], {n: [] for n in names}
+    for ln in lines[2:]:
+        if not ln:
+            continue
+        parts = ln.split()
+        paths.append(os.path.join(image_dir, parts[0]))
+        for n, v in zip(names, parts[1:]):
+            cols[n].append(v)
+    return paths, cols
+
+
+def get_celebA_files(style_A, style_B, constraint, constraint_type, test=False, n_test=200):
+    """dataset.py:88-117: images having ``style_A`` vs images having ``style_B`` (or lacking ``style_A``), optionally
+    restricted to ``constraint == constraint_type``; the last ``n_test`` of each list are the test split."""
+    paths, cols = read_attr_file(os.path.join(celebA_path, "list_attr_celeba.txt"), os.path.join(celebA_path, "img_align_celeba"))
+    keep = [True] * len(paths) if not constraint else [v == constraint_type for v in cols[constraint]]
+    a = [p for p, k, v in zip(paths, keep, cols[style_A]) if k and v == "1"]
+    if style_B:
+        b = [p for p, k, v in zip(paths, keep, cols[style_B]) if k and v == "1"]
+    else:
+        b = [p for p, k, v in zip(paths, keep, cols[style_A]) if k and v == "-1"]
+    a, b = np.array(a), np.array(b)
+    return (a[-n_test:], b[-n_test:]) if test else (a[:-n_test], b[:-n_test])
+
+
+def get_edge2photo_files(item="edges2shoes", test=False):
+    """dataset.py:119-146: every ``*.jpg`` of ``<root>/train`` (or ``test``), sorted; BOTH domains are the same file list
+    (each file holds the edge map in its left half and the photo in its right half)."""
+    roots = {"edges2shoes": shoe_path, "edges2handbags": handbag_path}
+    if item not in roots:
+        raise ValueError(f"unsupported item: {item}")
+    path = Path(roots[item]) / ("test" if test else "train")
+    if not path.exists():
+        raise FileNotFoundError(f"no such directory: {path}")
+    files = [str(f) for f in sorted(path.glob("*.jpg"))]
+    if not files:
+        raise ValueError(f"no image files under {path}")
+    return files, files
+
+
+def get_facescrub_files(test=False, n_test=200):
+    """dataset.py:148-173: all jpg / png below the facescrub root, sorted; 'actors' in the path = domain A, 'actresses' = B."""
+    if not Path(facescrub_path).exists():
+        raise FileNotFoundError(f"no such directory: {facescrub_path}")
+    every = sorted(str(p) for ext in IMAGE_EXTS for p in Path(facescrub_path).glob(f"**/{ext}"))
+    if not every:
+        raise ValueError(f"no image files under {facescrub_path}")
+    male = [p for p in every if "actors" in p.lower()]
+    female = [p for p in every if "actresses" in p.lower()]
+    return (male[-n_test:], female[-n_test:]) if test else (male[:-n_test], female[:-n_test])
+
+
+def get_custom_data(item_a="tops", item_b="hanbok", test=False, image_size=512):
+    """dataset.py:175-192: ``<root>/custom/<item>/{train,test}/*.jpg|*.png`` for both items (jpg first, directory order)."""
+    split = "test" if test else "train"
+    out = []
+    for item in (item_a, item_b):
+        d = Path(dataset_path) / "custom" / item / split
+        out.append([str(f) for ext in IMAGE_EXTS for f in d.glob(ext)])
+    if not out[0] or not out[1]:
+        raise ValueError(f"no dataset under {Path(dataset_path) / 'custom'} for {item_a} / {item_b} ({split})")
+    return np.array(out[0]), np.array(out[1])
+
+
+def get_data(args):
+    """(data_A, data_B, test_A, test_B) file lists for ``args.task_name`` (image_translation.py:83-133)."""
+    t = args.task_name
+    if t == "facescrub":
+        tr, te = get_facescrub_files(False, args.n_test), get_facescrub_files(True, args.n_test)
+    elif t == "celebA":
+        kw = dict(style_A=args.style_A, style_B=args.style_B, constraint=args.constraint, constraint_type=args.constraint_type, n_test=args.n_test)
+        tr, te = get_celebA_files(test=False, **kw), get_celebA_files(test=True, **kw)
+    elif t in ("edges2shoes", "edges2handbags"):
+        tr, te = get_edge2photo_files(t, False), get_edge2photo_files(t, True)
+    elif t == "handbags2shoes":
+        ha, hb = get_edge2photo_files("edges2handbags", False), get_edge2photo_files("edges2shoes", False)
+        ta, tb = get_edge2photo_files("edges2handbags", True), get_edge2photo_files("edges2shoes", True)
+        tr = (np.hstack(ha), np.hstack(hb))
+        te = (np.hstack(ta), np.hstack(tb))
+    elif t in ("tops2hanbok", "hanbok2tops"):
+        ia, ib = ("tops", "hanbok") if t == "tops2hanbok" else ("hanbok", "tops")
+        tr, te = get_custom_data(ia, ib, False, args.image_size), get_custom_data(ia, ib, True, args.image_size)
+    else:
+        raise ValueError(f"unknown task_name {t}")
+    return tr[0], tr[1], te[0], te[1]
+
+
+def task_domains(task_name):
+    """Domain processing of the two sides (image_translation.py:322-331)."""
+    if task_name.startswith("edges2"):
+        return "A", "B"
+    if task_name in ("handbags2shoes", "shoes2handbags"):
+        return "B", "B"
+    return None, None
+
+
+def shuffle_data(da, db, rng=None):
+    """Independent shuffles of the two lists (dataset.py:24-35; the reference uses the global numpy RNG)."""
+    rng = rng or np.random
+    ia, ib = np.arange(len(da)), np.arange(len(db))
+    rng.shuffle(ia)
+    rng.shuffle(ib)
+    return np.array(da)[ia], np.array(db)[ib]
+
+
+# ---- decode + device preparation -----------------------------------------------------------------------------------------
+def decode_rgb(path):
+    """``np.array(Image.open(fn).convert('RGB'))`` (dataset.py:44,49): uint8 [H, W, 3]."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+def _crop_of(domain, width):
+    """(first column, crop width, erode, arithmetic mode) of a domain rule for ``width``-pixel rows."""
+    if domain == "A":
+        if width < 256:
+            raise ValueError(f"domain 'A' takes the left 256 columns of an edges2* pair; the image is {width} wide")
+        return 0, 256, 1, 0          # eroded image is float64 in the reference: unrounded float resize
+    if domain == "B":
+        if width <= 256:
+            raise ValueError(f"domain 'B' takes the columns from 256 on; the image is {width} wide")
+        return 256, width - 256, 0, 1
+    if domain is None:
+        return 0, width, 0, 1        # uint8 image: cv2's 8-bit fixed-point resize
+    raise ValueError(f"domain must be 'A', 'B' or None, got {domain!r}")
+
+
+def prepare_batch(src_u8, domain, image_size, out=None):
+    """Device batch uint8 [n, H, W, 3] -> float32 [n, 3, S, S] through ``dg_image_prep`` on the current stream."""
+    if not (src_u8.is_cuda and src_u8.dtype == torch.uint8 and src_u8.dim() == 4 and src_u8.shape[3] == 3 and src_u8.is_contiguous()):
+        raise _lib.DiscoganHipError("prepare_batch needs a contiguous uint8 HIP tensor of shape [n, H, W, 3] (no CPU fallback)")
+    n, h, w, _ = src_u8.shape
+    x0, cw, erode, mode = _crop_of(domain, w)
+    if out is None:
+        out = torch.empty((n, 3, image_size, image_size), device=src_u8.device, dtype=torch.float32)
+    _lib.check(_lib.load().dg_image_prep(src_u8.data_ptr(), out.data_ptr(), n, h, w, x0, cw, erode, mode, image_size,
+                                         torch.cuda.current_stream().cuda_stream), "dg_image_prep")
+    return out
+
+
+def read_images(filenames, domain=None, image_size=64, device="cuda"):
+    """dataset.py:37-73 with the work after the decode on the device: returns float32 [n, 3, S, S] on ``device``.
+    Unreadable files are skipped with a message, like the reference; images of different sizes are prepared one launch each."""
+    imgs = []
+    for fn in filenames:
+        try:
+            imgs.append(decode_rgb(fn))
+        except Exception as e:      # noqa: BLE001
+            print(f"image load failed: {fn}: {e}")
+    if not imgs:
+        raise ValueError("no valid images")
+    return _prepare_list(imgs, domain, image_size, torch.device(device))
+
+
+def _prepare_list(imgs, domain, image_size, device):
+    out = torch.empty((len(imgs), 3, image_size, image_size), device=device, dtype=torch.float32)
+    by_shape = {}
+    for i, im in enumerate(imgs):
+        by_shape.setdefault(im.shape, []).append(i)
+    for shape, idx in by_shape.items():
+        stack = torch.from_numpy(np.stack([imgs[i] for i in idx])).to(device)
+        res = prepare_batch(stack, domain, image_size)
+        if len(by_shape) == 1:
+            return res
+        out[torch.tensor(idx, device=device)] = res
+    return out
+
+
+class DiscoGANDataset:
+    """Index pairing of dataset.py:194-222: item i = (A[i % len(A)], B[i % len(B)]), length = the shorter list.  Items are the
+    DECODED uint8 arrays; resize / normalise happen per batch on the device (DeviceLoader)."""
+
+    def __init__(self, domain_A_paths, domain_B_paths, domain_A_type=None, domain_B_type=None, image_size=64, transform=None):
+        self.domain_A_paths = list(domain_A_paths)
+        self.domain_B_paths = list(domain_B_paths)
+        self.domain_A_type, self.domain_B_type = domain_A_type, domain_B_type
+        self.image_size = image_size
+        self.transform = transform           # applied to the prepared device batch by DeviceLoader (dataset.py:233-236)
+        self.length = min(len(self.domain_A_paths), len(self.domain_B_paths))
+
+    def __len__(self):
+        return self.length
+
+    def paths(self, index):
+        return self.domain_A_paths[index % len(self.domain_A_paths)], self.domain_B_paths[index % len(self.domain_B_paths)]
+
+    def __getitem__(self, index):
+        a, b = self.paths(index)
+        return decode_rgb(a), decode_rgb(b)
+
+
+# ---- pre-decoded shards ------------------------------------------------------------------------------------------------
+def write_shard(filenames, out_path, workers=8):
+    """Decode once, keep the rows: uint8 [n, H, W, 3] as a .npy file (all images must share one size)."""
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        imgs = list(ex.map(decode_rgb, filenames))
+    if len({im.shape for im in imgs}) != 1:
+        raise ValueError("a shard holds images of ONE size; got " + ", ".join(sorted({str(im.shape) for im in imgs})))
+    np.save(out_path, np.stack(imgs))
+    return out_path
+
+
+class ShardSource:
+    """Memory-mapped uint8 [n, H, W, 3] shard(s): ``fetch(i, dst)`` copies image i into a (pinned) staging row."""
+
+    def __init__(self, paths):
+        self.arrays = [np.load(p, mmap_mode="r") for p in ([paths] if isinstance(paths, (str, os.PathLike)) else paths)]
+        shapes = {a.shape[1:] for a in self.arrays}
+        if len(shapes) != 1 or any(a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3 for a in self.arrays):
+            raise ValueError("shards must be uint8 [n, H, W, 3] arrays of one image size")
+        self.shape = next(iter(shapes))
+        self.offsets = np.cumsum([0] + [len(a) for a in self.arrays])
+
+    def __len__(self):
+        return int(self.offsets[-1])
+
+    def fetch(self, i, dst):
+        k = int(np.searchsorted(self.offsets, i, side="right") - 1)
+        dst[...] = self.arrays[k][i - self.offsets[k]]
+
+
+class FileSource:
+    """Image files decoded on demand (PIL); every image must have the size of the first one (edges2*: 256 x 512, celebA: 218 x 178)."""
+
+    def __init__(self, paths):
+        self.paths = list(paths)
+        self.shape = decode_rgb(self.paths[0]).shape
+
+    def __len__(self):
+        return len(self.paths)
+
+    def fetch(self, i, dst):
+        im = decode_rgb(self.paths[i])
+        if im.shape != self.shape:
+            raise ValueError(f"{self.paths[i]}: size {im.shape} differs from the dataset's {self.shape}; use read_images for mixed sizes")
+        dst[...] = im
+
+
+class DeviceLoader:
+    """One epoch of (A, B) float device batches from two sources (FileSource / ShardSource), given the epoch's index batches.
+
+    Stage k+1 (decode / gather into pinned uint8 memory by a thread pool, H2D on the copy stream, dg_image_prep on the copy
+    stream) runs while the caller trains on stage k; two staging slots per domain.  The consumer's stream waits on the
+    slot's event before it reads the batch, and the copy stream waits on the consumer's release event before it overwrites
+    the slot's tensors (reference: DataLoader(num_workers=4, pin_memory=True) + ``.to(device)``,
+    distributed_image_translation.py:209-216,462-463)."""
+
+    def __init__(self, source_A, source_B, domains, image_size, batches, device="cuda", workers=4, transform=None):
+        self.src = (source_A, source_B)
+        self.domains = tuple(domains)
+        self.S = image_size
+        self.batches = [(np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)) for a, b in batches]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DiscoganHipError("DeviceLoader needs a HIP device (no CPU fallback)")
+        self.transform = transform
+        self.bmax = max((max(len(a), len(b)) for a, b in self.batches), default=0)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = []
+        for _ in range(2):
+            slot = dict(ready=None, released=None, out=[None, None])
+            slot["pinned"] = [torch.empty((self.bmax,) + tuple(s.shape), dtype=torch.uint8).pin_memory() for s in self.src]
+            slot["dev_u8"] = [torch.empty((self.bmax,) + tuple(s.shape), dtype=torch.uint8, device=self.device) for s in self.src]
+            slot["dev_f32"] = [torch.empty((self.bmax, 3, self.S, self.S), dtype=torch.float32, device=self.device) for _ in self.src]
+            self.slots.append(slot)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _stage(self, k):
+        slot = self.slots[k % 2]
+        if slot["ready"] is not None:
+            slot["ready"].synchronize()                  # the slot's previous H2D copy has left the pinned rows (host-side wait)
+        torch.cuda.set_device(self.device)               # (worker thread: the current device is per thread)
+        futs = []
+        for d in range(2):
+            idx = self.batches[k][d]
+            rows = slot["pinned"][d].numpy()
+            futs += [self.pool.submit(self.src[d].fetch, int(i), rows[j]) for j, i in enumerate(idx)]
+        for f in futs:
+            f.result()                                   # decode / gather finished: the pinned rows are complete
+        with torch.cuda.stream(self.copy_stream):
+            if slot["released"] is not None:             # the consumer of this slot's previous batch has finished reading
+                self.copy_stream.wait_event(slot["released"])
+            for d in range(2):
+                n = len(self.batches[k][d])
+                slot["dev_u8"][d][:n].copy_(slot["pinned"][d][:n], non_blocking=True)
+                out = prepare_batch(slot["dev_u8"][d][:n], self.domains[d], self.S, out=slot["dev_f32"][d][:n])
+                slot["out"][d] = self.transform(out) if self.transform else out
+            slot["ready"] = torch.cuda.Event()
+            slot["ready"].record(self.copy_stream)
+
+    def __iter__(self):
+        if not self.batches:
+            return
+        stager = None
+        self._stage(0)
+        for k in range(len(self.batches)):
+            slot = self.slots[k % 2]
+            if k + 1 < len(self.batches):                # stage the next batch in the background while this one trains
+                stager = threading.Thread(target=self._stage, args=(k + 1,), daemon=True)
+                stager.start()
+            torch.cuda.current_stream(self.device).wait_event(slot["ready"])
+            yield slot["out"][0], slot["out"][1]
+            slot["released"] = torch.cuda.Event()
+            slot["released"].record(torch.cuda.current_stream(self.device))
+            if stager is not None:
+                stager.join()
+                stager = None
+
+    def close(self):
+        self.pool.shutdown(wait=True)

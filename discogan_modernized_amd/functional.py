@@ -231,7 +231,9 @@ class BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope,
-                partials=None):
+                partials=None, z_cm=False, dy_cm=False):
+        """z_cm / dy_cm (f32x3 plane path, ops.X3_CM): the plane triple of z / of this layer's dy will be read by a window
+        input-grad kernel -> written chunk-major (model.py decides from the neighbouring convolutions)."""
         y = ops.as_nhwc(y)
         if training and partials is not None and partials.numel() > 0:
             # statistics came out of the producing conv kernel's epilogue: no extra pass over y
@@ -240,9 +242,10 @@ class BatchNormActFn(Function):
             saved = ops.bn_train_stats(y, running_mean, running_var, nbt, eps, momentum)
         else:
             saved = torch.stack([running_mean, torch.rsqrt(running_var + eps)])
-        z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope)
+        z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope, planes_cm=z_cm)
         ctx.save_for_backward(y, saved, gamma, beta)
         ctx.cfg = (act, slope, training)
+        ctx.dy_cm = bool(dy_cm)
         ctx.prefs = (gamma, beta)
         ctx.final = FINAL_PASS
         return z
@@ -256,12 +259,12 @@ class BatchNormActFn(Function):
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         fg, fb = _flat_grad_of(ctx.prefs[0]), _flat_grad_of(ctx.prefs[1])
         if need_p and fg is not None and fb is not None:
-            dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb))
+            dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb), planes_cm=ctx.dy_cm)
             _final(ctx.final, ctx.prefs[0], ctx.prefs[1])
-            return (dy,) + (None,) * 11
-        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p)
+            return (dy,) + (None,) * 13
+        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p, planes_cm=ctx.dy_cm)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 class ActFn(Function):

@@ -6,11 +6,15 @@ Same flags and defaults (``--task_name --model_arch --image_size --batch_size --
 names (``gen_A_{iters}.pth`` ... ``*_final.pth``, :420-432).  The training loop dispatches into the
 HIP kernels through ``DiscoGANTrainer``.
 
-Image-file decoding (dataset.py's PIL/cv2 code) is outside the hot path: batches come from ``--data_A/--data_B``
-tensor files -- ``torch.save``d float tensors [n,3,S,S] in [0,1], or uint8 tensors [n,S,S,3] of decoded image rows,
-which stay uint8 in HBM (1 B/channel over PCIe) and are normalised / re-laid-out per batch on the device
-(dg_u8hwc_to_f32chw = dataset.py:65-66) -- or, by default, from synthetic uniform tensors (``--synthetic_size``
-images per domain), which is what the benchmark metric is defined on.
+Data sources (``--data_source``):
+  files      the reference's own layout under ``--data_root`` (default ./datasets; dataset.py:14-22): file lists per task
+             (dataset.get_data), PIL decode in worker threads, uint8 over PCIe on a copy stream, crop / erosion / resize /
+             normalise on the device (dataset.DeviceLoader + dg_image_prep), double-buffered against the training step
+  shards     ``--shard_A/--shard_B``: pre-decoded uint8 [n,H,W,3] .npy files (dataset.write_shard), memory-mapped, same device path
+  tensors    ``--data_A/--data_B``: ``torch.save``d float tensors [n,3,S,S] in [0,1], or uint8 tensors [n,S,S,3] of decoded image
+             rows that stay uint8 in HBM and are normalised / re-laid-out per batch on the device (dg_u8hwc_to_f32chw)
+  synthetic  uniform tensors (``--synthetic_size`` images per domain): what the benchmark metric is defined on
+  auto       tensors if --data_A/--data_B are given, shards if --shard_A/--shard_B, files if the task's directory exists, else synthetic
 
 Batch order.  Single process: A and B are shuffled independently every epoch (shuffle_data, dataset.py:24-35),
 ``data_size // batch_size`` batches.  Data parallel: the ``DistributedSampler`` contract of
@@ -64,6 +68,11 @@ def build_parser(description="HIP/MI355X implementation of the DiscoGAN training
     p.add_argument("--data_A", type=str, default=None, help="torch.save'd float tensor [n,3,S,S] for domain A")
     p.add_argument("--data_B", type=str, default=None, help="torch.save'd float tensor [n,3,S,S] for domain B")
     p.add_argument("--synthetic_size", type=int, default=1024, help="images per domain when no data files are given")
+    p.add_argument("--data_source", type=str, default="auto", choices=["auto", "files", "shards", "tensors", "synthetic"])
+    p.add_argument("--data_root", type=str, default=None, help="root of the reference's dataset layout (dataset.py:14-22; default ./datasets)")
+    p.add_argument("--shard_A", type=str, nargs="*", default=None, help="pre-decoded uint8 [n,H,W,3] .npy shard(s) for domain A")
+    p.add_argument("--shard_B", type=str, nargs="*", default=None, help="pre-decoded uint8 [n,H,W,3] .npy shard(s) for domain B")
+    p.add_argument("--loader_workers", type=int, default=4, help="decode threads of the device loader (reference: num_workers=4)")
     p.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0 = all epochs)")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--no_graph", action="store_true", help="dispatch every kernel from Python (no hipGraph replay)")
@@ -103,6 +112,68 @@ def load_domains(args, device, rank=0, world_size=1):
         A = torch.rand(args.synthetic_size, 3, args.image_size, args.image_size, generator=g)
         B = torch.rand(args.synthetic_size, 3, args.image_size, args.image_size, generator=g)
     return A.to(device), B.to(device)
+
+
+class _ResidentData:
+    """Both domains resident in HBM (tensor files / synthetic): a batch is an index_select (+ the uint8 ingest kernel)."""
+
+    def __init__(self, A, B):
+        self.A, self.B = A, B
+        self.size = min(len(A), len(B))
+
+    def epoch(self, batches, start=0):
+        for ia, ib in batches[start:]:
+            yield take_batch(self.A, ia), take_batch(self.B, ib)
+
+
+class _StreamedData:
+    """Image files or pre-decoded shards: dataset.DeviceLoader stages the next batch while the current one trains."""
+
+    def __init__(self, src_A, src_B, domains, image_size, device, workers):
+        self.src, self.domains, self.S, self.device, self.workers = (src_A, src_B), domains, image_size, device, workers
+        self.size = min(len(src_A), len(src_B))
+
+    def epoch(self, batches, start=0):
+        from . import dataset as ds
+        loader = ds.DeviceLoader(self.src[0], self.src[1], self.domains, self.S,
+                                 [(a.cpu().numpy(), b.cpu().numpy()) for a, b in batches[start:]], device=self.device, workers=self.workers)
+        try:
+            yield from loader
+        finally:
+            loader.close()
+
+
+def open_data(args, device, rank=0, world_size=1):
+    """The training data behind one interface (``.size``, ``.epoch(index batches, start)``), chosen by --data_source."""
+    from . import dataset as ds
+    src = getattr(args, "data_source", "auto")
+    if getattr(args, "data_root", None):
+        root = ds.Path(args.data_root)
+        ds.dataset_path, ds.celebA_path, ds.handbag_path = root, root / "celebA", root / "edges2handbags"
+        ds.shoe_path, ds.facescrub_path = root / "edges2shoes", root / "facescrub"
+    if src == "auto":
+        if args.data_A and args.data_B:
+            src = "tensors"
+        elif getattr(args, "shard_A", None) and getattr(args, "shard_B", None):
+            src = "shards"
+        else:
+            try:
+                ds.get_data(args)
+                src = "files"
+            except (FileNotFoundError, ValueError, KeyError, TypeError):
+                src = "synthetic"
+    domains = ds.task_domains(args.task_name)
+    workers = getattr(args, "loader_workers", 4)
+    if src == "files":
+        data_A, data_B, _, _ = ds.get_data(args)
+        return _StreamedData(ds.FileSource(data_A), ds.FileSource(data_B), domains, args.image_size, device, workers), src
+    if src == "shards":
+        return _StreamedData(ds.ShardSource(args.shard_A), ds.ShardSource(args.shard_B), domains, args.image_size, device, workers), src
+    if src == "tensors" and not (args.data_A and args.data_B):
+        raise ValueError("--data_source tensors needs --data_A and --data_B")
+    if src == "synthetic":
+        args = argparse.Namespace(**{**vars(args), "data_A": None, "data_B": None})
+    return _ResidentData(*load_domains(args, device, rank, world_size)), src
 
 
 def take_batch(data, idx):
@@ -171,8 +242,10 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
                                   process_group=process_group, use_graph=not args.no_graph,
                                   mfma_dtype=getattr(args, "mfma_dtype", "f32"), act_dtype=getattr(args, "act_dtype", "f32"),
                                   comm=getattr(args, "comm", "auto"))
-    data_A, data_B = load_domains(args, device, rank, world_size)
-    data_size = min(len(data_A), len(data_B))
+    data, data_kind = open_data(args, device, rank, world_size)
+    data_size = data.size
+    if is_main:
+        print(f"data source: {data_kind} ({data_size} images per domain)", flush=True)
     n_batches = batches_per_epoch(args, data_size, world_size)
     if n_batches < 1:
         raise ValueError(f"batch_size {args.batch_size} leaves no full batch in {data_size} images on {world_size} rank(s)")
@@ -205,9 +278,8 @@ def train(args, trainer=None, rank=0, world_size=1, is_main=True, process_group=
     done = False
     for epoch in range(start_epoch, args.epochs):
         batches = epoch_batches(args, epoch, data_size, rank, world_size, gperm, device)
-        for i in range(start_batch if epoch == start_epoch else 0, len(batches)):
-            A = take_batch(data_A, batches[i][0])
-            B = take_batch(data_B, batches[i][1])
+        first = start_batch if epoch == start_epoch else 0
+        for i, (A, B) in enumerate(data.epoch(batches, first), start=first):
             logging = iters % args.log_interval == 0
             out = trainer.train_iteration(A, B, iters, need_losses=logging or not lazy)
             if is_main and logging:

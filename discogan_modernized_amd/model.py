@@ -136,12 +136,12 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2, partials=None):
+    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2, partials=None, z_cm=False, dy_cm=False):
         if self.training and y.shape[0] * y.shape[2] * y.shape[3] <= 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
         return F.BatchNormActFn.apply(y, self.weight, self.bias, self.running_mean, self.running_var,
                                       self.num_batches_tracked, self.training, self.eps, self.momentum, fused_act, slope,
-                                      partials)
+                                      partials, z_cm, dy_cm)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine=True, track_running_stats=True"
@@ -179,6 +179,24 @@ class Sigmoid(_Act):
         super().__init__(0.0, False)
 
 
+def _plane_hints(conv, x, nxt):
+    """(z_cm, dy_cm) for the BatchNorm behind ``conv`` on the f32x3 plane path (ops.X3_CM): does a window input-grad kernel read
+      * dy of this group -- ``conv`` is a stride-2 Conv2d whose input-grad runs on the window kernel (<= 128 input channels);
+      * z of this group -- the next layer ``nxt`` is a stride-2 ConvTranspose2d whose forward does (<= 128 output channels)?"""
+    if not (ops.X3 and ops.X3_CM):
+        return False, False
+    n, _, h, w = x.shape
+    dy_cm = z_cm = False
+    if isinstance(conv, Conv2d) and conv.stride == 2 and conv.in_channels != 3:
+        dy_cm = ops.x3_window_dgrad(n, h, w, conv.in_channels, conv.out_channels)
+    if isinstance(nxt, ConvTranspose2d) and nxt.stride == 2 and nxt.out_channels != 3:
+        # z = this group's output [n, nxt.in_channels, ho, wo]; the transposed conv's forward is the input-grad of a
+        # Conv2d(nxt.out_channels -> nxt.in_channels) on a [2 ho, 2 wo] input
+        ho, wo = (h // 2, w // 2) if isinstance(conv, Conv2d) and conv.stride == 2 else ((2 * h, 2 * w) if conv.stride == 2 else (4, 4))
+        z_cm = ops.x3_window_dgrad(n, 2 * ho, 2 * wo, nxt.out_channels, nxt.in_channels)
+    return z_cm, dy_cm
+
+
 def drain(gen):
     """Run a ``*_steps`` generator to completion and return its value."""
     try:
@@ -208,9 +226,11 @@ def _run_fused_steps(layers, x):
             y, st = conv(x, want_stats=FUSE_BN_STATS)       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
+            nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
+            z_cm, dy_cm = _plane_hints(conv, x, nxt)
             y = conv(x)
             yield
-            x = bn(y, act, slope)
+            x = bn(y, act, slope, None, z_cm, dy_cm)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
             x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
         elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
@@ -256,9 +276,10 @@ class Discriminator(_FlatGradMixin, nn.Module):
                 y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
+                _, dy_cm = _plane_hints(conv, h, None)
                 y = conv(h)
                 yield
-                h = bn(y, ops.ACT_LEAKY, relu.negative_slope)
+                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, None, False, dy_cm)
             feats.append(h)
             yield
         out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))

@@ -274,6 +274,11 @@ def _bf16_ok(op, n, h, wd, c, k, stride, pad):
 #   activations: side table like the bf16 shadows; filled by the producers (BatchNorm kernels) or, for a tensor nobody has
 #                split yet, by dg_f32_to_bf16x3 at its first use (the triple then serves the forward AND the weight gradient)
 X3 = False
+# X3_CM: the BatchNorm kernels write the plane triples that a WINDOW input-grad kernel will read (dy of the conv layers with
+# <= 128 input channels, the input of the transposed convs with <= 128 output channels) 16-channel CHUNK-MAJOR
+# ([C/16][pixels][16], include/discogan_hip.h "plane_layout"): a window row of a chunk is then one contiguous run instead of 32
+# bytes of every pixel row.  Bit-identical results; DG_X3_CM=0 keeps every triple pixel-major (A/B).
+X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
 _PLANE_TAB = {}
 
 
@@ -281,8 +286,8 @@ def planes_clear():
     _PLANE_TAB.clear()
 
 
-def planes_put(t, t3):
-    _PLANE_TAB[t.data_ptr()] = (t, t3)
+def planes_put(t, t3, cm=False):
+    _PLANE_TAB[t.data_ptr()] = (t, t3, bool(cm))
 
 
 def f32_to_bf16x3(x, out3):
@@ -292,17 +297,29 @@ def f32_to_bf16x3(x, out3):
     return out3
 
 
-def planes_of(t):
-    """(plane-0 address, plane distance in bytes) of an fp32 activation / gradient tensor; splits it on first use."""
+def planes_of(t, allow_cm=False):
+    """(plane-0 address, plane distance in bytes, chunk-major?) of an fp32 activation / gradient tensor; splits it on first
+    use.  A chunk-major triple (written by a BatchNorm kernel for a window input-grad kernel) is only handed to callers that
+    can read it (allow_cm); anybody else gets a pixel-major split of the fp32 tensor."""
     e = _PLANE_TAB.get(t.data_ptr())
-    if e is None or e[0].shape != t.shape or e[0].stride() != t.stride():
+    if e is None or e[0].shape != t.shape or e[0].stride() != t.stride() or (e[2] and not allow_cm):
         t3 = torch.empty((3, t.numel()), device=t.device, dtype=torch.bfloat16)
         with _hbm("x3_split", 10.0 * t.numel()):
             f32_to_bf16x3(t, t3)
-        planes_put(t, t3)
-    else:
-        t3 = e[1]
-    return t3.data_ptr(), t3.stride(0) * 2
+        if e is None or not e[2]:
+            planes_put(t, t3)
+        return t3.data_ptr(), t3.stride(0) * 2, 0
+    return e[1].data_ptr(), e[1].stride(0) * 2, int(e[2])
+
+
+def x3_window_dgrad(n, h, wd, c, k):
+    """Will the input-grad of Conv2d(c, k, 4, 2, 1) on an [n, c, h, wd] input (= the forward of the transposed conv with the same
+    weight) run on the window kernel AND its weight gradient on the plane kernel?  Then the producer of the gradient operand
+    writes chunk-major planes (X3_CM)."""
+    if not (X3 and X3_CM) or k % 16 != 0:
+        return False
+    L = _lib.load()
+    return L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, 2, 1) == 2 and L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) == 1
 
 
 def x3_transpose_table(convs):
@@ -343,7 +360,7 @@ def weight_planes(w, transposed=False):
 
 
 def _x3_ok(op, n, h, wd, c, k, stride, pad):
-    return X3 and k > 1 and _lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad) == 1
+    return X3 and k > 1 and _lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad) >= 1
 
 
 # ---- interior convolutions ------------------------------------------------------------------------------
@@ -375,7 +392,7 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
     if rows == 0 and _x3_ok(0, n, h, wd, c, k, stride, pad):
-        xp, xd = planes_of(x)
+        xp, xd, _ = planes_of(x)
         wp, wdist, wt = weight_planes(w, transposed=True)
         y = empty_nhwc(n, k, ho, wo, x.device)
         with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
@@ -429,11 +446,11 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0
     if rows == 0 and _x3_ok(1, n, h, wd, c, k, stride, pad):
-        dp, dd = planes_of(dy)
+        dp, dd, dcm = planes_of(dy, allow_cm=L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, stride, pad) == 2)
         wp, wdist, _ = weight_planes(w)
         dx = empty_nhwc(n, c, h, wd, dy.device)
         with _prof("conv_dgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-            _lib.check(L.dg_conv_dgrad_x3(dp, dd, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+            _lib.check(L.dg_conv_dgrad_x3(dp, dd, dcm, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
                        "dg_conv_dgrad_x3")
         return (dx, None) if want_stats else dx
     mixed = False
@@ -509,10 +526,10 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     L = _lib.load()
     ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
     if _x3_ok(2, n, h, wd, c, k, stride, pad):
-        dp, dd = planes_of(dy)
-        xp, xd = planes_of(x)
+        dp, dd, dcm = planes_of(dy, allow_cm=True)
+        xp, xd, _ = planes_of(x)
         with _prof("conv_wgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-            _lib.check(L.dg_conv_wgrad_x3(dp, dd, xp, xd, _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate), _ptr(ws), wsb,
+            _lib.check(L.dg_conv_wgrad_x3(dp, dd, dcm, xp, xd, _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate), _ptr(ws), wsb,
                                           _stream()), "dg_conv_wgrad_x3")
         return dw
     da, d16, xa, x16 = dy, 0, x, 0
@@ -636,7 +653,8 @@ def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentu
     return saved
 
 
-def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
+def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False):
+    """planes_cm (f32x3 plane path): write z's plane triple chunk-major (its reader is a window input-grad kernel)."""
     _check_dev(y, allow16=True)
     y = as_nhwc(y)
     n, c, h, w = y.shape
@@ -650,9 +668,10 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     if X3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
         z3 = torch.empty((3, z.numel()), device=y.device, dtype=torch.bfloat16)
         with _hbm("bn_apply", 14.0 * n * h * w * c):
-            _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), _ptr(z), _ptr(z3), z3.stride(0), n * h * w, c, _ptr(saved), _ptr(gamma),
+            cm = int(bool(planes_cm) and c % 16 == 0)
+            _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), _ptr(z), _ptr(z3), z3.stride(0), cm, n * h * w, c, _ptr(saved), _ptr(gamma),
                                                     _ptr(beta), act, slope, _stream()), "dg_bn_act_fwd_x3")
-        planes_put(z, z3)
+        planes_put(z, z3, cm)
         return z
     if SHADOW and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
@@ -667,8 +686,9 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2):
     return z
 
 
-def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None):
-    """out_grads=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into those buffers in place."""
+def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None, planes_cm=False):
+    """out_grads=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into those buffers in place.
+    planes_cm (f32x3 plane path): write dy's plane triple chunk-major (its reader is a window input-grad kernel)."""
     _check_dev(dz, y, allow16=True)
     dz = as_nhwc(dz)
     y = as_nhwc(y)
@@ -695,9 +715,10 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
     if X3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
         dy3 = torch.empty((3, dy.numel()), device=y.device, dtype=torch.bfloat16)
         with _hbm("bn_backward", 26.0 * m * c):
-            _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy3), dy3.stride(0), m, c, _ptr(saved), _ptr(gamma), _ptr(beta),
+            cm = int(bool(planes_cm) and c % 16 == 0)
+            _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy3), dy3.stride(0), cm, m, c, _ptr(saved), _ptr(gamma), _ptr(beta),
                                           act, slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_x3")
-        planes_put(dy, dy3)
+        planes_put(dy, dy3, cm)
         return dy, dgamma, dbeta
     if SHADOW and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)

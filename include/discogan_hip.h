@@ -264,6 +264,13 @@ int dg_dp_destroy(void);
 /* ---- image ingest (dataset.py:62-66): uint8 [N][H][W][3] -> float [N][3][H][W] = pixel / 255 -------------
  * bgr != 0 swaps the channel order (cv2.imread-style BGR sources).  H*W must be a multiple of 4. */
 int dg_u8hwc_to_f32chw(const uint8_t* src, float* dst, int N, int H, int W, int bgr, dg_stream_t s);
+/* ---- image preparation (dataset.py:52-66 read_images, :239-254 DiscoGANDataset._load_and_process_image) ----------------
+ * uint8 [N][H][W][3] decoded rows -> float [N][3][S][S]: crop columns [x0, x0 + cw) (edges2*: the left / right half,
+ * dataset.py:54,59), optional 3x3 erosion = 255 - cv2.dilate(255 - x, ones(3,3)) (domain 'A', dataset.py:53-57; neighbours
+ * outside the crop do not count, like cv2's default border), cv2.resize(..., (S, S)) = INTER_LINEAR with half-pixel centres
+ * and edge clamp (dataset.py:62), / 255 and CHW (dataset.py:65-66).  mode 0: float arithmetic, unrounded (what the
+ * reference's float64 domain-'A' image gets); mode 1: cv2's 8-bit fixed-point path, result rounded to uint8 before / 255. */
+int dg_image_prep(const uint8_t* src, float* dst, int N, int H, int W, int x0, int cw, int erode, int mode, int S, dg_stream_t s);
 
 /* ---- bf16 shadow operands for the bf16 matrix path (option "bf16" = 1; BASELINE configs[4]) ---------------------
  * A shadow is a bf16 (RNE) copy of an fp32 tensor with the same logical layout, written by the tensor's PRODUCER so that
@@ -315,17 +322,24 @@ int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n,
                          void* p_planes, size_t plane_elems, dg_stream_t s);
 int dg_x3_transpose_planes(const void* src_planes, void* dst_planes, size_t plane_elems, const int64_t* w_off, const int* w_K,
                            const int* w_J, int n, dg_stream_t s);
-int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int M, int C, const float* saved,
+/* plane_layout / dy_layout: 0 = pixel-major planes [M][C] (the tensor's own NHWC order); 1 = 16-channel CHUNK-MAJOR planes
+ * [C / 16][M][16] (C % 16 == 0).  The window input-grad kernel fetches a 16-channel chunk of whole image rows per step: in the
+ * pixel-major order that is 32 bytes of every 256- or 512-byte pixel row (each 128-byte line crossed the fabric four times, PMC:
+ * 8x the algorithmic bytes); chunk-major it is one contiguous run.  Producers: the BatchNorm kernels below, for the two
+ * layer shapes per network whose input-grad dg_conv_x3_planes_ok reports as 2; readers: dg_conv_dgrad_x3 (window kernel)
+ * and dg_conv_wgrad_x3 (the dy operand).  Same products in the same order: results are bit-identical to layout 0. */
+int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int plane_layout, int M, int C, const float* saved,
                      const float* gamma, const float* beta, int act, float slope, dg_stream_t stream);
-int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int M, int C,
+int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,
                      const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
                      float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+/* 0: no plane kernel for this (op, shape); 1: yes; 2: yes -- the window input-grad kernel, which prefers dy_layout 1 */
 int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
 int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, int w_transposed, float* y,
                    int N, int H, int W, int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
-int dg_conv_dgrad_x3(const void* dy_planes, int64_t dy_plane, const void* w_planes, int64_t w_plane, float* dx, int N, int H, int W,
+int dg_conv_dgrad_x3(const void* dy_planes, int64_t dy_plane, int dy_layout, const void* w_planes, int64_t w_plane, float* dx, int N, int H, int W,
                      int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
-int dg_conv_wgrad_x3(const void* dy_planes, int64_t dy_plane, const void* x_planes, int64_t x_plane, float* dw, int N, int H, int W,
+int dg_conv_wgrad_x3(const void* dy_planes, int64_t dy_plane, int dy_layout, const void* x_planes, int64_t x_plane, float* dw, int N, int H, int W,
                      int C, int K, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 
 /* ---- bf16 ACTIVATION STORAGE (option "bf16" = 1; DiscoGANTrainer(mfma_dtype="bf16", act_dtype="bf16")) --------------------

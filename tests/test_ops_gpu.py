@@ -372,11 +372,30 @@ def test_conv_f32x3_input_grad_window_kernel(N, C, K, H, splitk):
     _lib.set_option("splitk", splitk)
     try:
         dxreg = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
-        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == 1
+        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == (2 if K % 16 == 0 else 1)      # 2: prefers chunk-major planes
         ops.X3 = True
         dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
         torch.cuda.synchronize()
         assert len(ops._PLANE_TAB) == 1
+        if K % 16 == 0:
+            # the same launch on CHUNK-MAJOR gradient planes [K/16][pixels][16] (what the BatchNorm kernels write for this kernel):
+            # same products, same order -> the same bits; and the plane weight-grad kernel reads that layout too
+            xg = nhwc(rnd(N, C, H, H, seed=9))
+            dw = ops.conv_wgrad(dyg, xg, 2, 1)
+            M = N * (H // 2) ** 2
+            t3 = ops._PLANE_TAB[dyg.data_ptr()][1]
+            cm3 = t3.view(3, M, K // 16, 16).permute(0, 2, 1, 3).contiguous().view(3, -1)
+            ops.planes_put(dyg, cm3, cm=True)
+            dx_cm = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+            dw_cm = ops.conv_wgrad(dyg, xg, 2, 1)
+            torch.cuda.synchronize()
+            assert ops._PLANE_TAB[dyg.data_ptr()][2] is True and ops._PLANE_TAB[dyg.data_ptr()][1] is cm3     # no silent re-split
+            assert torch.equal(dx_cm, dx), "window input-grad: chunk-major planes vs pixel-major planes"
+            if L.dg_conv_x3_planes_ok(2, N, H, H, C, K, 2, 1) == 1:
+                assert torch.equal(dw_cm, dw), "plane weight-grad: chunk-major dy planes vs pixel-major"
+            # a reader that cannot take the layout (the forward form) gets a pixel-major split of the fp32 tensor instead
+            p0, _, cmflag = ops.planes_of(dyg, allow_cm=False)
+            assert cmflag == 0 and p0 != cm3.data_ptr()
     finally:
         ops.X3 = False
         ops.planes_clear()
@@ -623,6 +642,15 @@ def test_batchnorm_writes_plane_triples(N, C, H, act):
         assert torch.equal(z3, ref(z)) and torch.equal(dy3, ref(dy))
         mem = lambda t: t.permute(0, 2, 3, 1).reshape(-1)
         assert torch.equal(z3.float().sum(0), mem(z)) and torch.equal(dy3.float().sum(0), mem(dy))
+        if C % 16 == 0:
+            # chunk-major planes [C/16][pixels][16] (plane_layout 1: for a window input-grad kernel): the same values, rearranged
+            zc = ops.bn_act_fwd(yg, saved, gg, bg, code, 0.2, planes_cm=True)
+            dyc, _, _ = ops.bn_act_bwd(dzg, yg, saved, gg, bg, code, 0.2, planes_cm=True)
+            M = N * H * H
+            cm = lambda t3: t3.view(3, M, C // 16, 16).permute(0, 2, 1, 3).contiguous().view(3, -1)
+            ez, edy = ops._PLANE_TAB[zc.data_ptr()], ops._PLANE_TAB[dyc.data_ptr()]
+            assert ez[2] and edy[2] and torch.equal(zc, z0) and torch.equal(dyc, dy0)
+            assert torch.equal(ez[1], cm(z3)) and torch.equal(edy[1], cm(dy3))
     finally:
         ops.X3 = False
         ops.planes_clear()
