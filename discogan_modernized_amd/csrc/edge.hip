@@ -193,11 +193,15 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
 // MF16 (with IN16, option "bf16" = 1): the dense GEMM runs on v_mfma_f32_16x16x32_bf16 -- the bf16 dy values ARE the A operand
 // (lane (pixel p, kq) holds k = 32 st + 8 kq + j: two 16-byte loads, no unpacking), the weights are rounded to bf16 once per
 // lane; 12 MFMAs of 16 cycles per tile and wave instead of 96 of 32.
-template <bool IN16, bool MF16 = false>
+// X3 (fp32 dy, option "bf16" = 2, the f32x3 path): the same 16x16x32 GEMM with fp32-ACCURATE products -- a lane's 8 fp32 dy values
+// of a k32 step and the weights are split into their three bf16 planes in registers (24 significand bits), six MFMAs per block
+// (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): 72 MFMAs of 16 cycles per tile and wave instead of 96 of 32.
+template <bool IN16, bool MF16 = false, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                   float* __restrict__ dx, int N, int H, int W, int act,
                                                                   int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
     static_assert(!MF16 || IN16, "the bf16 MFMA form takes a bf16 dy");
+    static_assert(!X3 || (!IN16 && !MF16), "the f32x3 form takes an fp32 dy");
     typedef __bf16 bf16x8_d __attribute__((ext_vector_type(8)));
     typedef float f32x8_d __attribute__((ext_vector_type(8)));
     __shared__ __attribute__((aligned(16))) float Ps[CS_PR * CS_PC * CS_LDP];
@@ -207,11 +211,29 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
     // B operand: W[k][col], col = c*16 + r*4 + s (the weight tensor's own order).  MFMA step s multiplies the four k values
     // 16*kq + s (kq = lane >> 4): the k order inside the GEMM is free as long as A uses the same one, and this one lets
     // every lane fetch its 16 A values of a pixel as 64 contiguous bytes.
-    float breg[3][MF16 ? 1 : 16];
+    float breg[3][(MF16 || X3) ? 1 : 16];
     bf16x8_d breg16[3][2];
+    bf16x8_d breg3[X3 ? 3 : 1][3][2];               // X3: [plane][block][k32 step]
+    auto split8 = [](const f32x8_d& v, bf16x8_d* pl) {
+        pl[0] = __builtin_convertvector(v, bf16x8_d);
+        const f32x8_d r1 = v - __builtin_convertvector(pl[0], f32x8_d);
+        pl[1] = __builtin_convertvector(r1, bf16x8_d);
+        pl[2] = __builtin_convertvector(r1 - __builtin_convertvector(pl[1], f32x8_d), bf16x8_d);
+    };
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        if constexpr (MF16) {
+        if constexpr (X3) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f32x8_d t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = w[(32 * st + 8 * kq + j) * 48 + blk * 16 + p];
+                bf16x8_d pl[3];
+                split8(t, pl);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) breg3[q][blk][st] = pl[q];
+            }
+        } else if constexpr (MF16) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f32x8_d t;
@@ -233,10 +255,10 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
         for (int g = 0; g < 2; ++g) {
             const int a = tr * CS_TR - 1 + wave + 4 * g, b = tc * CS_TC - 1 + p;
             const bool ok = t < ntiles && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
-            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + (MF16 ? 8 : 16) * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
+            const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + ((MF16 || X3) ? 8 : 16) * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
 #pragma unroll
-            for (int j = 0; j < (IN16 ? 2 : 4); ++j)
-                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + (MF16 ? 64 : 16) * j, 0, 0));
+            for (int j = 0; j < (IN16 ? 2 : 4); ++j)      // X3: float4 j holds k = 32 (j >> 1) + 8 kq + 4 (j & 1) ..+3
+                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + (X3 ? 128 * (j >> 1) + 16 * (j & 1) : (MF16 ? 64 : 16) * j), 0, 0));
         }
     };
     fetch(blockIdx.x, 0);
@@ -250,7 +272,22 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int blk = 0; blk < 3; ++blk) acc[g][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (MF16) {
+        if constexpr (X3) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (dy plane, weight plane), smallest product first
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 v0 = areg[S][g][2 * st], v1 = areg[S][g][2 * st + 1];
+                    bf16x8_d apl[3];
+                    split8((f32x8_d){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, apl);
+#pragma unroll
+                    for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            acc[g][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apl[PA[q]], breg3[PB[q]][blk][st], acc[g][blk], 0, 0, 0);
+                }
+        } else if constexpr (MF16) {
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -340,6 +377,9 @@ static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float
             else if (dy_bf16)
                 hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
+            else if (dg_get_option(DG_OPT_BF16) == 2)           // f32x3 path: fp32-accurate products on the bf16 MFMA
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false, true>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
             else
                 hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
@@ -491,7 +531,11 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __rest
 typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
 typedef float f32x8_e __attribute__((ext_vector_type(8)));
 typedef float f32x2_g __attribute__((ext_vector_type(2)));
-template <int ACT, bool OUT16>
+// X3 (option "bf16" = 2, the f32x3 path): image and weights are NOT rounded -- each fp32 value is split into its three bf16 planes
+// hi / mid / lo in registers (dg_split3: 24 significand bits) and every product block is the six MFMAs of igemm.hip's PREC 2
+// (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, smallest first): 36 MFMAs of 32 cycles per 32 pixels against the fp32 kernel's
+// 48 of 64 -- fp32-accurate products at 2.7x the matrix rate, so the kernel is bound by its loads and stores like the bf16 one.
+template <int ACT, bool OUT16, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
                                                                  long npix, int ngroups, float slope, int xbytes) {
@@ -500,14 +544,26 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __
     const int Ho = H >> 1, Wo = W >> 1;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     // B operand: block nb, column p = channel (OUT16 ? 2p + nb : 32 nb + p); k = 16 c + 8 h + j are 8 consecutive weights
-    bf16x8_e wb[2][3];
+    constexpr int NPL = X3 ? 3 : 1;
+    bf16x8_e wb[NPL][2][3];
+    auto split8 = [](const f32x8_e& v, bf16x8_e* pl) {     // X3: pl[0..2] = hi, mid, lo (both residuals are exact in fp32); else pl[0] = RNE(v)
+        pl[0] = __builtin_convertvector(v, bf16x8_e);
+        if constexpr (X3) {
+            const f32x8_e r1 = v - __builtin_convertvector(pl[0], f32x8_e);
+            pl[1] = __builtin_convertvector(r1, bf16x8_e);
+            pl[2] = __builtin_convertvector(r1 - __builtin_convertvector(pl[1], f32x8_e), bf16x8_e);
+        }
+    };
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* wp = w + (OUT16 ? 2 * p + nb : nb * 32 + p) * 48 + c * 16 + 8 * h;
             const f32x4 lo = *(const f32x4*)wp, hi = *(const f32x4*)(wp + 4);
-            wb[nb][c] = __builtin_convertvector((f32x8_e){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, bf16x8_e);
+            bf16x8_e pl[NPL];
+            split8((f32x8_e){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pl);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) wb[q][nb][c] = pl[q];
         }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
     const int HW4 = H * W * 4;
@@ -544,10 +600,20 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __
         f32x16 acc0 = {0.f}, acc1 = {0.f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const bf16x8_e av = __builtin_convertvector((f32x8_e){al[P][c][0], ap[P][c][0][0], ap[P][c][0][1], ar[P][c][0],
-                                                                  al[P][c][1], ap[P][c][1][0], ap[P][c][1][1], ar[P][c][1]}, bf16x8_e);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wb[0][c], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wb[1][c], acc1, 0, 0, 0);
+            bf16x8_e av[NPL];
+            split8((f32x8_e){al[P][c][0], ap[P][c][0][0], ap[P][c][0][1], ar[P][c][0],
+                             al[P][c][1], ap[P][c][1][0], ap[P][c][1][1], ar[P][c][1]}, av);
+            if constexpr (X3) {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (a plane, b plane), smallest product first
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]], wb[PB[q]][0][c], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]], wb[PB[q]][1][c], acc1, 0, 0, 0);
+                }
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], wb[0][0][c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], wb[0][1][c], acc1, 0, 0, 0);
+            }
         }
         const long pix0 = (long)gcur * 32;
         const bool whole = pix0 + 32 <= npix;
@@ -599,6 +665,16 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
       (void)once; }                                                                                                     \
     hipLaunchKernelGGL((c3_fwd_mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W, \
                        dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
+    if (dg_get_option(DG_OPT_BF16) == 2 && dg_get_option(DG_OPT_KT) != 16 && !y_bf16) {   // f32x3 path: fp32-accurate products on the bf16 MFMA
+#define CFX3_LAUNCH(ACT)                                                                                                    \
+        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W, \
+                           dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
+        if (act == DG_ACT_LEAKY) { CFX3_LAUNCH(DG_ACT_LEAKY); }
+        else if (act == DG_ACT_RELU) { CFX3_LAUNCH(DG_ACT_RELU); }
+        else { CFX3_LAUNCH(DG_ACT_NONE); }
+#undef CFX3_LAUNCH
+        return DG_OK;
+    }
     if (dg_get_option(DG_OPT_BF16) == 1 && dg_get_option(DG_OPT_KT) != 16) {     // bf16 matrix path ("kt" 16 keeps the fp32-MFMA kernel testable there)
 #define CF16_LAUNCH(ACT, O16)                                                                                              \
         hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W,    \

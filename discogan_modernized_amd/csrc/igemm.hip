@@ -1513,10 +1513,10 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     pl.a.a_plane = a_plane; pl.a.b_plane = b_plane;
     DG_CHECK_ARG(!b_transposed || op == 0, "%s: only the forward form takes transposed weight planes", who);
     pl.a.b_transposed = b_transposed ? 1 : 0;
-    // chunk-major gradient planes [K / 16][pixels][16]: read by the window input-grad kernel and by the plane weight-grad kernel
+    // quad-chunk gradient planes [pixels / 4][K / 16][4][16]: read by the window input-grad kernel and by the plane weight-grad kernel
     DG_CHECK_ARG(a_layout == 0 || a_layout == 1, "%s: plane layout %d", who, a_layout);
-    DG_CHECK_ARG(a_layout == 0 || (K % 16 == 0 && ((op == 1 && pl.dma == 3) || (op == 2 && pl.dma == 2))),
-                 "%s: chunk-major planes are only read by the window input-grad and the plane weight-grad kernels (K %% 16 == 0)", who);
+    DG_CHECK_ARG(a_layout == 0 || (K % 64 == 0 && ((op == 1 && pl.dma == 3) || (op == 2 && pl.dma == 2))),
+                 "%s: quad-chunk planes are only read by the window input-grad and the plane weight-grad kernels (K %% 64 == 0)", who);
     pl.a.a_cm = a_layout;
     return run_plan(who, pl, ws, ws_bytes, st);
 }
@@ -1534,14 +1534,14 @@ extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, int dy_layout, c
     return conv_x3(2, dy3, dy_plane, x3, x_plane, 0, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream, dy_layout);
 }
 // does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)  0: no; 1: yes; 2: yes, and it is the
-// window input-grad kernel, which wants its gradient operand chunk-major (plane_layout 1 of dg_bn_act_*_x3)
+// window input-grad kernel, which wants its gradient operand in the quad-chunk layout (plane_layout 1 of dg_bn_act_*_x3)
 extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_x3_planes_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
     if (dg_get_option(DG_OPT_BF16) != 2) return 0;
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
-    return pl.dma == 3 ? (K % 16 == 0 ? 2 : 1) : (pl.dma == 2 ? 1 : 0);
+    return pl.dma == 3 ? (K % 64 == 0 ? 2 : 1) : (pl.dma == 2 ? 1 : 0);
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

@@ -22,8 +22,8 @@ struct IgemmArgs {
     int a16, b16;        // PREC 1: operand A / B is a bf16 tensor in HBM (same logical layout, 2 bytes per element);
                          // 3 (PREC 2, igemm_dma_x3.hip): three bf16 planes hi / mid / lo, plane-major, a_plane / b_plane bytes apart
     long a_plane, b_plane;
-    int a_cm;            // igemm_dma_x3.hip WGRAD / igemm_dma_x3_dgw.hip: operand A's planes are 16-channel CHUNK-MAJOR [K / 16][pixels][16]
-                         // (written so by dg_bn_act_fwd_x3 / dg_bn_act_bwd_x3, plane_layout 1) instead of pixel-major [pixels][K]
+    int a_cm;            // igemm_dma_x3.hip WGRAD / igemm_dma_x3_dgw.hip: operand A's planes are in the QUAD-CHUNK layout
+                         // [pixels / 4][K / 16][4][16] (written so by dg_bn_act_fwd_x3 / dg_bn_act_bwd_x3, plane_layout 1) instead of [pixels][K]
     int b_transposed;    // igemm_dma_x3.hip FWD: the weight planes are the transposed copy [(r, s, c)][k]
     int out16;           // the output tensor C is bf16 (RNE of the fp32 accumulators; FWD / DGRAD modes, never the weight gradient)
     int dbg_zero;        // timing experiments: drop the A (bit 0) / B (bit 1) operand loads

@@ -185,10 +185,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
             const int krow = pq * RP + lane / GR;
             const int gc = (lane % GR) ^ kmswz(krow);
             const int col = m0 + gc * 8;
-            // pixel-major dy[pixel][K]: pixel rows >= R run off the end of the plane (zeros).  Chunk-major [K / 16][R][16]
-            // (a_cm): a row past R would land in the next chunk, so it is masked in a_voff (a_inv keeps the piece's pixel row)
-            a_ob[i] = col < K ? (p.a_cm ? (((col >> 4) * p.R + krow) * 16 + (col & 15)) * 2 : (krow * K + col) * 2) : OOR;
-            a_inv[i] = krow;
+            // pixel-major dy[pixel][K]: pixel rows >= R run off the end of the plane (zeros).  Quad-chunk planes (a_cm)
+            // [R / 4][K / 16][4][16]: the same 16-pixel x K block of bytes, permuted inside -- the tile stride is unchanged
+            a_ob[i] = col < K ? (p.a_cm ? (((krow >> 2) * (K >> 4) + (col >> 4)) * 64 + (krow & 3) * 16 + (col & 15)) * 2 : (krow * K + col) * 2) : OOR;
         }
     }
     int b_ob[NPB];
@@ -285,7 +284,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
             const int soff = ((dyo * Wo + dxo) * K + coff()) * 2;
             return (a_ob[i] + soff) | -((a_inv[i] >> tap) & 1);
         }
-        if (p.a_cm) return (a_ob[i] + dt * (KT * 2) * 16) | -((dt * KT + a_inv[i]) >= p.R ? 1 : 0);
         return a_ob[i] + dt * (KT * 2) * K;
     };
     auto b_voff = [&](int i) -> int {

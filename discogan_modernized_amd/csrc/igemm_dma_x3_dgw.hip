@@ -97,7 +97,6 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     const int n_img = m0 >> lgHW, a0 = (m0 >> lgWo) & (Ho - 1);
     const int WR = (256 / Wo + 2) * WW;                       // window rows
     const int wpieces = (WR + 31) >> 5;
-    const int a_chunk_bytes = (p.N << lgHW) * (KT * 2);        // chunk-major planes: bytes of one 16-channel chunk of all pixels
 
     constexpr int OOR = (int)0x80000000;
     __amdgpu_buffer_rsrc_t rA[3], rB[3];
@@ -121,8 +120,9 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
         const int a = a0 - 1 + wr, b = wc - 1;
         const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
         const int pix = (n_img * Ho + a) * Wo + b;
-        // chunk-major planes [K / 16][pixels][16]: a window row of a chunk is 32 contiguous bytes of a contiguous run of pixels
-        w_ob[j] = ok ? (p.a_cm ? (pix * 16 + g * 8) * 2 : (pix * K + g * 8) * 2) : OOR;
+        // quad-chunk planes [pixels / 4][K / 16][4][16]: the chunk of 4 consecutive pixels is one 128-byte line -- a window row
+        // of a chunk uses every byte of the lines it touches
+        w_ob[j] = ok ? (p.a_cm ? ((pix >> 2) * (4 * K) + (pix & 3) * 16 + g * 8) * 2 : (pix * K + g * 8) * 2) : OOR;
     }
     // ---- weight DMA descriptors: tile [16 k][256 columns], column = class-local-index * CW + c; one piece per plane ----
     // piece = k rows 2 w, 2 w + 1; lane L lands in (k row 2 w + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     };
     // plane pl of the window of chunk `c` into window stage `ast`
     auto issue_window = [&](int ast, int pl, int c) {
-        const int coff = p.a_cm ? c * a_chunk_bytes : c * KT * 2;
+        const int coff = p.a_cm ? c * (4 * KT * 2) : c * KT * 2;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (wave + 8 * j < wpieces)                                   // wave-uniform

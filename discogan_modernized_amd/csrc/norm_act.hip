@@ -253,24 +253,49 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
 
 typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
 // TI / TO: element types of y and z.  Z16 (fp32 z only) = 1: also write a bf16 (RNE) shadow of z for the bf16 matrix path;
-// = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart).  cmM > 0 (= M, the
-// pixel count): the planes are CHUNK-MAJOR [C / 16][M][16] instead of pixel-major [M][C] -- the layout the window input-grad
-// kernel (igemm_dma_x3_dgw.hip) wants: a 16-channel chunk of consecutive pixels is one contiguous run of 32-byte rows.
-__device__ __forceinline__ long bn_plane_index(long idx4, int c, int cvn, long cmM) {
-    if (cmM == 0) return idx4 * 4;
-    const long pix = idx4 / cvn;
-    return ((long)(c >> 4) * cmM + pix) * 16 + (c & 15);
+// = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart).  cm != 0: the planes
+// are written in the QUAD-CHUNK layout [M / 4][C / 16][4 pixels][16 channels] instead of pixel-major [M][C] -- the layout the
+// window input-grad kernel (igemm_dma_x3_dgw.hip) wants: the 16-channel chunk of 4 consecutive pixels is one 128-byte line, so
+// a window row of a chunk uses every byte of the lines it touches, while a 4-pixel block of all channels stays one contiguous
+// run (the weight-gradient kernel's 16-pixel tile is as contiguous as before).  The work items are then dealt so that 16
+// consecutive lanes hold (4 pixels) x (the 4 channel quads of one chunk): a wave reads 4 x 256 contiguous bytes of the fp32
+// tensors and writes whole 128-byte lines of every plane.
+struct BnItem { long v; int c; long pi; };      // fp32 vector index (4 channels), first channel, plane element index
+__device__ __forceinline__ BnItem bn_item(long i, int cvn, int cm) {
+    BnItem it;
+    if (!cm) {
+        it.v = i;
+        it.c = (int)(i % cvn) * 4;
+        it.pi = i * 4;
+        return it;
+    }
+    // i = ((grp * (cvn / 16) + h) * 4 + pp) * 16 + q16: pixel 4 grp + pp, channel quad 16 h + q16
+    const int q16 = (int)(i & 15), pp = (int)((i >> 4) & 3);
+    const long rest = i >> 6;
+    const int hs = cvn >> 4;
+    const int h = (int)(rest % hs);
+    const long grp = rest / hs;
+    const int cq = h * 16 + q16;
+    it.v = (grp * 4 + pp) * cvn + cq;
+    it.c = cq * 4;
+    it.pi = ((grp * (cvn >> 2) + (cq >> 2)) * 4 + pp) * 16 + (cq & 3) * 4;
+    return it;
 }
 template <typename TI, typename TO, int Z16>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ y, TO* __restrict__ z, long totalv,
                                                          int C, const float* __restrict__ saved,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope, __bf16* __restrict__ z16, long pstride, long cmM) {
+                                                         int act, float slope, __bf16* __restrict__ z16, long pstride, int cm) {
     constexpr int V = BnV<TI>::V;
     static_assert(BnV<TI>::V == BnV<TO>::V, "same storage type on both sides");
     const int cvn = C / V;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % cvn) * V;
+    for (long lin = (long)blockIdx.x * 256 + threadIdx.x; lin < totalv; lin += (long)gridDim.x * 256) {
+        long idx = lin, pi = lin * 4;
+        int c = (int)(lin % cvn) * V;
+        if constexpr (Z16 == 3) {
+            const BnItem it = bn_item(lin, cvn, cm);
+            idx = it.v; c = it.c; pi = it.pi;
+        }
         float v[V], o[V], mean[V], istd[V], g[V], b[V];
         bn_ld(y + idx * V, v);
         bn_ldp<V>(saved + c, mean);
@@ -284,7 +309,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
         if constexpr (Z16 == 3) {
             dg_bf16x4_t h, md, l;
             dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
-            const long pi = bn_plane_index(idx, c, cvn, cmM);
             *(dg_bf16x4_t*)(z16 + pi) = h;
             *(dg_bf16x4_t*)(z16 + pstride + pi) = md;
             *(dg_bf16x4_t*)(z16 + 2 * pstride + pi) = l;
@@ -555,11 +579,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dy, long totalv, int C,
                                                            const float* __restrict__ saved, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ coef,
-                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride, long cmM) {
+                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride, int cm) {
     constexpr int V = BnV<T>::V;
     const int cvn = C / V;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < totalv; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % cvn) * V;
+    for (long lin = (long)blockIdx.x * 256 + threadIdx.x; lin < totalv; lin += (long)gridDim.x * 256) {
+        long idx = lin, pi = lin * 4;
+        int c = (int)(lin % cvn) * V;
+        if constexpr (D16 == 3) {
+            const BnItem it = bn_item(lin, cvn, cm);
+            idx = it.v; c = it.c; pi = it.pi;
+        }
         float v[V], d[V], o[V], mean[V], istd[V], g[V], b[V];
         bn_ld(y + idx * V, v);
         bn_ld(dz + idx * V, d);
@@ -580,7 +609,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if constexpr (D16 == 3) {
             dg_bf16x4_t h, md, l;
             dg_split3((f32x4){o[0], o[1], o[2], o[3]}, h, md, l);
-            const long pi = bn_plane_index(idx, c, cvn, cmM);
             *(dg_bf16x4_t*)(dy16 + pi) = h;
             *(dg_bf16x4_t*)(dy16 + pstride + pi) = md;
             *(dg_bf16x4_t*)(dy16 + 2 * pstride + pi) = l;
@@ -700,7 +728,7 @@ static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const floa
                            const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
-    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 16 == 0), "dg_bn_act_fwd: chunk-major planes need plane operands and C %% 16 == 0 (C=%d)", C);
+    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_fwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
     const long totalv = (long)M * C / V;
@@ -714,19 +742,19 @@ static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const floa
     if constexpr (V == 4) {
         if (z16 && pstride > 0) {
             hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride, plane_cm ? (long)M : 0L);
+                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride, plane_cm);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
         if (z16) {
             hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L, 0L);
+                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L, 0);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
     }
     hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L, 0L);
+                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L, 0);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
@@ -742,7 +770,7 @@ extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M,
 // the same pass, also writing the three bf16 planes of z (plane_elems elements apart, >= M * C, % 8 == 0) for the f32x3 matrix path
 extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int plane_layout, int M, int C, const float* saved,
                                 const float* gamma, const float* beta, int act, float slope, dg_stream_t stream) {
-    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_fwd_x3: plane_layout 0 (pixel-major) or 1 (16-channel chunk-major)");
+    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_fwd_x3: plane_layout 0 (pixel-major) or 1 (quad-chunk)");
     DG_CHECK_ARG(z_planes, "dg_bn_act_fwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_fwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
     return bn_act_fwd_impl<float>(y, z, z_planes, M, C, saved, gamma, beta, act, slope, stream, (long)plane_elems, plane_layout);
@@ -759,7 +787,7 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
                            int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
     DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
-    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 16 == 0), "dg_bn_act_bwd: chunk-major planes need plane operands and C %% 16 == 0 (C=%d)", C);
+    DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_bwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
     if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
@@ -778,13 +806,13 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
     if constexpr (V == 4) {
         if (dy16 && pstride > 0) {
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride, plane_cm ? (long)M : 0L);
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride, plane_cm);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
         if (dy16) {
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L, 0L);
+                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L, 0);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
@@ -795,7 +823,7 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
         return DG_OK;
     }
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L, 0L);
+                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L, 0);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
 }
@@ -813,7 +841,7 @@ extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, vo
 extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,
                                 const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
                                 float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_bwd_x3: plane_layout 0 (pixel-major) or 1 (16-channel chunk-major)");
+    DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_bwd_x3: plane_layout 0 (pixel-major) or 1 (quad-chunk)");
     DG_CHECK_ARG(dy_planes, "dg_bn_act_bwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_bwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
     return bn_act_bwd_impl<float>(dz, y, dy, dy_planes, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream,

@@ -305,6 +305,8 @@ class DeviceLoader:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DiscoganHipError("DeviceLoader needs a HIP device (no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.transform = transform
         self.bmax = max((max(len(a), len(b)) for a, b in self.batches), default=0)
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))

@@ -275,9 +275,9 @@ def _bf16_ok(op, n, h, wd, c, k, stride, pad):
 #                split yet, by dg_f32_to_bf16x3 at its first use (the triple then serves the forward AND the weight gradient)
 X3 = False
 # X3_CM: the BatchNorm kernels write the plane triples that a WINDOW input-grad kernel will read (dy of the conv layers with
-# <= 128 input channels, the input of the transposed convs with <= 128 output channels) 16-channel CHUNK-MAJOR
-# ([C/16][pixels][16], include/discogan_hip.h "plane_layout"): a window row of a chunk is then one contiguous run instead of 32
-# bytes of every pixel row.  Bit-identical results; DG_X3_CM=0 keeps every triple pixel-major (A/B).
+# <= 128 input channels, the input of the transposed convs with <= 128 output channels) in the QUAD-CHUNK layout
+# ([pixels/4][C/16][4][16], include/discogan_hip.h "plane_layout"): the window kernel then uses every byte of the 128-byte lines
+# it fetches instead of 32.  Bit-identical results; DG_X3_CM=0 keeps every triple pixel-major (A/B).
 X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
 _PLANE_TAB = {}
 
@@ -316,7 +316,7 @@ def x3_window_dgrad(n, h, wd, c, k):
     """Will the input-grad of Conv2d(c, k, 4, 2, 1) on an [n, c, h, wd] input (= the forward of the transposed conv with the same
     weight) run on the window kernel AND its weight gradient on the plane kernel?  Then the producer of the gradient operand
     writes chunk-major planes (X3_CM)."""
-    if not (X3 and X3_CM) or k % 16 != 0:
+    if not (X3 and X3_CM) or k % 64 != 0:
         return False
     L = _lib.load()
     return L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, 2, 1) == 2 and L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) == 1
@@ -668,7 +668,7 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False):
     if X3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
         z3 = torch.empty((3, z.numel()), device=y.device, dtype=torch.bfloat16)
         with _hbm("bn_apply", 14.0 * n * h * w * c):
-            cm = int(bool(planes_cm) and c % 16 == 0)
+            cm = int(bool(planes_cm) and c % 64 == 0 and (n * h * w) % 4 == 0)
             _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), _ptr(z), _ptr(z3), z3.stride(0), cm, n * h * w, c, _ptr(saved), _ptr(gamma),
                                                     _ptr(beta), act, slope, _stream()), "dg_bn_act_fwd_x3")
         planes_put(z, z3, cm)
@@ -715,7 +715,7 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
     if X3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
         dy3 = torch.empty((3, dy.numel()), device=y.device, dtype=torch.bfloat16)
         with _hbm("bn_backward", 26.0 * m * c):
-            cm = int(bool(planes_cm) and c % 16 == 0)
+            cm = int(bool(planes_cm) and c % 64 == 0 and m % 4 == 0)
             _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy3), dy3.stride(0), cm, m, c, _ptr(saved), _ptr(gamma), _ptr(beta),
                                           act, slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_x3")
         planes_put(dy, dy3, cm)

@@ -322,12 +322,14 @@ int dg_adam_step_flat_x3(float* p, const float* g, float* m, float* v, size_t n,
                          void* p_planes, size_t plane_elems, dg_stream_t s);
 int dg_x3_transpose_planes(const void* src_planes, void* dst_planes, size_t plane_elems, const int64_t* w_off, const int* w_K,
                            const int* w_J, int n, dg_stream_t s);
-/* plane_layout / dy_layout: 0 = pixel-major planes [M][C] (the tensor's own NHWC order); 1 = 16-channel CHUNK-MAJOR planes
- * [C / 16][M][16] (C % 16 == 0).  The window input-grad kernel fetches a 16-channel chunk of whole image rows per step: in the
- * pixel-major order that is 32 bytes of every 256- or 512-byte pixel row (each 128-byte line crossed the fabric four times, PMC:
- * 8x the algorithmic bytes); chunk-major it is one contiguous run.  Producers: the BatchNorm kernels below, for the two
- * layer shapes per network whose input-grad dg_conv_x3_planes_ok reports as 2; readers: dg_conv_dgrad_x3 (window kernel)
- * and dg_conv_wgrad_x3 (the dy operand).  Same products in the same order: results are bit-identical to layout 0. */
+/* plane_layout / dy_layout: 0 = pixel-major planes [M][C] (the tensor's own NHWC order); 1 = QUAD-CHUNK planes
+ * [M / 4][C / 16][4 pixels][16 channels] (C % 64 == 0, M % 4 == 0): the 16-channel chunk of 4 consecutive pixels is one
+ * 128-byte line, a 4-pixel block of all channels stays one contiguous run.  The window input-grad kernel fetches a 16-channel
+ * chunk of whole image rows per step: pixel-major that is 32 bytes of every 256- or 512-byte pixel row (each 128-byte line
+ * crossed the fabric four times, PMC: 8x the algorithmic bytes); in the quad-chunk layout every fetched line is used whole.
+ * Producers: the BatchNorm kernels below, for the two layer shapes per network whose input-grad dg_conv_x3_planes_ok reports
+ * as 2; readers: dg_conv_dgrad_x3 (window kernel) and dg_conv_wgrad_x3 (the dy operand: its 16-pixel tile is the same block of
+ * bytes, permuted).  Same products in the same order: results are bit-identical to layout 0. */
 int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int plane_layout, int M, int C, const float* saved,
                      const float* gamma, const float* beta, int act, float slope, dg_stream_t stream);
 int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,

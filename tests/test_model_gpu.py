@@ -433,16 +433,16 @@ def test_f32x3_plane_step_is_graph_neutral_and_deterministic():
 
 def test_f32x3_chunk_major_planes_are_bitwise_neutral(monkeypatch):
     """ops.X3_CM: the BatchNorm kernels write the plane triples a window input-grad kernel reads (dy of the two narrow conv layers,
-    the inputs of the two narrow transposed convs) 16-channel chunk-major.  Same products in the same order: 6 iterations with
-    the layout on and off end in bitwise identical weights, and the layout was really used."""
-    A, B = synthetic_batch(4, 64, 3, DEV)
+    the inputs of the two narrow transposed convs) in the quad-chunk layout.  Same products in the same order: 6 iterations with
+    the layout on and off end in bitwise identical weights, and the layout was really used (the window kernel exists from 128 px)."""
+    A, B = synthetic_batch(2, 128, 3, DEV)
     runs, used = [], []
     for cm in (False, True):
         monkeypatch.setattr(ops, "X3_CM", cm)
         seen = []
         orig = ops.planes_put
         monkeypatch.setattr(ops, "planes_put", lambda t, t3, cm=False, _o=orig, _s=seen: (_s.append(bool(cm)), _o(t, t3, cm))[1])
-        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=64, seed=1234, mfma_dtype="f32x3", x3_planes=True)
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=128, seed=1234, mfma_dtype="f32x3", x3_planes=True)
         vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(6)]
         torch.cuda.synchronize()
         runs.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone()))

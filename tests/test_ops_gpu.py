@@ -372,27 +372,27 @@ def test_conv_f32x3_input_grad_window_kernel(N, C, K, H, splitk):
     _lib.set_option("splitk", splitk)
     try:
         dxreg = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
-        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == (2 if K % 16 == 0 else 1)      # 2: prefers chunk-major planes
+        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == (2 if K % 64 == 0 else 1)      # 2: prefers quad-chunk planes
         ops.X3 = True
         dx = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
         torch.cuda.synchronize()
         assert len(ops._PLANE_TAB) == 1
-        if K % 16 == 0:
-            # the same launch on CHUNK-MAJOR gradient planes [K/16][pixels][16] (what the BatchNorm kernels write for this kernel):
+        if K % 64 == 0:
+            # the same launch on QUAD-CHUNK gradient planes [pixels/4][K/16][4][16] (what the BatchNorm kernels write for this kernel):
             # same products, same order -> the same bits; and the plane weight-grad kernel reads that layout too
             xg = nhwc(rnd(N, C, H, H, seed=9))
             dw = ops.conv_wgrad(dyg, xg, 2, 1)
             M = N * (H // 2) ** 2
             t3 = ops._PLANE_TAB[dyg.data_ptr()][1]
-            cm3 = t3.view(3, M, K // 16, 16).permute(0, 2, 1, 3).contiguous().view(3, -1)
+            cm3 = t3.view(3, M // 4, 4, K // 16, 16).permute(0, 1, 3, 2, 4).contiguous().view(3, -1)
             ops.planes_put(dyg, cm3, cm=True)
             dx_cm = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
             dw_cm = ops.conv_wgrad(dyg, xg, 2, 1)
             torch.cuda.synchronize()
             assert ops._PLANE_TAB[dyg.data_ptr()][2] is True and ops._PLANE_TAB[dyg.data_ptr()][1] is cm3     # no silent re-split
-            assert torch.equal(dx_cm, dx), "window input-grad: chunk-major planes vs pixel-major planes"
+            assert torch.equal(dx_cm, dx), "window input-grad: quad-chunk planes vs pixel-major planes"
             if L.dg_conv_x3_planes_ok(2, N, H, H, C, K, 2, 1) == 1:
-                assert torch.equal(dw_cm, dw), "plane weight-grad: chunk-major dy planes vs pixel-major"
+                assert torch.equal(dw_cm, dw), "plane weight-grad: quad-chunk dy planes vs pixel-major"
             # a reader that cannot take the layout (the forward form) gets a pixel-major split of the fp32 tensor instead
             p0, _, cmflag = ops.planes_of(dyg, allow_cm=False)
             assert cmflag == 0 and p0 != cm3.data_ptr()
@@ -642,12 +642,12 @@ def test_batchnorm_writes_plane_triples(N, C, H, act):
         assert torch.equal(z3, ref(z)) and torch.equal(dy3, ref(dy))
         mem = lambda t: t.permute(0, 2, 3, 1).reshape(-1)
         assert torch.equal(z3.float().sum(0), mem(z)) and torch.equal(dy3.float().sum(0), mem(dy))
-        if C % 16 == 0:
-            # chunk-major planes [C/16][pixels][16] (plane_layout 1: for a window input-grad kernel): the same values, rearranged
+        if C % 64 == 0 and (N * H * H) % 4 == 0:
+            # quad-chunk planes [pixels/4][C/16][4][16] (plane_layout 1: for a window input-grad kernel): the same values, rearranged
             zc = ops.bn_act_fwd(yg, saved, gg, bg, code, 0.2, planes_cm=True)
             dyc, _, _ = ops.bn_act_bwd(dzg, yg, saved, gg, bg, code, 0.2, planes_cm=True)
             M = N * H * H
-            cm = lambda t3: t3.view(3, M, C // 16, 16).permute(0, 2, 1, 3).contiguous().view(3, -1)
+            cm = lambda t3: t3.view(3, M // 4, 4, C // 16, 16).permute(0, 1, 3, 2, 4).contiguous().view(3, -1)
             ez, edy = ops._PLANE_TAB[zc.data_ptr()], ops._PLANE_TAB[dyc.data_ptr()]
             assert ez[2] and edy[2] and torch.equal(zc, z0) and torch.equal(dyc, dy0)
             assert torch.equal(ez[1], cm(z3)) and torch.equal(edy[1], cm(dy3))
@@ -987,3 +987,48 @@ def test_edge_kernels_on_the_bf16_matrix_path(N, S):
         ops.ACT16 = False
         _lib.set_option("kt", 0)
         _lib.set_option("bf16", 0)
+
+
+@pytest.mark.parametrize("N,S", [(2, 16), (3, 64), (1, 256)])
+def test_edge_forward_on_the_f32x3_path(N, S):
+    """Option "bf16" = 2: the 3-channel forward (conv1, and the last transposed conv's input-grad) splits image and weights into
+    their three bf16 planes in registers and multiplies with six bf16 MFMAs per block -- fp32-accurate: at least as close to the
+    fp64 convolution of the UNROUNDED operands as the fp32-MFMA kernel (<= 2x its distance), padding and ragged groups included."""
+    x, w = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(1)), rnd(64, 3, 4, 4, seed=2, scale=0.2)
+    y64 = TF.conv2d(x.double(), w.double(), stride=2, padding=1)
+    xg, wg = x.to(DEV), w.to(DEV)
+    y32 = ops.c3_fwd(xg, wg, ops.ACT_NONE, 0.2)
+    _lib.set_option("bf16", 2)
+    try:
+        y3 = ops.c3_fwd(xg, wg, ops.ACT_NONE, 0.2)
+        y3l = ops.c3_fwd(xg, wg, ops.ACT_LEAKY, 0.2)
+    finally:
+        _lib.set_option("bf16", 0)
+    e32 = ((y32.double().cpu() - y64).norm() / y64.norm()).item()
+    e3 = ((y3.double().cpu() - y64).norm() / y64.norm()).item()
+    assert e3 <= 2 * e32 + 2e-8, f"f32x3 edge forward: relative L2 {e3:.2e} vs fp64 (fp32 MFMA kernel: {e32:.2e})"
+    close(y3, y64.float(), rtol=2e-6, what="c3_fwd f32x3")
+    close(y3l, TF.leaky_relu(y64, 0.2).float(), rtol=2e-6, what="c3_fwd f32x3 + LeakyReLU")
+
+
+@pytest.mark.parametrize("N,H", [(2, 8), (3, 16), (2, 64), (1, 256), (5, 32)])
+def test_edge_dgrad_on_the_f32x3_path(N, H):
+    """Option "bf16" = 2: the last ConvTranspose2d(64,3,4,2,1) (+ Sigmoid) / conv1 input-grad in the scatter form with fp32-accurate
+    products on the bf16 MFMA (dy and weights split into three bf16 planes in registers, six MFMAs per block): at least as close to
+    the fp64 result as the fp32-MFMA kernel (<= 2x its distance), ragged tiles and zero halo included."""
+    x = rnd(N, 64, H // 2, H // 2, seed=5)
+    w = rnd(64, 3, 4, 4, seed=6, scale=0.1)
+    raw64 = TF.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
+    xg, wg = nhwc(x), w.to(DEV)
+    d32 = ops.c3_dgrad(xg, wg, ops.ACT_NONE)
+    _lib.set_option("bf16", 2)
+    try:
+        d3 = ops.c3_dgrad(xg, wg, ops.ACT_NONE)
+        d3s = ops.c3_dgrad(xg, wg, ops.ACT_SIGMOID)
+    finally:
+        _lib.set_option("bf16", 0)
+    e32 = ((d32.double().cpu() - raw64).norm() / raw64.norm()).item()
+    e3 = ((d3.double().cpu() - raw64).norm() / raw64.norm()).item()
+    assert e3 <= 2 * e32 + 2e-8, f"f32x3 edge dgrad: relative L2 {e3:.2e} vs fp64 (fp32 MFMA kernel: {e32:.2e})"
+    close(d3, raw64.float(), rtol=2e-6, what="c3_dgrad f32x3")
+    close(d3s, torch.sigmoid(raw64).float(), rtol=2e-6, atol=1e-6, what="c3_dgrad f32x3 + sigmoid")

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--dma_mfma", type=int, default=0, help="32: the LDS-DMA kernel's 32x32x16 body (default 16x16x32)")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
     ap.add_argument("--x3planes", type=int, default=0, help="with --bf16 2: plane operands (igemm_dma_x3.hip), what the f32x3 trainer does; 2 = forward on the transposed weight planes")
-    ap.add_argument("--x3cm", type=int, default=0, help="with --x3planes: hand the window input-grad kernel (and the weight-grad) CHUNK-MAJOR gradient planes, what the BatchNorm kernels write for it (ops.X3_CM)")
+    ap.add_argument("--x3cm", type=int, default=0, help="with --x3planes: hand the window input-grad kernel (and the weight-grad) QUAD-CHUNK gradient planes, what the BatchNorm kernels write for it (ops.X3_CM)")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
     a = ap.parse_args()
@@ -94,7 +94,7 @@ def main():
         if a.x3cm and ops.x3_window_dgrad(N, H, H, C, K):
             t3_ = torch.empty((3, dy.numel()), device=dev, dtype=torch.bfloat16)
             ops.f32_to_bf16x3(dy, t3_)
-            ops.planes_put(dy, t3_.view(3, N * (H // 2) ** 2, K // 16, 16).permute(0, 2, 1, 3).contiguous().view(3, -1), cm=True)
+            ops.planes_put(dy, t3_.view(3, N * (H // 2) ** 2 // 4, 4, K // 16, 16).permute(0, 1, 3, 2, 4).contiguous().view(3, -1), cm=True)
         t1 = timeit(lambda: ops.conv_fwd(x, w, 2, 1))
         t2 = timeit(lambda: ops.conv_dgrad(dy, w, (H, H), 2, 1))
         t3 = timeit(lambda: ops.conv_wgrad(dy, x, 2, 1))

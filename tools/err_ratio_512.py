@@ -7,8 +7,9 @@ fp32 gradients with fp64 on ITS pattern; the ratio of the two errors is 0.8-1.4 
 prints the ratio PER TENSOR and repeats the run with library variants that change one suspect at a time:
 
     fp32            the exact-fp32 MFMA path as shipped (32x32x2: one sequential fp32 chain per output element, up to 32768 long)
-    fp32_splitk4    the same kernels with every conv reduction cut into 4 slabs summed in a fixed order (option "splitk" 4):
-                    chain length / 4 + 4 -- if the chain length is the cause, the ratios drop
+    fp32_splitkN    the same kernels with every conv reduction cut into N slabs summed in a fixed order (option "splitk" N): other
+                    summation orders of the SAME arithmetic -- if the ratios scatter without a trend in N, they are draws of the
+                    rounding noise through the small-batch BatchNorms, not a property of one order
     f32x3           plane path (exact bf16 products, the same sequential fp32 accumulation order per tile)
 
     python tools/err_ratio_512.py --out gpurun_out/err_ratio_512.json
@@ -41,8 +42,8 @@ def main():
     for v in a.variants.split(","):
         mf = "f32x3" if v == "f32x3" else "f32"
         tr = DiscoGANTrainer(default_args(), device="cuda", image_size=a.size, seed=1234, mfma_dtype=mf)
-        if v == "fp32_splitk4":
-            _lib.set_option("splitk", 4)
+        if v.startswith("fp32_splitk"):            # fp32_splitkN: every conv reduction in N slabs, summed in a fixed order
+            _lib.set_option("splitk", int(v[len("fp32_splitk"):]))
         rows = []
         try:
             T._teacher_forced(a.size, a.batch, 0, tr=tr, st=st, iter_list=[0, 1], step=False, rows_out=rows, noise_cache=cache, mfma_dtype=mf)
