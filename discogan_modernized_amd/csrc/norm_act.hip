@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
         bn_ldp<V>(beta + c, b);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], g[j] * istd[j], b[j]), act, slope);
-        bn_st(z + idx * V, o);
+        if (Z16 != 3 || z != nullptr) bn_st(z + idx * V, o);      // plane-only output (f32x3 path): the fp32 copy has no reader
         if constexpr (Z16 == 1) *(bf16x4_n*)(z16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
         if constexpr (Z16 == 3) {
             dg_bf16x4_t h, md, l;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const double xhat = ((double)v[j] - (double)mean[j]) * (double)istd[j];
             o[j] = (float)((double)g[j] * (double)istd[j] * (gg - coef[c + j] - xhat * coef[C + c + j]));
         }
-        bn_st(dy + idx * V, o);
+        if (D16 != 3 || dy != nullptr) bn_st(dy + idx * V, o);   // plane-only output (f32x3 path): the fp32 copy has no reader
         if constexpr (D16 == 1) *(bf16x4_n*)(dy16 + idx * 4) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
         if constexpr (D16 == 3) {
             dg_bf16x4_t h, md, l;
@@ -727,7 +727,7 @@ template <typename T>
 static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const float* saved, const float* gamma,
                            const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
-    DG_CHECK_ARG(y && z && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
+    DG_CHECK_ARG(y && (z || (z16 && pstride > 0)) && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
     DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_fwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
@@ -786,7 +786,7 @@ static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, in
                            const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                            int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
-    DG_CHECK_ARG(dz && y && dy && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
+    DG_CHECK_ARG(dz && y && (dy || (dy16 && pstride > 0)) && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
     DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_bwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);

@@ -231,9 +231,10 @@ class BatchNormActFn(Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope,
-                partials=None, z_cm=False, dy_cm=False):
+                partials=None, z_cm=False, dy_cm=False, z_po=False, dy_po=False):
         """z_cm / dy_cm (f32x3 plane path, ops.X3_CM): the plane triple of z / of this layer's dy will be read by a window
-        input-grad kernel -> written chunk-major (model.py decides from the neighbouring convolutions)."""
+        input-grad kernel -> written in the quad-chunk layout; z_po / dy_po (ops.X3_PLANES_ONLY): every reader of z / dy is a plane
+        kernel -> the fp32 copy is not written (model.py decides both from the neighbouring convolutions)."""
         y = ops.as_nhwc(y)
         if training and partials is not None and partials.numel() > 0:
             # statistics came out of the producing conv kernel's epilogue: no extra pass over y
@@ -242,10 +243,11 @@ class BatchNormActFn(Function):
             saved = ops.bn_train_stats(y, running_mean, running_var, nbt, eps, momentum)
         else:
             saved = torch.stack([running_mean, torch.rsqrt(running_var + eps)])
-        z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope, planes_cm=z_cm)
+        z = ops.bn_act_fwd(y, saved, gamma, beta, act, slope, planes_cm=z_cm, planes_only=z_po and training)
         ctx.save_for_backward(y, saved, gamma, beta)
         ctx.cfg = (act, slope, training)
         ctx.dy_cm = bool(dy_cm)
+        ctx.dy_po = bool(dy_po)
         ctx.prefs = (gamma, beta)
         ctx.final = FINAL_PASS
         return z
@@ -259,12 +261,13 @@ class BatchNormActFn(Function):
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         fg, fb = _flat_grad_of(ctx.prefs[0]), _flat_grad_of(ctx.prefs[1])
         if need_p and fg is not None and fb is not None:
-            dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb), planes_cm=ctx.dy_cm)
+            dy, _, _ = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, out_grads=(fg, fb), planes_cm=ctx.dy_cm, planes_only=ctx.dy_po)
             _final(ctx.final, ctx.prefs[0], ctx.prefs[1])
-            return (dy,) + (None,) * 13
-        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p, planes_cm=ctx.dy_cm)
+            return (dy,) + (None,) * 15
+        dy, dgamma, dbeta = ops.bn_act_bwd(dz, y, saved, gamma, beta, act, slope, need_param_grads=need_p, planes_cm=ctx.dy_cm,
+                                           planes_only=ctx.dy_po)
         return (dy, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class ActFn(Function):

@@ -136,12 +136,12 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2, partials=None, z_cm=False, dy_cm=False):
+    def forward(self, y, fused_act=ops.ACT_NONE, slope=0.2, partials=None, z_cm=False, dy_cm=False, z_po=False, dy_po=False):
         if self.training and y.shape[0] * y.shape[2] * y.shape[3] <= 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
         return F.BatchNormActFn.apply(y, self.weight, self.bias, self.running_mean, self.running_var,
                                       self.num_batches_tracked, self.training, self.eps, self.momentum, fused_act, slope,
-                                      partials, z_cm, dy_cm)
+                                      partials, z_cm, dy_cm, z_po, dy_po)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine=True, track_running_stats=True"
@@ -179,22 +179,37 @@ class Sigmoid(_Act):
         super().__init__(0.0, False)
 
 
-def _plane_hints(conv, x, nxt):
-    """(z_cm, dy_cm) for the BatchNorm behind ``conv`` on the f32x3 plane path (ops.X3_CM): does a window input-grad kernel read
-      * dy of this group -- ``conv`` is a stride-2 Conv2d whose input-grad runs on the window kernel (<= 128 input channels);
-      * z of this group -- the next layer ``nxt`` is a stride-2 ConvTranspose2d whose forward does (<= 128 output channels)?"""
-    if not (ops.X3 and ops.X3_CM):
-        return False, False
+def _plane_hints(conv, x, nxt, z_is_output=False):
+    """Hints for the BatchNorm behind ``conv`` on the f32x3 plane path, from the convolutions on either side of it:
+      z_cm / dy_cm (ops.X3_CM): a window input-grad kernel reads z (the next layer ``nxt`` is a stride-2 ConvTranspose2d with
+          <= 128 output channels) / dy (``conv`` is a stride-2 Conv2d with <= 128 input channels) -> quad-chunk planes;
+      z_po / dy_po (ops.X3_PLANES_ONLY): EVERY reader of z (the next conv's forward and weight-grad) / of dy (this conv's
+          input-grad and weight-grad) is a plane kernel -> no fp32 copy.  ``z_is_output``: z is handed to the caller (a
+          discriminator feature map, the end of a Sequential) -> it keeps its fp32 copy."""
+    if not ops.X3:
+        return False, False, False, False
     n, _, h, w = x.shape
-    dy_cm = z_cm = False
-    if isinstance(conv, Conv2d) and conv.stride == 2 and conv.in_channels != 3:
+    dy_cm = z_cm = dy_po = z_po = False
+    s2conv = isinstance(conv, Conv2d) and conv.stride == 2 and conv.in_channels != 3
+    s2convT = isinstance(conv, ConvTranspose2d) and conv.stride == 2 and conv.out_channels != 3
+    if s2conv:
         dy_cm = ops.x3_window_dgrad(n, h, w, conv.in_channels, conv.out_channels)
-    if isinstance(nxt, ConvTranspose2d) and nxt.stride == 2 and nxt.out_channels != 3:
+        dy_po = ops.x3_all_plane_readers(n, h, w, conv.in_channels, conv.out_channels, forward_is_dgrad=True)
+        ho, wo = h // 2, w // 2
+    elif s2convT:
+        # backward of the transposed conv: input-grad = a FORWARD-form conv of dy, weight-grad with dy in the x role
+        dy_po = ops.x3_all_plane_readers(n, 2 * h, 2 * w, conv.out_channels, conv.in_channels, forward_is_dgrad=False)
+        ho, wo = 2 * h, 2 * w
+    else:
+        ho, wo = (4, 4) if isinstance(conv, ConvTranspose2d) else (1, 1)
+    if not z_is_output and isinstance(nxt, ConvTranspose2d) and nxt.stride == 2 and nxt.out_channels != 3:
         # z = this group's output [n, nxt.in_channels, ho, wo]; the transposed conv's forward is the input-grad of a
         # Conv2d(nxt.out_channels -> nxt.in_channels) on a [2 ho, 2 wo] input
-        ho, wo = (h // 2, w // 2) if isinstance(conv, Conv2d) and conv.stride == 2 else ((2 * h, 2 * w) if conv.stride == 2 else (4, 4))
         z_cm = ops.x3_window_dgrad(n, 2 * ho, 2 * wo, nxt.out_channels, nxt.in_channels)
-    return z_cm, dy_cm
+        z_po = ops.x3_all_plane_readers(n, 2 * ho, 2 * wo, nxt.out_channels, nxt.in_channels, forward_is_dgrad=True)
+    elif not z_is_output and isinstance(nxt, Conv2d) and nxt.stride == 2 and nxt.in_channels != 3:
+        z_po = ops.x3_all_plane_readers(n, ho, wo, nxt.in_channels, nxt.out_channels, forward_is_dgrad=False)
+    return z_cm and ops.X3_CM, dy_cm and ops.X3_CM, z_po, dy_po
 
 
 def drain(gen):
@@ -227,10 +242,10 @@ def _run_fused_steps(layers, x):
             x = bn(y, act, slope, st)
         elif bn is not None:
             nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
-            z_cm, dy_cm = _plane_hints(conv, x, nxt)
+            z_cm, dy_cm, z_po, dy_po = _plane_hints(conv, x, nxt, z_is_output=nxt is None)
             y = conv(x)
             yield
-            x = bn(y, act, slope, None, z_cm, dy_cm)
+            x = bn(y, act, slope, None, z_cm, dy_cm, z_po, dy_po)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
             x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
         elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
@@ -276,10 +291,10 @@ class Discriminator(_FlatGradMixin, nn.Module):
                 y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
-                _, dy_cm = _plane_hints(conv, h, None)
+                _, dy_cm, _, dy_po = _plane_hints(conv, h, None, z_is_output=True)      # z is a feature map: it keeps its fp32 copy
                 y = conv(h)
                 yield
-                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, None, False, dy_cm)
+                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, None, False, dy_cm, False, dy_po)
             feats.append(h)
             yield
         out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))

@@ -88,6 +88,12 @@ class _hbm:
         return False
 
 
+def _need_fp32(t, who):
+    """Guard of the non-plane code paths: a plane-only tensor (X3_PLANES_ONLY) has no fp32 memory image to read."""
+    if getattr(t, "_dg_planes_only", False):
+        raise _lib.DiscoganHipError(f"{who}: the operand exists only as its plane triple, but this shape has no plane kernel")
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -96,7 +102,7 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def _check_dev(*ts, allow16=False):
+def _check_dev(*ts, allow16=False, planes_ok=False):
     """fp32 HIP tensors only.  allow16: the wrapper dispatches on the storage type itself (bf16 activation storage: the
     ``*_t`` / ``*_mixed`` entry points); every other wrapper calls an fp32-only kernel with numel() elements, where a bf16
     tensor would be read as floats past its end -- refused here instead."""
@@ -108,6 +114,9 @@ def _check_dev(*ts, allow16=False):
                 "discogan_modernized_amd ops need CUDA/HIP tensors (no CPU fallback exists); got a CPU tensor")
         if t.dtype != torch.float32 and not (allow16 and t.dtype == torch.bfloat16):
             raise _lib.DiscoganHipError(("fp32 or bf16" if allow16 else "fp32") + f" tensors required, got {t.dtype}")
+        if not planes_ok and getattr(t, "_dg_planes_only", False):
+            raise _lib.DiscoganHipError("this tensor exists only as its plane triple (ops.X3_PLANES_ONLY): its fp32 memory was never "
+                                        "written and this op would read it")
 
 
 # ---- layout helpers -------------------------------------------------------------------------------------
@@ -279,6 +288,11 @@ X3 = False
 # ([pixels/4][C/16][4][16], include/discogan_hip.h "plane_layout"): the window kernel then uses every byte of the 128-byte lines
 # it fetches instead of 32.  Bit-identical results; DG_X3_CM=0 keeps every triple pixel-major (A/B).
 X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
+# X3_PLANES_ONLY: a BatchNorm output whose every reader is a plane kernel (the next conv's forward and weight-grad; the
+# layer's own input-grad and weight-grad for a gradient) is written ONLY as its plane triple: the planes carry all 24 significand
+# bits (hi + mid + lo == the fp32 value), the fp32 tensor stays allocated but unwritten and is flagged ``_dg_planes_only`` --
+# every op wrapper that would read fp32 memory refuses such a tensor.  model.py decides per layer; DG_X3_PLANES_ONLY=0: off (A/B).
+X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
 _PLANE_TAB = {}
 
 
@@ -303,6 +317,8 @@ def planes_of(t, allow_cm=False):
     can read it (allow_cm); anybody else gets a pixel-major split of the fp32 tensor."""
     e = _PLANE_TAB.get(t.data_ptr())
     if e is None or e[0].shape != t.shape or e[0].stride() != t.stride() or (e[2] and not allow_cm):
+        if getattr(t, "_dg_planes_only", False):
+            raise _lib.DiscoganHipError("plane-only tensor without a usable plane triple (released, or in a layout this reader cannot take)")
         t3 = torch.empty((3, t.numel()), device=t.device, dtype=torch.bfloat16)
         with _hbm("x3_split", 10.0 * t.numel()):
             f32_to_bf16x3(t, t3)
@@ -310,6 +326,17 @@ def planes_of(t, allow_cm=False):
             planes_put(t, t3)
         return t3.data_ptr(), t3.stride(0) * 2, 0
     return e[1].data_ptr(), e[1].stride(0) * 2, int(e[2])
+
+
+def x3_all_plane_readers(n, h, wd, c, k, forward_is_dgrad=False, need_wgrad=True):
+    """Are the conv kernels that will READ a tensor all plane kernels?  For a layer input x of Conv2d(c, k, 4, 2, 1) on [n, c, h, wd]:
+    its forward (op 0) and weight-grad (op 2); with forward_is_dgrad (ConvTranspose2d: the same geometry read as an input-grad): op 1
+    and op 2.  For a gradient dy: the layer's input-grad (op 1) and weight-grad -- the same question with forward_is_dgrad."""
+    if not (X3 and X3_PLANES_ONLY):
+        return False
+    L = _lib.load()
+    first = 1 if forward_is_dgrad else 0
+    return L.dg_conv_x3_planes_ok(first, n, h, wd, c, k, 2, 1) >= 1 and (not need_wgrad or L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) >= 1)
 
 
 def x3_window_dgrad(n, h, wd, c, k):
@@ -379,7 +406,7 @@ def _mixed_operand(t, allow_shadow=True):
 def conv_fwd(x, w, stride, pad, want_stats=False):
     """nn.Conv2d(C,K,4,stride,pad,bias=False) forward. x NHWC-memory [N,C,H,W], w [K,C,4,4] KRSC.
     want_stats: also return the BatchNorm partial-statistics rows of y (None if the layer has no fused path)."""
-    _check_dev(x, allow16=True)
+    _check_dev(x, allow16=True, planes_ok=True)
     _check_dev(w)
     x = as_nhwc(x)
     w = _krsc(w)
@@ -399,6 +426,7 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
             _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
                        "dg_conv_fwd_x3")
         return (y, None) if want_stats else y
+    _need_fp32(x, "conv_fwd")
     mixed = False
     xa, x16, wa, w16, o16 = x, 0, w, 0, 0
     if k == 1:
@@ -433,7 +461,7 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
 def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     """Input-gradient of that Conv2d == ConvTranspose2d forward. dy [N,K,Ho,Wo]; returns [N,C,H,W]
     (and, with want_stats, the BatchNorm partial-statistics rows of the result or None)."""
-    _check_dev(dy, allow16=True)
+    _check_dev(dy, allow16=True, planes_ok=True)
     _check_dev(w)
     dy = as_nhwc(dy)
     w = _krsc(w)
@@ -453,6 +481,7 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
             _lib.check(L.dg_conv_dgrad_x3(dp, dd, dcm, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
                        "dg_conv_dgrad_x3")
         return (dx, None) if want_stats else dx
+    _need_fp32(dy, "conv_dgrad")
     mixed = False
     da, d16, wa, w16, o16 = dy, 0, w, 0, 0
     if k == 1:
@@ -517,7 +546,7 @@ def conv_dgrad_bias_act(x, w, bias, out_hw, stride, pad, act=ACT_NONE, slope=0.0
 
 def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     """Weight-gradient of that Conv2d: returns logical [K,C,4,4] (KRSC memory)."""
-    _check_dev(dy, x, allow16=True)
+    _check_dev(dy, x, allow16=True, planes_ok=True)
     dy = as_nhwc(dy)
     x = as_nhwc(x)
     n, c, h, wd = x.shape
@@ -532,6 +561,8 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
             _lib.check(L.dg_conv_wgrad_x3(dp, dd, dcm, xp, xd, _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate), _ptr(ws), wsb,
                                           _stream()), "dg_conv_wgrad_x3")
         return dw
+    _need_fp32(dy, "conv_wgrad")
+    _need_fp32(x, "conv_wgrad")
     da, d16, xa, x16 = dy, 0, x, 0
     if k == 1:
         x16 = int(_is16(x))
@@ -653,8 +684,9 @@ def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentu
     return saved
 
 
-def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False):
-    """planes_cm (f32x3 plane path): write z's plane triple chunk-major (its reader is a window input-grad kernel)."""
+def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False, planes_only=False):
+    """planes_cm (f32x3 plane path): write z's plane triple in the quad-chunk layout (its reader is a window input-grad kernel);
+    planes_only: every reader of z is a plane kernel -> the fp32 copy is not written (X3_PLANES_ONLY)."""
     _check_dev(y, allow16=True)
     y = as_nhwc(y)
     n, c, h, w = y.shape
@@ -667,11 +699,14 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False):
     z = empty_nhwc(n, c, h, w, y.device)
     if X3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
         z3 = torch.empty((3, z.numel()), device=y.device, dtype=torch.bfloat16)
-        with _hbm("bn_apply", 14.0 * n * h * w * c):
+        with _hbm("bn_apply", (10.0 if (planes_only and X3_PLANES_ONLY) else 14.0) * n * h * w * c):
             cm = int(bool(planes_cm) and c % 64 == 0 and (n * h * w) % 4 == 0)
-            _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), _ptr(z), _ptr(z3), z3.stride(0), cm, n * h * w, c, _ptr(saved), _ptr(gamma),
-                                                    _ptr(beta), act, slope, _stream()), "dg_bn_act_fwd_x3")
+            po = bool(planes_only) and X3_PLANES_ONLY
+            _lib.check(_lib.load().dg_bn_act_fwd_x3(_ptr(y), None if po else _ptr(z), _ptr(z3), z3.stride(0), cm, n * h * w, c, _ptr(saved),
+                                                    _ptr(gamma), _ptr(beta), act, slope, _stream()), "dg_bn_act_fwd_x3")
         planes_put(z, z3, cm)
+        if po:
+            z._dg_planes_only = True
         return z
     if SHADOW and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
@@ -686,7 +721,7 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False):
     return z
 
 
-def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None, planes_cm=False):
+def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True, out_grads=None, planes_cm=False, planes_only=False):
     """out_grads=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into those buffers in place.
     planes_cm (f32x3 plane path): write dy's plane triple chunk-major (its reader is a window input-grad kernel)."""
     _check_dev(dz, y, allow16=True)
@@ -714,11 +749,14 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
     dy = empty_nhwc(n, c, h, w, y.device)
     if X3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
         dy3 = torch.empty((3, dy.numel()), device=y.device, dtype=torch.bfloat16)
-        with _hbm("bn_backward", 26.0 * m * c):
+        po = bool(planes_only) and X3_PLANES_ONLY
+        with _hbm("bn_backward", (22.0 if po else 26.0) * m * c):
             cm = int(bool(planes_cm) and c % 64 == 0 and m % 4 == 0)
-            _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy3), dy3.stride(0), cm, m, c, _ptr(saved), _ptr(gamma), _ptr(beta),
-                                          act, slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_x3")
+            _lib.check(L.dg_bn_act_bwd_x3(_ptr(dz), _ptr(y), None if po else _ptr(dy), _ptr(dy3), dy3.stride(0), cm, m, c, _ptr(saved), _ptr(gamma),
+                                          _ptr(beta), act, slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_x3")
         planes_put(dy, dy3, cm)
+        if po:
+            dy._dg_planes_only = True
         return dy, dgamma, dbeta
     if SHADOW and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)

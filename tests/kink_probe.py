@@ -90,6 +90,9 @@ class record_masks_hip:
 
     def __enter__(self):
         from discogan_modernized_amd import model as M
+        from discogan_modernized_amd import ops
+        # the hooks read the fp32 outputs of the BatchNorm groups: keep them written while recording (f32x3 plane path)
+        self._po, ops.X3_PLANES_ONLY = ops.X3_PLANES_ONLY, False
         for k, net in self.nets.items():
             for m in net.modules():
                 if isinstance(m, M.BatchNorm2d) or (isinstance(m, M.Conv2d) and m.in_channels == 3):
@@ -98,6 +101,8 @@ class record_masks_hip:
         return self.masks
 
     def __exit__(self, *exc):
+        from discogan_modernized_amd import ops
+        ops.X3_PLANES_ONLY = self._po
         for h in self.handles:
             h.remove()
         return False

@@ -453,6 +453,34 @@ def test_f32x3_chunk_major_planes_are_bitwise_neutral(monkeypatch):
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
+def test_f32x3_plane_only_batchnorm_outputs_are_bitwise_neutral(monkeypatch):
+    """ops.X3_PLANES_ONLY: a BatchNorm output (or input gradient) whose every reader is a plane kernel is written only as its
+    plane triple -- hi + mid + lo IS the fp32 value, so nothing changes: 6 iterations with the switch on and off end in bitwise
+    identical weights and losses; the switch was really used; and an op that would read the unwritten fp32 memory refuses."""
+    A, B = synthetic_batch(2, 128, 3, DEV)
+    runs, used = [], []
+    for po in (False, True):
+        monkeypatch.setattr(ops, "X3_PLANES_ONLY", po)
+        flagged = []
+        orig = ops.planes_put
+        monkeypatch.setattr(ops, "planes_put", lambda t, t3, cm=False, _o=orig, _f=flagged: (_f.append(t), _o(t, t3, cm))[1])
+        tr = DiscoGANTrainer(default_args(), device=DEV, image_size=128, seed=1234, mfma_dtype="f32x3", x3_planes=True)
+        vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(6)]
+        torch.cuda.synchronize()
+        runs.append((vals, tr.optim_gen.flat_p.clone(), tr.optim_dis.flat_p.clone(), tr.generator_A.encoder[3].running_mean.clone()))
+        only = [t for t in flagged if getattr(t, "_dg_planes_only", False)]
+        used.append(len(only))
+        if po:
+            with pytest.raises(ops._lib.DiscoganHipError, match="only as its plane triple"):
+                ops.act_fwd(only[0], ops.ACT_RELU)
+            with pytest.raises(ops._lib.DiscoganHipError, match="plane-only tensor without"):
+                ops.planes_of(only[0])                         # its triple was released after the last reader
+        tr.close()
+        monkeypatch.setattr(ops, "planes_put", orig)
+    assert used[0] == 0 and used[1] > 0, f"plane-only tensors: {used}"
+    assert runs[0][0] == runs[1][0] and all(torch.equal(a, b) for a, b in zip(runs[0][1:], runs[1][1:]))
+
+
 def test_masked_fp64_gradient_parity_512():
     """The reference's own network (512 px, batch 2): D-step from the seeded init and a G-step from the same init,
     every gradient tensor against the fp64 oracle on the implementation's activation pattern.  Together with
@@ -884,10 +912,16 @@ def test_bf16_path_vs_reference_golden_512_n2(act_dtype):
 # ---- configs[4] (bf16 MFMA + fp32 BatchNorm accum) pinned to the reference at ITS OWN batch and on the generator side -----------------
 # One 512 px trainer serves every case: the arithmetic is a per-call switch (trainer.mfma_dtype / act_dtype / bf16_shadow are
 # read at every _fwd_bwd), the weights stay at the seeded init (do_step=False), BatchNorm buffers are restored between runs.
-BF16_GRAD_BOUNDS = {   # (batch, step, tensor group): (worst tensor, whole group) relative L2 against the fp32 HIP gradients; None = reported only
-    (2, "G", "decoder"): (9.9, 9.9), (2, "G", "encoder"): None,
-    (32, "D", "discriminator"): (9.9, 9.9),
-    (32, "G", "decoder"): (9.9, 9.9), (32, "G", "encoder"): (9.9, 9.9),
+BF16_GRAD_BOUNDS = {
+    # (batch, step, tensor group): (worst tensor, whole group, worst norm-vs-reference) -- relative L2 of the stepped side's gradients
+    # against the fp32 HIP gradients on the same batch / deviation of the tensor norms from the TRUE reference's recorded norms.
+    # Bounds = 1.5 x the measured values (profiles/r03_bf16_gradient_table_512px.json); None = reported only.
+    # Batch 2: every gradient passes BatchNorms over 2..32 samples per channel (the [N,100,1,1] bottleneck normalises over N),
+    # which amplify the operand rounding until direction is lost upstream of them (encoder: 4-7 x the gradient itself); only the
+    # decoder tensors' NORMS are held there.
+    (2, "G", "decoder"): (None, None, 0.20), (2, "G", "encoder"): (None, None, None),
+    (32, "D", "discriminator"): (0.50, 0.20, 0.08),
+    (32, "G", "decoder"): (0.67, 0.60, 0.08), (32, "G", "encoder"): (0.75, 0.66, 0.15),
 }
 
 
@@ -1006,13 +1040,10 @@ def test_bf16_path_vs_reference_golden_512_own_batch(fixture, N, trainer512_bf16
         if only_table:
             continue
         for grp, sm in summary.items():
-            bound = BF16_GRAD_BOUNDS[(N, rec["step"], grp)]
-            if bound is None:
-                continue
-            bt, bg = bound
-            assert sm["worst"] <= bt, f"bf16 ({act} maps) {fixture}: {grp} tensor {sm['worst_tensor']} is {sm['worst']:.3e} from the fp32 HIP gradient (bound {bt})"
-            assert sm["group_rel_l2"] <= bg, f"bf16 ({act} maps) {fixture}: {grp} gradients {sm['group_rel_l2']:.3e} from the fp32 HIP gradients (bound {bg})"
-            assert sm["worst_norm_dev_vs_reference"] <= bt, f"bf16 ({act} maps) {fixture}: a {grp} gradient norm is {sm['worst_norm_dev_vs_reference']:.3e} from the reference's"
+            bt, bg, bn = BF16_GRAD_BOUNDS[(N, rec["step"], grp)]
+            assert bt is None or sm["worst"] <= bt, f"bf16 ({act} maps) {fixture}: {grp} tensor {sm['worst_tensor']} is {sm['worst']:.3e} from the fp32 HIP gradient (bound {bt})"
+            assert bg is None or sm["group_rel_l2"] <= bg, f"bf16 ({act} maps) {fixture}: {grp} gradients {sm['group_rel_l2']:.3e} from the fp32 HIP gradients (bound {bg})"
+            assert bn is None or sm["worst_norm_dev_vs_reference"] <= bn, f"bf16 ({act} maps) {fixture}: a {grp} gradient norm is {sm['worst_norm_dev_vs_reference']:.3e} from the reference's (bound {bn})"
     outdir = os.environ.get("DG_TABLE_DIR")
     if outdir:
         os.makedirs(outdir, exist_ok=True)
