@@ -34,6 +34,10 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--variants", default="fp32,fp32_splitk4,f32x3")
+    ap.add_argument("--teacher_forced_steps", type=int, default=0,
+                    help="instead of the D-step / G-step from the seeded init: teacher-forced iterations 0..N-1 WITH the Adam steps "
+                         "(every iteration starts from the oracle's weights), i.e. iterations 2-3 run in the post-update, saturated-"
+                         "discriminator regime (one variant only)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -46,7 +50,10 @@ def main():
             _lib.set_option("splitk", int(v[len("fp32_splitk"):]))
         rows = []
         try:
-            T._teacher_forced(a.size, a.batch, 0, tr=tr, st=st, iter_list=[0, 1], step=False, rows_out=rows, noise_cache=cache, mfma_dtype=mf)
+            if a.teacher_forced_steps:
+                T._teacher_forced(a.size, a.batch, a.teacher_forced_steps, tr=tr, st=st, step=True, rows_out=rows, mfma_dtype=mf)
+            else:
+                T._teacher_forced(a.size, a.batch, 0, tr=tr, st=st, iter_list=[0, 1], step=False, rows_out=rows, noise_cache=cache, mfma_dtype=mf)
         except AssertionError as e:
             print(f"[{v}] bound exceeded: {e}", flush=True)
         finally:
@@ -55,7 +62,7 @@ def main():
         del tr
         torch.cuda.empty_cache()
         doc[v] = rows
-        for it in (0, 1):
+        for it in sorted({x["iter"] for x in rows}):
             r = sorted([x for x in rows if x["iter"] == it], key=lambda x: -x["ratio"])
             big = [x for x in r if x["ratio"] > 2]
             print(f"[{v}] iter {it}: worst ratio {r[0]['ratio']:.2f} ({r[0]['tensor']}), {len(big)} of {len(r)} tensors above 2; "

@@ -35,7 +35,7 @@ for k in sorted(set(fetch) & set(write)):
 fg, wg = means(sys.argv[1], "FETCH_SIZE", True), means(sys.argv[2], "WRITE_SIZE", True)
 out["igemm_by_grid"] = {}
 for k in sorted(set(fg) & set(wg)):
-    if ("igemm_kernel" in k or "igemm_dma_kernel" in k) and fg[k][1] >= 3:
+    if any(t in k for t in ("igemm_kernel", "igemm_dma_kernel", "igemm_dma_x3_kernel", "igemm_x3_dgw_kernel", "igemm_bf16_dgw_kernel")) and fg[k][1] >= 3:
         out["igemm_by_grid"][k] = {"launches": fg[k][1], "hbm_MB_per_launch": round((2 * fg[k][0] + wg[k][0]) / 1024, 2)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["kernels"].items():
