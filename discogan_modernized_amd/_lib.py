@@ -100,6 +100,7 @@ SIGNATURES = {
     "dg_conv_bf16_operands_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dg_f32_to_bf16x3": (_i, [_p, _p, _z, _z, _p]),
     "dg_adam_step_flat_x3": (_i, [_p, _p, _p, _p, _z, _p, _f, _f, _f, _f, _f, _p, _z, _p]),
+    "dg_conv4x4s2_c3_fwd_x3": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _p]),
     "dg_conv_x3_planes_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "dg_bn_act_fwd_x3": (_i, [_p, _p, _p, _z, _i, _i, _i, _p, _p, _p, _i, _f, _p]),
     "dg_bn_act_bwd_x3": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),

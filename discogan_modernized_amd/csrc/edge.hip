@@ -535,10 +535,16 @@ typedef float f32x2_g __attribute__((ext_vector_type(2)));
 // hi / mid / lo in registers (dg_split3: 24 significand bits) and every product block is the six MFMAs of igemm.hip's PREC 2
 // (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, smallest first): 36 MFMAs of 32 cycles per 32 pixels against the fp32 kernel's
 // 48 of 64 -- fp32-accurate products at 2.7x the matrix rate, so the kernel is bound by its loads and stores like the bf16 one.
-template <int ACT, bool OUT16, bool X3 = false>
+// PL (with X3): the epilogue also writes the three bf16 PLANES of y (pixel-major [pixel][64], `pstride` elements apart) -- the next
+// layer's weight-gradient reads them, and a stand-alone split pass over the 537 MB tensor (read 4 + write 6 bytes per element) is
+// replaced by 6 more bytes per element here.  The two accumulator blocks then hold the even / odd channels (like OUT16), so a lane
+// stores an 8-byte fp32 pair and one packed bf16 pair per plane.
+template <int ACT, bool OUT16, bool X3 = false, bool PL = false>
 __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
-                                                                 long npix, int ngroups, float slope, int xbytes) {
+                                                                 long npix, int ngroups, float slope, int xbytes,
+                                                                 __bf16* __restrict__ planes = nullptr, long pstride = 0) {
+    static_assert(!PL || (X3 && !OUT16), "planes are written by the f32x3 form with an fp32 output");
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* wp = w + (OUT16 ? 2 * p + nb : nb * 32 + p) * 48 + c * 16 + 8 * h;
+            const float* wp = w + ((OUT16 || PL) ? 2 * p + nb : nb * 32 + p) * 48 + c * 16 + 8 * h;
             const f32x4 lo = *(const f32x4*)wp, hi = *(const f32x4*)(wp + 4);
             bf16x8_e pl[NPL];
             split8((f32x8_e){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pl);
@@ -628,6 +634,26 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __
                 if (whole || pix0 + h * 4 + i < npix)
                     o16[i * (CF_K / 2)] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_e));
             }
+        } else if constexpr (PL) {
+            typedef __bf16 bf16x2_p __attribute__((ext_vector_type(2)));
+            typedef float f32x2_p __attribute__((ext_vector_type(2)));
+            float* o = y + (pix0 + h * 4) * CF_K + 2 * p;
+            __bf16* pb = planes + (pix0 + h * 4) * CF_K + 2 * p;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v >> 2) * 8 + (v & 3);
+                if (whole || pix0 + h * 4 + i < npix) {
+                    const f32x2_p pr = {dg_apply_act(acc0[v], ACT, slope), dg_apply_act(acc1[v], ACT, slope)};
+                    *(f32x2_p*)(o + i * CF_K) = pr;
+                    const bf16x2_p hi2 = __builtin_convertvector(pr, bf16x2_p);
+                    const f32x2_p r1 = pr - __builtin_convertvector(hi2, f32x2_p);
+                    const bf16x2_p mid2 = __builtin_convertvector(r1, bf16x2_p);
+                    const bf16x2_p lo2 = __builtin_convertvector(r1 - __builtin_convertvector(mid2, f32x2_p), bf16x2_p);
+                    *(bf16x2_p*)(pb + i * CF_K) = hi2;
+                    *(bf16x2_p*)(pb + pstride + i * CF_K) = mid2;
+                    *(bf16x2_p*)(pb + 2 * pstride + i * CF_K) = lo2;
+                }
+            }
         } else {
             float* o = y + (pix0 + h * 4) * CF_K + p;
 #pragma unroll
@@ -644,6 +670,34 @@ __global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __
         body(std::integral_constant<int, 0>{}, g);
         if (g + nwaves < ngroups) body(std::integral_constant<int, 1>{}, g + nwaves);
     }
+}
+
+// f32x3 path: conv1 forward (+ fused activation) that ALSO writes the plane triple of its output (see PL above).
+extern "C" int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float* y_nhwc, void* y_planes, size_t plane_elems, int N, int H,
+                                      int W, int K, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(x_nchw && w && y_nhwc && y_planes, "dg_conv4x4s2_c3_fwd_x3: null pointer");
+    DG_CHECK_ARG(K == CF_K, "dg_conv4x4s2_c3_fwd_x3: K must be %d", CF_K);
+    DG_CHECK_ARG(N >= 1 && dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd_x3: H, W must be powers of two");
+    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 2, "dg_conv4x4s2_c3_fwd_x3: plane output needs option bf16 = 2");
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd_x3: bad act %d", act);
+    const int Ho = H / 2, Wo = W / 2;
+    const long npix = (long)N * Ho * Wo;
+    DG_CHECK_ARG((long)N * 3 * H * W * 4 < (1L << 30) && npix < (1L << 30), "dg_conv4x4s2_c3_fwd_x3: tensors must be below 1 GiB");
+    DG_CHECK_ARG(plane_elems >= (size_t)npix * CF_K && plane_elems % 8 == 0, "dg_conv4x4s2_c3_fwd_x3: plane distance %zu for %ld elements", plane_elems, npix * CF_K);
+    const long ngroups = (npix + 31) / 32;
+    long wgs = (ngroups + 31) / 32;
+    if (wgs > 4096) wgs = 4096;
+    if (wgs < 1) wgs = 1;
+    hipStream_t st = (hipStream_t)stream;
+#define CFPL_LAUNCH(ACT)                                                                                                          \
+    hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true, true>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W, \
+                       dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4), (__bf16*)y_planes, (long)plane_elems)
+    if (act == DG_ACT_LEAKY) { CFPL_LAUNCH(DG_ACT_LEAKY); }
+    else if (act == DG_ACT_RELU) { CFPL_LAUNCH(DG_ACT_RELU); }
+    else { CFPL_LAUNCH(DG_ACT_NONE); }
+#undef CFPL_LAUNCH
+    DG_CHECK_LAUNCH("dg_conv4x4s2_c3_fwd_x3");
+    return DG_OK;
 }
 
 extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc_v, int y_bf16, int N, int H, int W, int act,

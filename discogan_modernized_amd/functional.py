@@ -165,8 +165,8 @@ class ConvC3Fn(Function):
     LeakyReLU fused (model.py:8-9, 80-81)."""
 
     @staticmethod
-    def forward(ctx, x, w, act, slope):
-        y = ops.c3_fwd(x, w, act, slope)
+    def forward(ctx, x, w, act, slope, want_planes=False):
+        y = ops.c3_fwd(x, w, act, slope, want_planes=want_planes)
         ctx.save_for_backward(x, w, y)
         ctx.act = (act, slope)
         ctx.wref = w
@@ -193,7 +193,7 @@ class ConvC3Fn(Function):
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.c3_wgrad(g, x, **fuse)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class ConvTransposeC3Fn(Function):

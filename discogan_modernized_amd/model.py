@@ -79,10 +79,11 @@ class Conv2d(nn.Module):
             w = ops.krsc_param(w)  # memory [K][4][4][C], logical shape unchanged
         self.weight = nn.Parameter(w)
 
-    def forward(self, x, fused_act=ops.ACT_NONE, slope=0.2, want_stats=False):
-        """want_stats (interior stride-2 layers): returns (y, BatchNorm partial statistics of y)."""
+    def forward(self, x, fused_act=ops.ACT_NONE, slope=0.2, want_stats=False, want_planes=False):
+        """want_stats (interior stride-2 layers): returns (y, BatchNorm partial statistics of y).
+        want_planes (3-channel first layer, f32x3 plane path): also write the plane triple of y for the next layer's weight-grad."""
         if self.in_channels == 3:
-            return F.ConvC3Fn.apply(x, self.weight, fused_act, slope)
+            return F.ConvC3Fn.apply(x, self.weight, fused_act, slope, want_planes)
         if want_stats:
             return F.ConvFn.apply(x, self.weight, self.stride, self.padding, want_stats)
         return F.ConvFn.apply(x, self.weight, self.stride, self.padding)
@@ -212,6 +213,19 @@ def _plane_hints(conv, x, nxt, z_is_output=False):
     return z_cm and ops.X3_CM, dy_cm and ops.X3_CM, z_po, dy_po
 
 
+C3_PLANES = __import__("os").environ.get("DG_X3_C3_PLANES", "1") != "0"      # A/B switch of _first_layer_planes
+
+
+def _first_layer_planes(x, nxt):
+    """f32x3 plane path: will the weight-gradient of the layer behind the 3-channel first conv read the first conv's output as a
+    plane triple?  (``nxt`` = that layer; only when its weights take gradients in this pass.)  Then the first conv writes the
+    triple itself instead of leaving a separate split pass over the network's largest activation to ``ops.planes_of``."""
+    if not (ops.X3 and C3_PLANES and isinstance(nxt, Conv2d) and nxt.stride == 2 and torch.is_grad_enabled() and nxt.weight.requires_grad):
+        return False
+    n, _, h, w = x.shape
+    return ops._x3_ok(2, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1)
+
+
 def drain(gen):
     """Run a ``*_steps`` generator to completion and return its value."""
     try:
@@ -247,7 +261,8 @@ def _run_fused_steps(layers, x):
             yield
             x = bn(y, act, slope, None, z_cm, dy_cm, z_po, dy_po)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
-            x = conv(x, act, slope)                         # conv1 + LeakyReLU in one kernel
+            nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
+            x = conv(x, act, slope, want_planes=_first_layer_planes(x, nxt))      # conv1 + LeakyReLU in one kernel
         elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
             x = conv(x, act)                                # last convT + Sigmoid in one kernel
         else:
@@ -283,7 +298,8 @@ class Discriminator(_FlatGradMixin, nn.Module):
     def forward_steps(self, input_tensor):
         """forward() as a generator that yields after every conv(+BN+act) group."""
         feats = []
-        h = self.conv1(input_tensor, ops.ACT_LEAKY, self.relu1.negative_slope)
+        h = self.conv1(input_tensor, ops.ACT_LEAKY, self.relu1.negative_slope,
+                       want_planes=_first_layer_planes(input_tensor, getattr(self, "conv2", None)))
         yield
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")

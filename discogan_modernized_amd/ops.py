@@ -583,13 +583,22 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
 
 
 # ---- 3-channel edge layers ------------------------------------------------------------------------------
-def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2):
-    """x contiguous NCHW [N,3,H,W], w contiguous [K,3,4,4] -> NHWC-memory [N,K,H/2,W/2] (act fused)."""
+def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2, want_planes=False):
+    """x contiguous NCHW [N,3,H,W], w contiguous [K,3,4,4] -> NHWC-memory [N,K,H/2,W/2] (act fused).
+    want_planes (f32x3 plane path): the kernel also writes the plane triple of its output (the next layer's weight-gradient reads it)."""
     _check_dev(x_nchw, w)
     x = x_nchw.contiguous()
     w = w.contiguous()
     n, _, h, wd = x.shape
     k = w.shape[0]
+    if want_planes and X3 and k == 64 and x.numel() * 4 < (1 << 30) and n * (h // 2) * (wd // 2) < (1 << 30):
+        y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
+        y3 = torch.empty((3, y.numel()), device=x.device, dtype=torch.bfloat16)
+        with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), _hbm("edge_c3_fwd", 4.0 * x.numel() + 10.0 * y.numel()):
+            _lib.check(_lib.load().dg_conv4x4s2_c3_fwd_x3(_ptr(x), _ptr(w), _ptr(y), _ptr(y3), y3.stride(0), n, h, wd, k, act, slope, _stream()),
+                       "dg_conv4x4s2_c3_fwd_x3")
+        planes_put(y, y3)
+        return y
     o16 = ACT16 and k == 64 and x.numel() * 4 < (1 << 30)
     y = empty_nhwc(n, k, h // 2, wd // 2, x.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), \

@@ -337,6 +337,10 @@ int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elem
 int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,
                      const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
                      float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+/* conv1 forward (+ fused activation) on the f32x3 path that also writes the plane triple of its output (pixel-major), so the next
+ * layer's weight-gradient needs no separate split pass over the largest activation of the network (K == 64, tensors < 1 GiB) */
+int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float* y_nhwc, void* y_planes, size_t plane_elems, int N, int H, int W,
+                           int K, int act, float slope, dg_stream_t stream);
 /* 0: no plane kernel for this (op, shape); 1: yes; 2: yes -- the window input-grad kernel, which prefers dy_layout 1 */
 int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
 int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, int w_transposed, float* y,

@@ -1032,3 +1032,25 @@ def test_edge_dgrad_on_the_f32x3_path(N, H):
     assert e3 <= 2 * e32 + 2e-8, f"f32x3 edge dgrad: relative L2 {e3:.2e} vs fp64 (fp32 MFMA kernel: {e32:.2e})"
     close(d3, raw64.float(), rtol=2e-6, what="c3_dgrad f32x3")
     close(d3s, torch.sigmoid(raw64).float(), rtol=2e-6, atol=1e-6, what="c3_dgrad f32x3 + sigmoid")
+
+
+@pytest.mark.parametrize("N,S", [(2, 16), (3, 64), (1, 256)])
+def test_edge_forward_writes_the_plane_triple_of_its_output(N, S):
+    """f32x3 plane path: conv1's forward kernel also writes hi / mid / lo of its output (dg_conv4x4s2_c3_fwd_x3), so the next layer's
+    weight-gradient needs no separate split pass.  The fp32 output is the plain f32x3 kernel's bit for bit (the two accumulator
+    blocks hold even / odd channels instead of halves: same products, same order per element), the planes are dg_f32_to_bf16x3 of it."""
+    x, w = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(1)).to(DEV), rnd(64, 3, 4, 4, seed=2, scale=0.2).to(DEV)
+    _lib.set_option("bf16", 2)
+    ops.X3 = True
+    try:
+        for act in (ops.ACT_LEAKY, ops.ACT_NONE):
+            y0 = ops.c3_fwd(x, w, act, 0.2)
+            y1 = ops.c3_fwd(x, w, act, 0.2, want_planes=True)
+            t3 = ops._PLANE_TAB[y1.data_ptr()][1]
+            assert torch.equal(y0, y1)
+            ref = ops.f32_to_bf16x3(y1, torch.empty((3, y1.numel()), device=DEV, dtype=torch.bfloat16))
+            assert torch.equal(t3, ref) and torch.equal(t3.float().sum(0), y1.permute(0, 2, 3, 1).reshape(-1))
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("bf16", 0)
