@@ -42,6 +42,16 @@ facescrub_path = dataset_path / "facescrub"
 IMAGE_EXTS = ("*.jpg", "*.png")
 
 
+def set_root(root="./datasets"):
+    """Point every dataset path at ``root`` (the reference edits its module-level paths by hand, dataset.py:13-22)."""
+    global dataset_path, celebA_path, handbag_path, shoe_path, facescrub_path
+    dataset_path = Path(root)
+    celebA_path = dataset_path / "celebA"
+    handbag_path = dataset_path / "edges2handbags"
+    shoe_path = dataset_path / "edges2shoes"
+    facescrub_path = dataset_path / "facescrub"
+
+
 # ---- file lists -------------------------------------------------------------------------------------------------------
 def read_attr_file(attr_path, image_dir):
     """CelebA ``list_attr_celeba.txt`` (line 0: count, line 1: attribute names, then ``file v1 v2 ...``) ->

@@ -147,10 +147,7 @@ def open_data(args, device, rank=0, world_size=1):
     """The training data behind one interface (``.size``, ``.epoch(index batches, start)``), chosen by --data_source."""
     from . import dataset as ds
     src = getattr(args, "data_source", "auto")
-    if getattr(args, "data_root", None):
-        root = ds.Path(args.data_root)
-        ds.dataset_path, ds.celebA_path, ds.handbag_path = root, root / "celebA", root / "edges2handbags"
-        ds.shoe_path, ds.facescrub_path = root / "edges2shoes", root / "facescrub"
+    ds.set_root(getattr(args, "data_root", None) or "./datasets")      # every run states its root: nothing leaks from an earlier call
     if src == "auto":
         if args.data_A and args.data_B:
             src = "tensors"
