@@ -1087,6 +1087,7 @@ struct Plan {
 int dg_igemm_dma_launch(int mode, const IgemmArgs& a, int zmul, hipStream_t st);      // igemm_dma.hip
 int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st);   // igemm_dma_x3.hip
 int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st);                              // igemm_dma_x3_dgw.hip
+int dg_igemm_x3_fww_launch(const IgemmArgs& a, hipStream_t st);                                        // igemm_dma_x3_fww.hip
 int dg_igemm_bf16_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st);                            // igemm_dma_dgw.hip
 
 static int reduce_stats_rchunks(long R, int Ng) {
@@ -1211,13 +1212,20 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
             pl->ncls = g.C <= 64 ? 4 : 2;
             a.nIt = g.K / 16;                       // the split unit is a 16-channel chunk (4 tap steps)
         }
+        // forward with <= 128 output channels: the input window of one (chunk, parity class) in LDS, re-used by the class's four taps
+        // (igemm_dma_x3_fww.hip); whole output rows per 256-pixel tile, transposed weight planes; no split-K
+        else if (pl->mode == MODE_FWD && g.stride == 2 && g.pad == 1 && g.K <= 128 && g.K % 8 == 0 && g.C % 16 == 0 && g.Wo >= 32 &&
+                 g.Wo <= 128 && (g.Ho * g.Wo) % 256 == 0 && dg_get_option(DG_OPT_DMA_MFMA) != 1) {
+            pl->dma = 5;
+            pl->ncls = 4;
+        }
     }
     const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm);
     const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma >= 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
     const int base = a.tilesM * a.tilesN * (pl->dma >= 3 ? 4 / pl->ncls : zmul);
-    a.splits = choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
+    a.splits = pl->dma == 5 ? 1 : choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
     // measured (PMC, MB per launch beyond L2, 64 px layers): forward 83 -> 76, weight-grad 222 -> 90, input-grad with
@@ -1280,7 +1288,8 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
     if (pl.dma) {
-        const int ok = pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
+        const int ok = pl.dma == 5 ? dg_igemm_x3_fww_launch(a, st)
+                     : pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
                      : pl.dma == 3 ? dg_igemm_x3_dgw_launch(pl.ncls, a, st)
                      : pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
         if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
@@ -1506,7 +1515,8 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no plane form", who);
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
-    if (pl.dma != 2 && pl.dma != 3) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
+    if (pl.dma != 2 && pl.dma != 3 && pl.dma != 5) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
+    if (pl.dma == 5 && !b_transposed) return dg_fail(DG_ERR_INVALID, "%s: the window forward kernel reads the TRANSPOSED weight planes (dg_x3_transpose_planes)", who);
     DG_CHECK_ARG(a_plane >= (long)pl.a.abytes && b_plane >= (long)pl.a.bbytes && a_plane % 16 == 0 && b_plane % 16 == 0,
                  "%s: plane distances %ld / %ld (operands are %u / %u bytes per plane)", who, a_plane, b_plane, pl.a.abytes, pl.a.bbytes);
     pl.a.A = (const float*)a3; pl.a.B = (const float*)b3; pl.a.C = out; pl.a.accumulate = accumulate;
@@ -1533,7 +1543,8 @@ extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, int dy_layout, c
                                 int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     return conv_x3(2, dy3, dy_plane, x3, x_plane, 0, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream, dy_layout);
 }
-// does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)  0: no; 1: yes; 2: yes, and it is the
+// does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)  0: no; 1: yes; 3: yes -- the window
+// FORWARD kernel, which needs the transposed weight planes (w_transposed = 1 of dg_conv_fwd_x3); 2: yes, and it is the
 // window input-grad kernel, which wants its gradient operand in the quad-chunk layout (plane_layout 1 of dg_bn_act_*_x3)
 extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
@@ -1541,7 +1552,7 @@ extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, i
     if (dg_get_option(DG_OPT_BF16) != 2) return 0;
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
-    return pl.dma == 3 ? (K % 64 == 0 ? 2 : 1) : (pl.dma == 2 ? 1 : 0);
+    return pl.dma == 5 ? 3 : (pl.dma == 3 ? (K % 64 == 0 ? 2 : 1) : (pl.dma == 2 ? 1 : 0));
 }
 
 // ---- inference path: conv with BatchNorm folded in (scale in the weights, shift as a bias) + activation ----------

@@ -217,13 +217,16 @@ C3_PLANES = __import__("os").environ.get("DG_X3_C3_PLANES", "1") != "0"      # A
 
 
 def _first_layer_planes(x, nxt):
-    """f32x3 plane path: will the weight-gradient of the layer behind the 3-channel first conv read the first conv's output as a
-    plane triple?  (``nxt`` = that layer; only when its weights take gradients in this pass.)  Then the first conv writes the
-    triple itself instead of leaving a separate split pass over the network's largest activation to ``ops.planes_of``."""
-    if not (ops.X3 and C3_PLANES and isinstance(nxt, Conv2d) and nxt.stride == 2 and torch.is_grad_enabled() and nxt.weight.requires_grad):
+    """f32x3 plane path: will the layer behind the 3-channel first conv read the first conv's output as a plane triple -- in its
+    FORWARD (the window forward kernel, any pass) or in its weight-gradient (only when its weights take gradients in this pass)?
+    Then the first conv writes the triple itself instead of leaving a separate split pass over the network's largest activation to
+    ``ops.planes_of``."""
+    if not (ops.X3 and C3_PLANES and isinstance(nxt, Conv2d) and nxt.stride == 2):
         return False
     n, _, h, w = x.shape
-    return ops._x3_ok(2, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1)
+    if ops._x3_ok(0, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1) and getattr(nxt.weight, "_dg_x3", (None, 0, None))[2] is not None:
+        return True
+    return torch.is_grad_enabled() and nxt.weight.requires_grad and ops._x3_ok(2, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1)
 
 
 def drain(gen):

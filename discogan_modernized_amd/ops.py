@@ -293,6 +293,13 @@ X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
 # bits (hi + mid + lo == the fp32 value), the fp32 tensor stays allocated but unwritten and is flagged ``_dg_planes_only`` --
 # every op wrapper that would read fp32 memory refuses such a tensor.  model.py decides per layer; DG_X3_PLANES_ONLY=0: off (A/B).
 X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
+# X3_FWW: forward convolutions with <= 128 output channels on the window forward kernel (csrc/igemm_dma_x3_fww.hip; planner code 3:
+# needs the transposed weight planes); DG_X3_FWW=0 keeps them on the register-staged f32x3 tiles (A/B).
+X3_FWW = __import__("os").environ.get("DG_X3_FWW", "1") != "0"
+
+
+def _plane_code_ok(code):
+    return code >= 1 and (code != 3 or X3_FWW)
 _PLANE_TAB = {}
 
 
@@ -336,7 +343,7 @@ def x3_all_plane_readers(n, h, wd, c, k, forward_is_dgrad=False, need_wgrad=True
         return False
     L = _lib.load()
     first = 1 if forward_is_dgrad else 0
-    return L.dg_conv_x3_planes_ok(first, n, h, wd, c, k, 2, 1) >= 1 and (not need_wgrad or L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) >= 1)
+    return _plane_code_ok(L.dg_conv_x3_planes_ok(first, n, h, wd, c, k, 2, 1)) and (not need_wgrad or L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) >= 1)
 
 
 def x3_window_dgrad(n, h, wd, c, k):
@@ -387,7 +394,7 @@ def weight_planes(w, transposed=False):
 
 
 def _x3_ok(op, n, h, wd, c, k, stride, pad):
-    return X3 and k > 1 and _lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad) >= 1
+    return X3 and k > 1 and _plane_code_ok(_lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad))
 
 
 # ---- interior convolutions ------------------------------------------------------------------------------
@@ -418,14 +425,16 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
-    if rows == 0 and _x3_ok(0, n, h, wd, c, k, stride, pad):
-        xp, xd, _ = planes_of(x)
+    code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (rows == 0 and X3 and k > 1) else 0
+    if code >= 1:
         wp, wdist, wt = weight_planes(w, transposed=True)
-        y = empty_nhwc(n, k, ho, wo, x.device)
-        with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
-            _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                       "dg_conv_fwd_x3")
-        return (y, None) if want_stats else y
+        if code != 3 or (wt and X3_FWW):         # 3 = the window forward kernel: it reads the TRANSPOSED weight planes only
+            xp, xd, _ = planes_of(x)
+            y = empty_nhwc(n, k, ho, wo, x.device)
+            with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
+                _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
+                           "dg_conv_fwd_x3")
+            return (y, None) if want_stats else y
     _need_fp32(x, "conv_fwd")
     mixed = False
     xa, x16, wa, w16, o16 = x, 0, w, 0, 0

@@ -139,9 +139,10 @@ def test_conv_planner_dispatch_at_512px_batch32():
         _lib.set_option("bf16", 2)           # f32x3: plane kernels (igemm_dma_x3.hip; narrow input-grads: igemm_dma_x3_dgw.hip)
         for C, K, H in layers:
             got = [L.dg_conv_x3_planes_ok(op, 32, H, H, C, K, 2, 1) for op in (0, 1, 2)]
-            # forward with < 192 columns stays on the register-staged split; every input-grad has a plane kernel (>= 192 columns:
-            # 256 x 256 tile = 1; <= 128: the window kernel = 2, which takes its gradient operand chunk-major) and so has every weight-grad
-            want = [int(K >= 192), 2 if C <= 128 else 1, 1]
+            # every forward has a plane kernel (>= 192 columns: 256 x 256 tile = 1; <= 128: the window forward kernel = 3, which reads the
+            # transposed weight planes), every input-grad (>= 192 columns: 1; <= 128: the window kernel = 2, which takes its gradient
+            # operand in the quad-chunk layout) and every weight-grad
+            want = [1 if K >= 192 else 3, 2 if C <= 128 else 1, 1]
             assert got == want, (C, K, H, got, want)
         _lib.set_option("bf16", 1)           # bf16: 2 = LDS-DMA kernel (igemm_dma.hip) or the window kernel, 1 = register-staged tiles
         for C, K, H in layers:

@@ -1054,3 +1054,45 @@ def test_edge_forward_writes_the_plane_triple_of_its_output(N, S):
         ops.X3 = False
         ops.planes_clear()
         _lib.set_option("bf16", 0)
+
+
+X3_FWW_SHAPES = [
+    (1, 64, 128, 256),     # the benchmark layer: Wo = 128, two output rows per tile, 16 super-chunks
+    (3, 48, 104, 128),     # ragged: 104 of 128 columns, 3 chunks; Wo = 64
+    (1, 16, 8, 64),        # one chunk, 8 columns; Wo = 32: eight output rows per tile
+    (2, 128, 64, 64),      # 8 chunks, 64 columns
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", X3_FWW_SHAPES)
+def test_conv_f32x3_forward_window_kernel(N, C, K, H):
+    """Forward with few output channels on plane operands (csrc/igemm_dma_x3_fww.hip): the input window of one (16-channel chunk,
+    input-parity class) in LDS, re-used by the class's four taps; transposed weight planes.  fp32 tolerance against the fp64
+    convolution, at most 2x the exact-fp32 MFMA kernel's distance from it, borders (the conv's zero padding = out-of-range window
+    pixels) and ragged column counts included; without transposed weight planes the register-staged tiles take the shape."""
+    x, w = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    y64 = TF.conv2d(x.double(), w.double(), stride=2, padding=1)
+    xg, wg = nhwc(x), krsc(w)
+    e32 = _rel(ops.conv_fwd(xg, wg, 2, 1), y64)
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    try:
+        yreg = ops.conv_fwd(xg, wg, 2, 1)
+        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == 3
+        ops.X3 = True
+        y_nt = ops.conv_fwd(xg, wg, 2, 1)                      # no transposed planes: register-staged tiles, same bits
+        assert torch.equal(y_nt, yreg)
+        buf = torch.empty((3, wg.numel()), device=DEV, dtype=torch.bfloat16)
+        wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
+        ops.planes_clear()
+        y = ops.conv_fwd(xg, wg, 2, 1)
+        torch.cuda.synchronize()
+        assert len(ops._PLANE_TAB) == 1                        # x was split into planes: the window kernel ran
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("bf16", 0)
+    close(y, y64.float(), what="window forward")
+    close(y, yreg, rtol=2e-5, atol=2e-6, what="window forward vs register-staged f32x3")
+    e3 = _rel(y, y64)
+    assert e3 <= 2.0 * e32 + 2e-7, f"window forward: {e3:.2e} vs fp64 (exact-fp32 MFMA kernel: {e32:.2e})"
