@@ -1058,8 +1058,8 @@ def test_edge_forward_writes_the_plane_triple_of_its_output(N, S):
 
 X3_FWW_SHAPES = [
     (1, 64, 128, 256),     # the benchmark layer: Wo = 128, two output rows per tile, 16 super-chunks
-    (3, 48, 104, 128),     # ragged: 104 of 128 columns, 3 chunks; Wo = 64
-    (1, 16, 8, 64),        # one chunk, 8 columns; Wo = 32: eight output rows per tile
+    (3, 96, 104, 128),     # ragged: 104 of 128 columns, 6 chunks; Wo = 64
+    (1, 32, 8, 64),        # two chunks, 8 columns; Wo = 32: eight output rows per tile
     (2, 128, 64, 64),      # 8 chunks, 64 columns
 ]
 
