@@ -1049,13 +1049,18 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_bf16mfma_kernel(const float* 
 //   s = 2: x[2 ox + 1] -> O[ox]                                 s = 3: x[2 ox + 2] -> E1[ox] (E1[Wo-1] = 0: right padding)
 // Rows above / below the image are staged as zeros.  Two LDS stages: the next output row is staged while the current one is
 // multiplied; the A operand (dy, one dword = two channels of a pixel) is loaded as in the kernel above.
+// X3 (fp32 dy / act_out, option "bf16" = 2: the f32x3 path): the image rows stay FP32 in LDS (101 KB, one workgroup per CU), dy is
+// loaded as fp32 pairs; both operands are split into their three bf16 planes in registers in front of the MFMAs and every block is
+// the six plane products of igemm.hip's PREC 2 -- fp32-accurate, 24 MFMAs of 32 cycles per 16 pixels and wave where the fp32-MFMA
+// kernel above needs 96 of 64, with coalesced image loads instead of its 24-lines-per-instruction gathers.
 #define CWL_WOMAX 256
-template <bool FACT>
-__global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool FACT, bool X3 = false>
+__global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ part, int N, int H, int W, int K,
                                                               long npix, int rows_per_wg, const float* __restrict__ act_out, float slope) {
-    constexpr int ROWE = CWL_WOMAX + 8;                       // bf16 elements per LDS array row (zero tail)
-    __shared__ __attribute__((aligned(16))) __bf16 img[2][4][12][ROWE];      // [stage][s][c * 4 + r][ox]
+    constexpr int ROWE = CWL_WOMAX + 8;                       // elements per LDS array row (zero tail)
+    typedef typename std::conditional<X3, float, __bf16>::type ET;           // element type of the staged image rows
+    __shared__ __attribute__((aligned(16))) ET img[2][4][12][ROWE];          // [stage][s][c * 4 + r][ox]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -1081,10 +1086,15 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __res
     const int nrows = N * Ho;
     const int u0 = blockIdx.x * rows_per_wg, u1 = min(nrows, u0 + rows_per_wg);
     constexpr int BIG = 0x40000000;
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(npix * K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, (int)(npix * K * 2), 0x00020000);
+    constexpr int EB = X3 ? 4 : 2;                            // bytes per dy / act_out element
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(npix * K * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? act_out : dy), 0, (int)(npix * K * EB), 0x00020000);
     auto bload = [](const __amdgpu_buffer_rsrc_t& r, int off) -> unsigned {
         return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    };
+    typedef float f32x2_w __attribute__((ext_vector_type(2)));
+    auto bload2 = [](const __amdgpu_buffer_rsrc_t& r, int off) -> f32x2_w {
+        return __builtin_bit_cast(f32x2_w, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
     };
     // ---- staging of output row u: 12 input rows x W / 4 float4 chunks over 256 threads (<= 6 per thread).  The global loads
     // are issued BEFORE the current row's MFMAs (into registers), converted and written to the other LDS stage after them
@@ -1108,38 +1118,89 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __res
             const int e = tid + 256 * k;
             if (e >= chunks) continue;
             const int rowi = e / wq, m = e - rowi * wq;          // rowi = c * 4 + r, chunk m = columns 4m .. 4m+3
-            typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
-            typedef __bf16 bf16x2_s __attribute__((ext_vector_type(2)));
-            const bf16x4_s b = __builtin_convertvector(sv[k], bf16x4_s);          // x[4m], x[4m+1], x[4m+2], x[4m+3]
-            __bf16* E = &img[st][1][rowi][0];
-            __bf16* O = &img[st][2][rowi][0];
-            __bf16* O0 = &img[st][0][rowi][0];
-            __bf16* E1 = &img[st][3][rowi][0];
-            *(bf16x2_s*)(E + 2 * m) = (bf16x2_s){b[0], b[2]};
-            *(bf16x2_s*)(O + 2 * m) = (bf16x2_s){b[1], b[3]};
+            typedef ET etx4_s __attribute__((ext_vector_type(4)));
+            typedef ET etx2_s __attribute__((ext_vector_type(2)));
+            const etx4_s b = __builtin_convertvector(sv[k], etx4_s);              // x[4m], x[4m+1], x[4m+2], x[4m+3]
+            ET* E = &img[st][1][rowi][0];
+            ET* O = &img[st][2][rowi][0];
+            ET* O0 = &img[st][0][rowi][0];
+            ET* E1 = &img[st][3][rowi][0];
+            *(etx2_s*)(E + 2 * m) = (etx2_s){b[0], b[2]};
+            *(etx2_s*)(O + 2 * m) = (etx2_s){b[1], b[3]};
             O0[2 * m + 1] = b[1];                                             // x[2 ox - 1] at ox = 2m + 1
             if (2 * m + 2 < Wo) O0[2 * m + 2] = b[3];
             E1[2 * m] = b[2];                                                 // x[2 ox + 2] at ox = 2m
             if (m > 0) E1[2 * m - 1] = b[0];
-            if (m == 0) O0[0] = (__bf16)0.f;
-            if (2 * m + 2 == Wo) E1[Wo - 1] = (__bf16)0.f;
+            if (m == 0) O0[0] = (ET)0.f;
+            if (2 * m + 2 == Wo) E1[Wo - 1] = (ET)0.f;
         }
     };
     // ---- A operand of batch b of row u: 8 pixels per lane, one dword (two channels) each
-    unsigned wa[2][8], wo[2][FACT ? 8 : 1];
+    unsigned wa[2][X3 ? 1 : 8], wo[2][(FACT && !X3) ? 8 : 1];
+    f32x2_w fa2[2][X3 ? 8 : 1], fo2[2][(FACT && X3) ? 8 : 1];      // X3: fp32 pairs (channels 2 l31, 2 l31 + 1) of the lane's 8 pixels
     const int nbatch = Wo >> 4;
     auto load_a = [&](int set, int u, int b) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int pp = u * Wo + 16 * b + 8 * lh + t;
-            const int aoff = (u < u1 && b < nbatch) ? (pp * K + kg * 64 + 2 * l31) * 2 : BIG;
-            wa[set][t] = bload(rdy, aoff);
-            if constexpr (FACT) wo[set][t] = bload(rao, aoff);
+            const int aoff = (u < u1 && b < nbatch) ? (pp * K + kg * 64 + 2 * l31) * EB : BIG;
+            if constexpr (X3) {
+                fa2[set][t] = bload2(rdy, aoff);
+                if constexpr (FACT) fo2[set][t] = bload2(rao, aoff);
+            } else {
+                wa[set][t] = bload(rdy, aoff);
+                if constexpr (FACT) wo[set][t] = bload(rao, aoff);
+            }
         }
     };
     typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
     typedef unsigned u32x4_l __attribute__((ext_vector_type(4)));
+    typedef float f32x8_l __attribute__((ext_vector_type(8)));
+    auto split8 = [](const f32x8_l& v, bf16x8_l* pl) {
+        pl[0] = __builtin_convertvector(v, bf16x8_l);
+        const f32x8_l r1 = v - __builtin_convertvector(pl[0], f32x8_l);
+        pl[1] = __builtin_convertvector(r1, bf16x8_l);
+        pl[2] = __builtin_convertvector(r1 - __builtin_convertvector(pl[1], f32x8_l), bf16x8_l);
+    };
+    auto mma_x3 = [&](int set, int st, int b) {
+        if constexpr (X3) {
+            f32x8_l a0, a1;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x2_w v = fa2[set][t];
+                if constexpr (FACT) {
+                    const f32x2_w o = fo2[set][t];
+                    v[0] = o[0] > 0.f ? v[0] : v[0] * slope;
+                    v[1] = o[1] > 0.f ? v[1] : v[1] * slope;
+                }
+                a0[t] = v[0];
+                a1[t] = v[1];
+            }
+            bf16x8_l pa0[3], pa1[3];
+            split8(a0, pa0);
+            split8(a1, pa1);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (dy plane, image plane), smallest product first
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const float* src = (const float*)&img[st][jarr[jn]][jrow[jn]][16 * b + 8 * lh];
+                const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+                f32x8_l bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (!jok[jn]) bv = (f32x8_l){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                bf16x8_l pb[3];
+                split8(bv, pb);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0[PA[q]], pb[PB[q]], acc[0][jn], 0, 0, 0);
+                    acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[PA[q]], pb[PB[q]], acc[1][jn], 0, 0, 0);
+                }
+            }
+        }
+    };
     auto mma = [&](int set, int st, int b) {
+        if constexpr (X3) {
+            mma_x3(set, st, b);
+            return;
+        } else {
         unsigned w8[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -1165,7 +1226,7 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __res
         bf16x8_l fb[2];
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
-            fb[jn] = *(const bf16x8_l*)&img[st][jarr[jn]][jrow[jn]][16 * b + 8 * lh];
+            fb[jn] = *(const bf16x8_l*)(const void*)&img[st][jarr[jn]][jrow[jn]][16 * b + 8 * lh];
             if (!jok[jn]) fb[jn] = __builtin_bit_cast(bf16x8_l, (u32x4_l){0u, 0u, 0u, 0u});
         }
 #pragma unroll
@@ -1173,10 +1234,11 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_lds_kernel(const float* __res
             acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[jn], acc[0][jn], 0, 0, 0);
             acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[jn], acc[1][jn], 0, 0, 0);
         }
+        }
     };
     // zero the tails of the LDS rows once (columns >= Wo are never written by the staging; batches never reach them, but keep
     // the arrays defined)
-    for (int e = tid; e < 2 * 4 * 12 * ROWE; e += 256) (&img[0][0][0][0])[e] = (__bf16)0.f;
+    for (int e = tid; e < 2 * 4 * 12 * ROWE; e += 256) (&img[0][0][0][0])[e] = (ET)0.f;
     __syncthreads();
     if (u0 < u1) {
         stage_load(u0);
@@ -1300,6 +1362,22 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
                        K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
     if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
+    if (!io_bf16 && buf && dg_get_option(DG_OPT_BF16) == 2 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
+        // f32x3 path: fp32-accurate plane products on the bf16 MFMA, image rows staged through LDS (fp32)
+        const int nrows = N * (H / 2);
+        const int rpw = (nrows + nb - 1) / nb;
+        if (fact)
+            hipLaunchKernelGGL((c3_wgrad_lds_kernel<true, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
+                               npix, rpw, act_out, slope);
+        else
+            hipLaunchKernelGGL((c3_wgrad_lds_kernel<false, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
+                               npix, rpw, act_out, slope);
+        DG_CHECK_LAUNCH("c3_wgrad_lds_x3");
+        const int total = K * 48;
+        hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);
+        DG_CHECK_LAUNCH("c3_wgrad_reduce");
+        return DG_OK;
+    }
     if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
         // bf16 matrix path, image rows staged through LDS: the same nb slabs, a contiguous range of output rows per workgroup
         const int nrows = N * (H / 2);

@@ -76,7 +76,13 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     const int n_img = m0 >> lgHW, a0 = (m0 >> lgWo) & (Ho - 1);
     const int WR = (256 / Wo + 2) * WW;                       // window rows
     const int wpieces = (WR + 31) >> 5;
-    const int nSC = (Cc >> 4) * 4;                            // super-chunks: (channel chunk, parity class)
+    const int nCh = Cc >> 4;
+    const int nSC = nCh * 4;                                  // super-chunks: (channel chunk, parity class)
+    // order of the super-chunks: class-major (the chunks of one parity class back to back: the 128-byte lines of a pixel -- 4
+    // chunks of 32 bytes -- are requested in consecutive steps) or chunk-major (dbg_zero bit 2: timing experiment)
+    const bool cmaj = (p.dbg_zero & 4) != 0;
+    auto sc_c = [&](int sc) -> int { return cmaj ? (sc >> 2) : (sc % nCh); };
+    auto sc_q = [&](int sc) -> int { return cmaj ? (sc & 3) : (sc / nCh); };
 
     constexpr int OOR = (int)0x80000000;
     __amdgpu_buffer_rsrc_t rA[3], rB[3];
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     };
     // the whole window (three planes) of super-chunk sc into window stage `ast`
     auto issue_window = [&](int ast, int sc) {
-        const int c = sc >> 2, qy = (sc >> 1) & 1, qx = sc & 1;
+        const int c = sc_c(sc), q = sc_q(sc), qy = q >> 1, qx = q & 1;
         const int scoff = ((qy * W + qx) * Cc + c * KT) * 2;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     // weight tiles of tap pair `ty` of super-chunk sc into weight stage `bst` (three planes): filter row r from (qy, ty), this wave's
     // filter column s from (qx, tx = b_tx)
     auto issue_weights = [&](int bst, int sc, int ty) {
-        const int c = sc >> 2, qy = (sc >> 1) & 1, qx = sc & 1;
+        const int c = sc_c(sc), q = sc_q(sc), qy = q >> 1, qx = q & 1;
         const int r = qy == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
         const int sx = qx == 0 ? (b_tx == 0 ? 1 : 3) : (b_tx == 0 ? 2 : 0);
         const int voff = b_base + (((r * 4 + sx) * Cc + c * KT) * K) * 2;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     };
     // window-row shift of tap t = (ty, tx) of class q
     auto shift_of = [&](int sc, int t) -> int {
-        const int qy = (sc >> 1) & 1, qx = sc & 1, ty = t >> 1, tx = t & 1;
+        const int q = sc_q(sc), qy = q >> 1, qx = q & 1, ty = t >> 1, tx = t & 1;
         const int da = ty == 0 ? 0 : (qy ? -1 : 1);
         const int db = tx == 0 ? 0 : (qx ? -1 : 1);
         return da * WW + db;

@@ -294,8 +294,11 @@ X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
 # every op wrapper that would read fp32 memory refuses such a tensor.  model.py decides per layer; DG_X3_PLANES_ONLY=0: off (A/B).
 X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
 # X3_FWW: forward convolutions with <= 128 output channels on the window forward kernel (csrc/igemm_dma_x3_fww.hip; planner code 3:
-# needs the transposed weight planes); DG_X3_FWW=0 keeps them on the register-staged f32x3 tiles (A/B).
-X3_FWW = __import__("os").environ.get("DG_X3_FWW", "1") != "0"
+# needs the transposed weight planes).  OFF by default: built, parity-tested and measured at the benchmark shape (64 -> 128 channels,
+# 512 px / batch 32) at 0.923 ms against 0.927 ms for the register-staged f32x3 tiles -- its window pixels are every OTHER pixel of a
+# pixel-major plane, 32 bytes of each 128-byte line per fetch, and those loads cost it 0.28 of its 0.92 ms.
+# DG_X3_FWW=1 turns it on.
+X3_FWW = __import__("os").environ.get("DG_X3_FWW", "0") == "1"
 
 
 def _plane_code_ok(code):
