@@ -1242,7 +1242,9 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
     pl->stat_rows = 0;
     if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)
-        pl->stat_rows = a.splits > 1 ? reduce_stats_rchunks((long)zmul * a.M, a.Ng) : zmul * a.tilesM * pl->wm;
+        pl->stat_rows = a.splits > 1 ? reduce_stats_rchunks((long)zmul * a.M, a.Ng)
+                                     : (pl->dma == 3 ? 4 * a.tilesM * 2 : zmul * a.tilesM * pl->wm);   // window kernel: (class, tile, wave row)
+    if (pl->dma == 1 || pl->dma == 4 || pl->dma == 5) pl->stat_rows = 0;      // the bf16 LDS-DMA kernels / the window forward kernel emit none
 }
 
 template <int MODE, int WM, int WN, int KT>
@@ -1505,7 +1507,8 @@ extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int 
 // tensor's 2 * numel; a weight inside a flat parameter group has the group's plane distance).  Written by dg_f32_to_bf16x3 or
 // by the fused producers (dg_adam_step_flat_x3, dg_bn_act_fwd_x3, dg_bn_act_bwd_x3); outputs are fp32.
 static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_plane, int b_transposed, float* out, int N, int H, int W, int C, int K,
-                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int a_layout = 0) {
+                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int a_layout = 0, float* stat = nullptr,
+                   size_t stat_floats = 0) {
     const char* who = op == 0 ? "dg_conv_fwd_x3" : (op == 1 ? "dg_conv_dgrad_x3" : "dg_conv_wgrad_x3");
     ConvGeom g;
     int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
@@ -1528,16 +1531,32 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     DG_CHECK_ARG(a_layout == 0 || (K % 64 == 0 && ((op == 1 && pl.dma == 3) || (op == 2 && pl.dma == 2))),
                  "%s: quad-chunk planes are only read by the window input-grad and the plane weight-grad kernels (K %% 64 == 0)", who);
     pl.a.a_cm = a_layout;
+    if (stat) {     // fused BatchNorm partial statistics of the output (forward / input-grad): rows from dg_conv_x3_bnstats_rows
+        const int ncols = op == 0 ? K : C;
+        DG_CHECK_ARG(op != 2 && pl.stat_rows > 0 && stat_floats >= (size_t)pl.stat_rows * (3 * ncols + 4),
+                     "%s: statistics buffer too small or no fused statistics for this plan (ask dg_conv_x3_bnstats_rows)", who);
+        pl.a.stat = stat;
+        pl.a.stat_rs = 3 * ncols + 4;
+    }
     return run_plan(who, pl, ws, ws_bytes, st);
 }
 // w_transposed: w3 is the transposed copy wT[(r, s, c)][k] of the weight planes (dg_x3_transpose_planes) -- the faster form
 extern "C" int dg_conv_fwd_x3(const void* x3, long x_plane, const void* w3, long w_plane, int w_transposed, float* y, int N, int H, int W,
-                              int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_x3(0, x3, x_plane, w3, w_plane, w_transposed, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+                              int C, int K, int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(0, x3, x_plane, w3, w_plane, w_transposed, y, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream, 0, stat, stat_floats);
 }
 extern "C" int dg_conv_dgrad_x3(const void* dy3, long dy_plane, int dy_layout, const void* w3, long w_plane, float* dx, int N, int H, int W, int C, int K,
-                                int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_x3(1, dy3, dy_plane, w3, w_plane, 0, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream, dy_layout);
+                                int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_x3(1, dy3, dy_plane, w3, w_plane, 0, dx, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream, dy_layout, stat, stat_floats);
+}
+// partial-statistics rows the plane kernel of (op, shape) emits (0: none -- no plane kernel, or one without the epilogue)
+extern "C" int dg_conv_x3_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad) {
+    ConvGeom g;
+    if (op == 2 || check_geom("dg_conv_x3_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
+    if (dg_get_option(DG_OPT_BF16) != 2) return 0;
+    Plan pl;
+    make_plan(op, g, &pl, 3, 3);
+    return (pl.dma == 2 || pl.dma == 3) ? pl.stat_rows : 0;
 }
 extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, int dy_layout, const void* x3, long x_plane, float* dw, int N, int H, int W, int C, int K,
                                 int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {

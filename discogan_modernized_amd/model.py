@@ -254,15 +254,20 @@ def _run_fused_steps(layers, x):
         act_mod = layers[j] if j < n and isinstance(layers[j], _Act) else None
         act = act_mod.act if act_mod is not None else ops.ACT_NONE
         slope = act_mod.negative_slope if act_mod is not None else 0.0
-        if bn is not None and bn.training and FUSE_BN_STATS and conv.emits_bn_stats:
+        if bn is not None and bn.training and FUSE_BN_STATS and conv.emits_bn_stats and not ops.X3:
             y, st = conv(x, want_stats=FUSE_BN_STATS)       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
             nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
             z_cm, dy_cm, z_po, dy_po = _plane_hints(conv, x, nxt, z_is_output=nxt is None)
-            y = conv(x)
+            st = None
+            if ops.X3 and ops.X3_FUSE_STATS and bn.training and conv.emits_bn_stats:
+                y, st = conv(x, want_stats=True)            # plane path: statistics from the plane kernel's epilogue (None: no such kernel)
+                st = st if st.numel() > 0 else None
+            else:
+                y = conv(x)
             yield
-            x = bn(y, act, slope, None, z_cm, dy_cm, z_po, dy_po)
+            x = bn(y, act, slope, st, z_cm, dy_cm, z_po, dy_po)
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
             nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
             x = conv(x, act, slope, want_planes=_first_layer_planes(x, nxt))      # conv1 + LeakyReLU in one kernel
@@ -306,14 +311,19 @@ class Discriminator(_FlatGradMixin, nn.Module):
         yield
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
-            if bn.training and FUSE_BN_STATS:
+            if bn.training and FUSE_BN_STATS and not ops.X3:
                 y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
                 _, dy_cm, _, dy_po = _plane_hints(conv, h, None, z_is_output=True)      # z is a feature map: it keeps its fp32 copy
-                y = conv(h)
+                st = None
+                if ops.X3 and ops.X3_FUSE_STATS and bn.training:
+                    y, st = conv(h, want_stats=True)        # plane path: statistics from the plane kernel's epilogue
+                    st = st if st.numel() > 0 else None
+                else:
+                    y = conv(h)
                 yield
-                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, None, False, dy_cm, False, dy_po)
+                h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st, False, dy_cm, False, dy_po)
             feats.append(h)
             yield
         out = self.sigmoid(getattr(self, f"conv{self.n_stages + 1}")(h))

@@ -299,6 +299,11 @@ X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
 # pixel-major plane, 32 bytes of each 128-byte line per fetch, and those loads cost it 0.28 of its 0.92 ms.
 # DG_X3_FWW=1 turns it on.
 X3_FWW = __import__("os").environ.get("DG_X3_FWW", "0") == "1"
+# X3_FUSE_STATS: on the plane path the BatchNorm batch statistics come out of the producing conv kernel's epilogue (or its split-K
+# reduction) as partial rows, merged by dg_bn_stats_from_partials -- no separate read pass over the conv output.  (On the exact-fp32
+# path of the 64 px network the same idea lengthened 140 us kernels by more than the pass it saved: model.FUSE_BN_STATS stays off
+# there; the plane kernels run for hundreds of microseconds per tile and do not notice ~400 VALU instructions per wave.)
+X3_FUSE_STATS = __import__("os").environ.get("DG_X3_FUSE_STATS", "1") != "0"
 
 
 def _plane_code_ok(code):
@@ -428,16 +433,18 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
-    code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (rows == 0 and X3 and k > 1) else 0
+    code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (X3 and k > 1) else 0
     if code >= 1:
         wp, wdist, wt = weight_planes(w, transposed=True)
         if code != 3 or (wt and X3_FWW):         # 3 = the window forward kernel: it reads the TRANSPOSED weight planes only
             xp, xd, _ = planes_of(x)
             y = empty_nhwc(n, k, ho, wo, x.device)
+            srows = L.dg_conv_x3_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
+            stat = torch.empty((srows, 3 * k + 4), device=x.device, dtype=torch.float32) if srows > 0 else None
             with _prof("conv_fwd", 2.0 * n * ho * wo * k * c * 16):
-                _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                           "dg_conv_fwd_x3")
-            return (y, None) if want_stats else y
+                _lib.check(L.dg_conv_fwd_x3(xp, xd, wp, wdist, wt, _ptr(y), n, h, wd, c, k, stride, pad, _ptr(stat),
+                                            stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()), "dg_conv_fwd_x3")
+            return (y, stat) if want_stats else y
     _need_fp32(x, "conv_fwd")
     mixed = False
     xa, x16, wa, w16, o16 = x, 0, w, 0, 0
@@ -485,14 +492,16 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
     if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0
-    if rows == 0 and _x3_ok(1, n, h, wd, c, k, stride, pad):
+    if _x3_ok(1, n, h, wd, c, k, stride, pad):
         dp, dd, dcm = planes_of(dy, allow_cm=L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, stride, pad) == 2)
         wp, wdist, _ = weight_planes(w)
         dx = empty_nhwc(n, c, h, wd, dy.device)
+        srows = L.dg_conv_x3_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
+        stat = torch.empty((srows, 3 * c + 4), device=dy.device, dtype=torch.float32) if srows > 0 else None
         with _prof("conv_dgrad", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
-            _lib.check(L.dg_conv_dgrad_x3(dp, dd, dcm, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                       "dg_conv_dgrad_x3")
-        return (dx, None) if want_stats else dx
+            _lib.check(L.dg_conv_dgrad_x3(dp, dd, dcm, wp, wdist, _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(stat),
+                                          stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()), "dg_conv_dgrad_x3")
+        return (dx, stat) if want_stats else dx
     _need_fp32(dy, "conv_dgrad")
     mixed = False
     da, d16, wa, w16, o16 = dy, 0, w, 0, 0

@@ -343,10 +343,15 @@ int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float* y_nhwc, v
                            int K, int act, float slope, dg_stream_t stream);
 /* 0: no plane kernel for this (op, shape); 1: yes; 2: yes -- the window input-grad kernel, which prefers dy_layout 1 */
 int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
+/* stat (may be NULL): fused BatchNorm partial statistics of the OUTPUT, dg_conv_x3_bnstats_rows(op, ...) rows of 3 * columns + 4
+ * floats in the layout of dg_conv_fwd_bnstats (merged by dg_bn_stats_from_partials): the plane kernels' epilogues (or their split-K
+ * reduction) sum the fp32 accumulators per column, which removes the separate read pass of dg_bn_train_stats over the conv output. */
+int dg_conv_x3_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad);
 int dg_conv_fwd_x3(const void* x_planes, int64_t x_plane, const void* w_planes, int64_t w_plane, int w_transposed, float* y,
-                   int N, int H, int W, int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+                   int N, int H, int W, int C, int K, int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes,
+                   dg_stream_t stream);
 int dg_conv_dgrad_x3(const void* dy_planes, int64_t dy_plane, int dy_layout, const void* w_planes, int64_t w_plane, float* dx, int N, int H, int W,
-                     int C, int K, int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+                     int C, int K, int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_wgrad_x3(const void* dy_planes, int64_t dy_plane, int dy_layout, const void* x_planes, int64_t x_plane, float* dw, int N, int H, int W,
                      int C, int K, int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 

@@ -1128,3 +1128,42 @@ def test_edge_wgrad_on_the_f32x3_path(N, S):
     close(d3, dw64.float(), rtol=2e-5, what="c3_wgrad f32x3")
     close(d3a, dw64a.float(), rtol=2e-5, what="c3_wgrad_act f32x3")
     close(acc, dw64.float() + 1.0, rtol=2e-5, what="c3_wgrad f32x3 accumulate")
+
+
+@pytest.mark.parametrize("N,C,K,H,op", [(2, 64, 256, 64, 0), (1, 256, 512, 32, 0), (2, 256, 64, 64, 1), (1, 128, 256, 128, 1), (2, 512, 256, 32, 1)])
+def test_plane_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
+    """f32x3 plane path: the plane kernels' epilogues (256 x 256 tile, the window input-grad kernel, or their split-K reduction) emit
+    BatchNorm partial rows of the conv OUTPUT; merged by dg_bn_stats_from_partials they must give the statistics of the separate
+    pass (dg_bn_train_stats) over the same output, and identical running-statistics updates."""
+    x, w = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    dy = rnd(N, K, H // 2, H // 2, seed=3)
+    xg, wg, dyg = nhwc(x), krsc(w), nhwc(dy)
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    ops.X3 = True
+    try:
+        buf = torch.empty((3, wg.numel()), device=DEV, dtype=torch.bfloat16)
+        wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
+        if op == 0:
+            assert L.dg_conv_x3_bnstats_rows(0, N, H, H, C, K, 2, 1) > 0
+            y, stat = ops.conv_fwd(xg, wg, 2, 1, want_stats=True)
+            y0 = ops.conv_fwd(xg, wg, 2, 1)
+        else:
+            assert L.dg_conv_x3_bnstats_rows(1, N, H, H, C, K, 2, 1) > 0
+            y, stat = ops.conv_dgrad(dyg, wg, (H, H), 2, 1, want_stats=True)
+            y0 = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+        assert stat is not None and torch.equal(y, y0)
+        ch = y.shape[1]
+        rm1, rv1, nb1 = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+        rm2, rv2, nb2 = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+        s_sep = ops.bn_train_stats(y, rm1, rv1, nb1, 1e-5, 0.1)
+        s_fus = ops.bn_stats_from_partials(stat, y, rm2, rv2, nb2, 1e-5, 0.1)
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("bf16", 0)
+    close(s_fus[0], s_sep[0], rtol=1e-5, atol=1e-6, what="fused mean")
+    close(s_fus[1], s_sep[1], rtol=1e-5, atol=1e-6, what="fused invstd")
+    close(rm2, rm1, rtol=1e-5, atol=1e-7, what="running mean")
+    close(rv2, rv1, rtol=1e-5, atol=1e-7, what="running var")
+    assert int(nb1) == int(nb2) == 1
