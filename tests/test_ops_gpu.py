@@ -1152,7 +1152,10 @@ def test_plane_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
             assert L.dg_conv_x3_bnstats_rows(1, N, H, H, C, K, 2, 1) > 0
             y, stat = ops.conv_dgrad(dyg, wg, (H, H), 2, 1, want_stats=True)
             y0 = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
-        assert stat is not None and torch.equal(y, y0)
+        assert stat is not None
+        # unsplit reductions: the same launch, the same bits; with split-K the statistics come out of a reduction kernel that sums
+        # the slabs in its own (fixed) order -- outputs agree to fp32 rounding
+        close(y, y0, rtol=1e-6, atol=1e-7, what="conv output with / without fused statistics")
         ch = y.shape[1]
         rm1, rv1, nb1 = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
         rm2, rv2, nb2 = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
