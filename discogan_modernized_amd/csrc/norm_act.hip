@@ -211,36 +211,47 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
                                                                   float eps, float momentum, float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                                   float* __restrict__ saved) {
-    __shared__ double red[2][64][4];
-    const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
-    double S = 0.0, Q = 0.0;
-    double G = 0.0;
-    if (c < C) {
-        G = (double)stat[4 + c];                    // row 0 always has count > 0
-        for (int p = pl; p < P; p += 64) {
-            const float* row = stat + (long)p * rs;
-            const double np = (double)row[0];
-            const double s = (double)row[4 + C + c], q = (double)row[4 + 2 * C + c];
-            const double d = (double)row[4 + c] - G;
-            if (np > 0.0) {
-                S += s + np * d;
-                Q += q + d * (2.0 * s + np * d);
+    // block = 4 channels (one 16-byte load per row and array), 256 row lanes; fixed-order tree reduction in fp64.
+    // (Round 3: the first form gave every thread ONE channel and 64 row lanes -- 4-byte loads, P / 64 iterations -- and cost 41 us
+    // per call on the 1024..4096 partial rows the plane kernels emit, more than the statistics pass it replaces.)
+    __shared__ double red[256][8];
+    const int t = threadIdx.x;
+    const int c4 = blockIdx.x * 4;
+    double S[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
+    const f32x4 G4 = *(const f32x4*)(stat + 4 + c4);                    // row 0 always has count > 0: the global shift
+    for (int p = t; p < P; p += 256) {
+        const float* row = stat + (long)p * rs;
+        const double np = (double)row[0];
+        if (np > 0.0) {
+            const f32x4 sh = *(const f32x4*)(row + 4 + c4), s4 = *(const f32x4*)(row + 4 + C + c4), q4 = *(const f32x4*)(row + 4 + 2 * C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)sh[j] - (double)G4[j], s = (double)s4[j];
+                S[j] += s + np * d;
+                Q[j] += (double)q4[j] + d * (2.0 * s + np * d);
             }
         }
     }
-    red[0][pl][cl] = S;
-    red[1][pl][cl] = Q;
-    __syncthreads();
-    if (pl != 0 || c >= C) return;
-    for (int j = 1; j < 64; ++j) {
-        S += red[0][j][cl];
-        Q += red[1][j][cl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[t][j] = S[j];
+        red[t][4 + j] = Q[j];
     }
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (t < half) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[t][j] += red[t + half][j];
+        }
+        __syncthreads();
+    }
+    if (t >= 4) return;
+    const int c = c4 + t;
+    if (c >= C) return;
     if (c == 0 && nbt) nbt[0] += 1;
-    const double dm = S / M;
-    const double mean = G + dm;
-    double var = Q / M - dm * dm;
+    const double dm = red[0][t] / M;
+    const double mean = (double)G4[t] + dm;
+    double var = red[0][4 + t] / M - dm * dm;
     if (var < 0.0) var = 0.0;
     saved[c] = (float)mean;
     saved[C + c] = (float)(1.0 / sqrt(var + (double)eps));
