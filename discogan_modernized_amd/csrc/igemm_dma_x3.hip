@@ -39,6 +39,9 @@ __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...
     (f(std::integral_constant<int, Q>{}), ...);
 }
 #define DG_X3T_MAX 48
+// 16x16x32 body: (block row, pair type) of the 24 MFMA groups of a K-tile, in issue order
+constexpr int G16_I[24] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 7, 6, 6, 7, 7};
+constexpr int G16_T[24] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 0, 1, 2, 1, 2};
 
 // BT (FWD only): the weight planes are the TRANSPOSED copy wT[(r, s, c)][k] (dg_x3_transpose_planes): the B tile of a K-tile is
 // 16 reduction rows x 256 contiguous out channels (512-byte pieces) instead of 256 rows x 32 bytes 16 C elements apart.
@@ -48,7 +51,15 @@ __device__ __forceinline__ void dg_x3_static_for(std::integer_sequence<int, Q...
 // NS: LDS stages (2 or 3).  With 3 the DMA of a tile has TWO tile periods to land (the 256 x 256 tile: 144 KB of LDS, 246-254
 // VGPRs); same-box A/B at 512 px / batch 32: 223-225 / 220-221 / 250 TFLOP/s forward / input-grad / weight-grad with either
 // -- the loop waits for the (power-limited) matrix cores, not for the DMA -- so two stages are what is instantiated.
-template <int MODE, bool BT, int WM, int WN, int NS>
+// M16: the MFMA shape of the loop body.  false: six v_mfma_f32_32x32x16_bf16 per 32 x 32 block and K-tile (one per plane product).
+// true: THREE v_mfma_f32_16x16x32_bf16 per 16 x 16 block, each 32-deep step pairing two plane products along k --
+//   [a_lo | a_hi] . [b_hi | b_lo],  [a_mid | a_mid] . [b_mid | b_hi],  [a_hi | a_hi] . [b_mid | b_hi]
+// (a lane's 8 k values come from ONE plane: k groups 0, 1 of the lane quarter l >> 4 read the first plane of a pair, groups 2, 3 the
+// second, both at the same 16 k of the tile, so a fragment is still one ds_read_b128 / two transposing reads with a lane-dependent
+// plane base).  Same six products, same FLOPs, 1.8x the LDS reads; under it the chip holds 1.9 instead of 1.7 GHz
+// (tools/probes/x3_body_shapes.hip: +4 % in the bare loop).  A tile's fragments no longer fit the registers (128): the A fragments
+// go through a ring six deep, the tile barrier moves to the last fifth of the tile and the DMA gets a third LDS stage to land in.
+template <int MODE, bool BT, int WM, int WN, int NS, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const IgemmArgs p) {
     static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD_S2 || MODE == MODE_WGRAD, "modes with an LDS-DMA form");
     static_assert(!BT || MODE == MODE_FWD, "the transposed weight copy serves the forward form");
@@ -64,6 +75,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     constexpr int NPC = 3 * (NPA + NPB);
     constexpr int LDS_BYTES = NS * STAGE;
     static_assert((NS == 2 || NS == 3) && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(!M16 || (NS == 3 && WM == 2 && WN == 4), "the 16x16x32 body: 256 x 256 tile, three stages");
     constexpr int EPI_BYTES = NW * 32 * 68 * 4;
     static_assert(EPI_BYTES <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
@@ -135,10 +147,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         rB[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + pl * p.b_plane), 0, (p.dbg_zero & 2) ? 0 : (int)p.bbytes, 0x00020000);
     }
 
-    auto kmswz = [](int k) -> int { return (k & 3) << 2; };
+    // granule swizzle of a reduction-major image by k row.  32x32 body: a transposing read covers k rows 8 lh + 0..3 x 64 B; the
+    // 16x16 body's 32-lane group covers k rows 0..3 and 8..11 x 32 B, so bit 3 of the row must move the granule too
+    auto kmswz = [](int k) -> int { return M16 ? (((k & 3) << 2) | (((k >> 3) & 1) << 1)) : ((k & 3) << 2); };
     // ---- per-lane source descriptors of this wave's DMA pieces (the same for the three planes; fixed over the K loop) ----
     // k-contiguous image: piece pq covers rows 32 pq .. 32 pq + 31; lane L lands in (row 32 pq + L / 2, slot L % 2) and fetches
-    // granule slot ^ ((row >> 3) & 1).  Reduction-major image of NC columns: GR = NC / 8 granules per row, piece pq covers k rows
+    // granule slot ^ ((row >> 3) & 1) (16x16 body: granule slot -- its 16-row reads are conflict-free on the plain image).  Reduction-major image of NC columns: GR = NC / 8 granules per row, piece pq covers k rows
     // RP pq .. RP pq + RP - 1 (RP = 64 / GR); lane L lands in (k row RP pq + L / GR, slot L % GR) and fetches granule
     // slot ^ kmswz(k row).  This wave owns pieces wave * NP + i of every plane.
     int a_ob[NPA], a_inv[NPA];
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         a_inv[i] = 0;
         if (!A_KM) {
             const int row = pq * 32 + (lane >> 1);
-            const int g = (lane & 1) ^ ((row >> 3) & 1);
+            const int g = (lane & 1) ^ (M16 ? 0 : ((row >> 3) & 1));
             const int m = m0 + row;
             if (MODE == MODE_FWD) {
                 a_inv[i] = 0xFFFF;
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         wg_ybad[i] = wg_xbad[i] = -1;
         if (MODE == MODE_FWD && !BT) {
             const int row = pq * 32 + (lane >> 1);
-            const int g = (lane & 1) ^ ((row >> 3) & 1);
+            const int g = (lane & 1) ^ (M16 ? 0 : ((row >> 3) & 1));
             const int k = n0 + row;
             b_ob[i] = k < K ? (k * 16 * Cc + g * 8) * 2 : OOR;
         } else {
@@ -345,13 +359,68 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         else fb[pl - 1][j] = v;
     };
 
-    f32x16 acc[FM][FN];
+    // ---- 16x16x32 body: fragment = 16 rows / columns x (16 k of plane X | 16 k of plane Y), lane (l15, l4): plane by l4 >> 1 ----
+    constexpr int AM = 2 * FM, BNB = 2 * FN;            // 8 x 4 blocks of 16 x 16 per wave
+    constexpr int NG16 = 3 * AM, RING = 8, FD16 = 7;    // 24 groups of 4 MFMAs per K-tile; A fragment ring, fetched FD16 groups ahead
+    const int l15 = lane & 15, l4 = lane >> 4, kh16 = l4 >> 1, kg16 = l4 & 1;
+    // byte offset inside a stage of the plane this lane reads for pair type ty.  A: [lo | hi], [mid | mid], [hi | hi];  B: [hi | lo], [mid | hi]
+    const int a16_pl[3] = {(kh16 ? 0 : 2) * PLA, PLA, 0};
+    const int b16_pl[2] = {OPA + (kh16 ? 2 : 0) * PLB, OPA + (kh16 ? 0 : 1) * PLB};
+    // k-contiguous image (plain, no swizzle): row (blk0 + l15), granule kg16 -- block and stage are immediate offsets.
+    // Reduction-major image: the granule swizzle XORs address bits 5..7, where the block index lives too, so the address of block b
+    // is (address of block 0) ^ (b << 5); that XOR is issued per fetch from inline asm -- left to the compiler, every (block, type,
+    // far stage) address is hoisted out of the K loop into its own VGPR (60 of them: the weight-gradient form spilled).
+    auto km16_base = [&](int plane_off, int rowb, int wave_col0) -> int {
+        const int kr = 8 * kg16 + tr_q, col = wave_col0 + (lane & 3) * 4;
+        return plane_off + kr * rowb + ((((col >> 3) ^ kmswz(kr))) << 4) + (col & 7) * 2;
+    };
+    int akm16[3], bkm16[2];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int ty = 0; ty < 3; ++ty) akm16[ty] = km16_base(a16_pl[ty], BM * 2, wm * (32 * FM));
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+    for (int ty = 0; ty < 2; ++ty) bkm16[ty] = km16_base(b16_pl[ty], BN * 2, wn * (32 * FN));
+    auto frag16_km = [&](int stage, int base, int rowb, int blk) -> bf16x8 {
+        int off;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(blk << 5), "v"(base));
+        const char* p0 = smem + stage * STAGE + off;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4_ptr)(p0 + 4 * rowb));     // kr + 4: same swizzle
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto frag16_kc = [&](const char* img, int blk0) -> bf16x8 {
+        return *(const bf16x8*)(img + (blk0 + l15) * 32 + (kg16 << 4));
+    };
+    bf16x8 ga[M16 ? RING : 1], gb0[M16 ? BNB : 1], gb1[2][M16 ? BNB : 1];
+    auto fetchA16 = [&](int stage, int ty, int i, int slot) {
+        if constexpr (A_KM) ga[slot] = frag16_km(stage, akm16[ty], BM * 2, i);
+        else ga[slot] = frag16_kc(smem + stage * STAGE + a16_pl[ty], wm * (32 * FM) + i * 16);
+    };
+    auto fetchB16 = [&](int stage, int ty, int j, int set) {
+        bf16x8 v;
+        if constexpr (B_KM) v = frag16_km(stage, bkm16[ty], BN * 2, j);
+        else v = frag16_kc(smem + stage * STAGE + b16_pl[ty], wn * (32 * FN) + j * 16);
+        if (ty == 0) gb0[j] = v;
+        else gb1[set][j] = v;
+    };
+    // the order of a tile's groups: (block row, pair type).  Rows 6 and 7 run their [hi | lo] products first so that the single
+    // register set of B [hi | lo] is free 16 MFMAs before the end of the tile.  Small terms first inside every block, as in the 32x32 body.
+    // (G16_I / G16_T at the top of the file)
+
+    f32x16 acc[M16 ? 1 : FM][M16 ? 1 : FN];
+    f32x4 acc16[M16 ? AM : 1][M16 ? BNB : 1];
+    if constexpr (M16) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < BNB; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     // ---- prologue: tiles 0 .. NS-1 --------------------------------------------------------------------------------------
     if (it_begin < it_end) {
@@ -365,12 +434,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     }
     __builtin_amdgcn_s_barrier();
     if (stp) stp[2] = clock64();
+    if constexpr (M16) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+        for (int j = 0; j < BNB; ++j) {
+            fetchB16(0, 0, j, 0);
+            fetchB16(0, 1, j, 0);
+        }
+        dg_x3_static_for(std::make_integer_sequence<int, FD16>{}, [&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            fetchA16(0, G16_T[g], G16_I[g], g);
+        });
+    } else {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
+        for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fetchA(0, pl, i);
+            for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fetchA(0, pl, i);
+        }
     }
 
     // ---- one K-tile: 48 MFMAs per wave, row of blocks i = q / 12, plane pair (q % 12) / 2, column block q % 2 -------------
@@ -414,12 +495,50 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         fetchA(NX, 1, 3);
         fetchA(NX, 2, 3);
     };
+    // ---- one K-tile on the 16x16x32 MFMA: 24 groups (block row, pair type) of 4 MFMAs (column blocks) = 96 MFMAs of 16 cycles.
+    // Group g reads A slot g % RING and B [hi | lo] (type 0) or B [mid | hi] of the tile's parity set (types 1, 2).  In front of
+    // its first MFMA the A fragment of group g + FD16 is fetched into the slot group g - 1 has left (from group 19 on: the NEXT
+    // tile's, behind the tile barrier in front of group 19 -- every read of the current stage was issued by group 16).  Behind the
+    // barrier: the next tile's B [mid | hi] into the other set, B [hi | lo] once group 19 (its last reader) has issued, and the DMA
+    // of tile t + NS into the stage tile t is leaving; that DMA has two tile periods to land (vmcnt: this wave's pieces of tile
+    // t + 1 are in, tile t + 2's may still fly).
+    constexpr int GB16 = 19, QB16 = GB16 * BNB;
+    static_assert(NG16 - FD16 <= GB16 - 2 && GB16 + FD16 - NG16 < BNB && NG16 % RING == 0 && RING > FD16, "A ring schedule");
+    static_assert(QB16 + 2 * NPC <= NG16 * BNB, "the DMA of tile t+NS is issued inside tile t");
+    auto body16 = [&](auto ST_, auto PAR_) {
+        constexpr int ST = decltype(ST_)::value, PAR = decltype(PAR_)::value, NX = (ST + 1) % NS;
+        dg_x3_static_for(std::make_integer_sequence<int, NG16 * BNB>{}, [&](auto Q_) {
+            constexpr int q = decltype(Q_)::value;
+            constexpr int g = q / BNB, j = q % BNB, i = G16_I[g], ty = G16_T[g];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q == QB16) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC * (NS - 2)) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // A ring: group g fetches group g + FD16.  The tile's last fragment is fetched by group 23 - FD16, THREE groups before
+            // the barrier (its lgkmcnt(0) then finds the reads long complete); groups 17, 18 would read the next stage in front of
+            // the barrier: their fetches are caught up by group 19, one per MFMA
+            if constexpr (j == 0 && g + FD16 < NG16) fetchA16(ST, G16_T[g + FD16], G16_I[g + FD16], (g + FD16) % RING);
+            if constexpr (g == GB16 && NG16 + j <= GB16 + FD16) fetchA16(NX, G16_T[j], G16_I[j], (NG16 + j) % RING);
+            if constexpr (j == 0 && g > GB16) fetchA16(NX, G16_T[g + FD16 - NG16], G16_I[g + FD16 - NG16], (g + FD16) % RING);
+            if constexpr (g >= 19 && g < 19 + BNB && j == 1) fetchB16(NX, 1, g - 19, PAR ^ 1);
+            if constexpr (g >= 20 && g < 20 + BNB && j == 2) fetchB16(NX, 0, g - 20, 0);
+            if constexpr (ty == 0) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[g % RING], gb0[j], acc16[i][j], 0, 0, 0);
+            else acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[g % RING], gb1[PAR][j], acc16[i][j], 0, 0, 0);
+            if constexpr (q >= QB16 && q < QB16 + 2 * NPC && (q - QB16) % 2 == 0) issue(ST, (q - QB16) / 2);
+            if constexpr (q == QB16 + 2 * NPC - 1) advance();
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // the bodies cycle through (stage, parity): 2 stages -> 2 bodies, 3 stages -> 6
     constexpr int NB = NS == 2 ? 2 : 6;
     for (int it = it_begin; it < it_end; it += NB) {
         dg_x3_static_for(std::make_integer_sequence<int, NB>{}, [&](auto B_) {
             constexpr int bi = decltype(B_)::value;
-            if (it + bi < it_end) body(std::integral_constant<int, bi % NS>{}, std::integral_constant<int, bi & 1>{});
+            if (it + bi < it_end) {
+                if constexpr (M16) body16(std::integral_constant<int, bi % NS>{}, std::integral_constant<int, bi & 1>{});
+                else body(std::integral_constant<int, bi % NS>{}, std::integral_constant<int, bi & 1>{});
+            }
         });
     }
     // the clamped re-loads of the last tile and the fragment prefetch behind the last barrier still touch LDS
@@ -436,6 +555,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
         const int prow = ((MODE == MODE_DGRAD_S2 ? parity : 0) * p.tilesM + tm) * WM + wm;
         float* srow = p.stat + (long)prow * p.stat_rs;
         if (wn == 0 && tn == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
+        if constexpr (M16) {          // acc16[bi][bj][e] = row 16 bi + 4 l4 + e, column 16 bj + l15 of the wave tile
+            if (nrows > 0) {
+#pragma unroll
+                for (int bj = 0; bj < BNB; ++bj) {
+                    const float sh = __shfl(acc16[0][bj][0], l15, 64);
+                    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                    for (int bi = 0; bi < AM; ++bi)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int lr = bi * 16 + 4 * l4 + e;
+                            if (lr < nrows) {
+                                const float d = acc16[bi][bj][e] - sh;
+                                ssum += d;
+                                ssq += d * d;
+                            }
+                        }
+                    ssum += __shfl_xor(ssum, 16, 64);
+                    ssq += __shfl_xor(ssq, 16, 64);
+                    ssum += __shfl_xor(ssum, 32, 64);
+                    ssq += __shfl_xor(ssq, 32, 64);
+                    const int n = n0 + wn * (32 * FN) + bj * 16 + l15;
+                    if (l4 == 0 && n < p.Ng) {
+                        srow[4 + n] = sh;
+                        srow[4 + p.Ng + n] = ssum;
+                        srow[4 + 2 * p.Ng + n] = ssq;
+                    }
+                }
+            }
+        } else
         if (nrows > 0) {
 #pragma unroll
             for (int jn = 0; jn < FN; ++jn) {
@@ -472,11 +621,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     const int ncol = n0 + wn * (32 * FN) + ec4;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        if constexpr (M16) {      // 16x16 blocks: rows 32 i .. 32 i + 31 of the wave tile = block rows 2 i, 2 i + 1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            eps[lr * 68 + l31] = acc[i][0][r];
-            eps[lr * 68 + 32 + l31] = acc[i][1][r];
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < BNB; ++bj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) eps[(bi * 16 + 4 * l4 + e) * 68 + bj * 16 + l15] = acc16[2 * i + bi][bj][e];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                eps[lr * 68 + l31] = acc[i][0][r];
+                eps[lr * 68 + 32 + l31] = acc[i][1][r];
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -511,22 +669,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
 }
 
 // host: launch the plane kernel for a plan made by igemm.hip (mode, args, wm x wn waves); returns 0 when there is no instantiation
-template <int WM, int WN, int NS>
+template <int WM, int WN, int NS, bool M16>
 static int x3_launch_tile(int mode, const IgemmArgs& a, int grid, hipStream_t st) {
     const dim3 blk(64 * WM * WN);
     switch (mode) {
         case MODE_FWD:
-            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true, WM, WN, NS>), dim3(grid), blk, 0, st, a);
-            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false, WM, WN, NS>), dim3(grid), blk, 0, st, a);
+            if (a.b_transposed) hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, true, WM, WN, NS, M16>), dim3(grid), blk, 0, st, a);
+            else hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_FWD, false, WM, WN, NS, M16>), dim3(grid), blk, 0, st, a);
             return 1;
-        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false, WM, WN, NS>), dim3(grid), blk, 0, st, a); return 1;
-        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, WM, WN, NS>), dim3(grid), blk, 0, st, a); return 1;
+        case MODE_DGRAD_S2: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_DGRAD_S2, false, WM, WN, NS, M16>), dim3(grid), blk, 0, st, a); return 1;
+        case MODE_WGRAD: hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, WM, WN, NS, M16>), dim3(grid), blk, 0, st, a); return 1;
         default: return 0;
     }
 }
 int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmul, hipStream_t st) {
     const int grid = a.tilesM * a.tilesN * zmul * a.splits;
-    if (wm == 2 && wn == 4) return x3_launch_tile<2, 4, 2>(mode, a, grid, st);
+    // option "x3_mfma": 16 = the 256 x 256 tile on the 16x16x32 MFMA with planes paired along k (three LDS stages); 32 / 0 = the
+    // 32x32x16 body (two stages), the default.  Same-box A/B at 512 px / batch 32, 16 against 32: +2.2..4.2 % forward / input-grad /
+    // weight-grad on 256 -> 512 and 512 -> 1024 channels, +0..1.8 % on 1024 -> 2048 (256 K-tiles per workgroup each), -1..-3 % on
+    // 128 -> 256 and -12 % on the forward of 2048 -> 2048 @ 8 (128 K-tiles per workgroup) in isolated launches -- and NOTHING in the
+    // whole step (284.2 / 283.4 images/s with 32, 282.6 with 16, 283.1 / 281.9 with 16 on the long K loops only): DESIGN.md 3.1
+    const int body = dg_get_option(DG_OPT_X3_MFMA) == 16 ? 16 : 32;
+    if (wm == 2 && wn == 4 && body == 16) return x3_launch_tile<2, 4, 3, true>(mode, a, grid, st);
+    if (wm == 2 && wn == 4) return x3_launch_tile<2, 4, 2, false>(mode, a, grid, st);
     if (wm == 1 && wn == 4 && mode == MODE_WGRAD) {
         hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4, 2>), dim3(grid), dim3(256), 0, st, a);
         return 1;

@@ -304,6 +304,12 @@ X3_FWW = __import__("os").environ.get("DG_X3_FWW", "0") == "1"
 # path of the 64 px network the same idea lengthened 140 us kernels by more than the pass it saved: model.FUSE_BN_STATS stays off
 # there; the plane kernels run for hundreds of microseconds per tile and do not notice ~400 VALU instructions per wave.)
 X3_FUSE_STATS = __import__("os").environ.get("DG_X3_FUSE_STATS", "1") != "0"
+# X3_MFMA: the MFMA shape of the plane kernel's 256 x 256 tile (library option "x3_mfma").  16 = v_mfma_f32_16x16x32_bf16 with the
+# planes paired along k (three instructions per 16 x 16 block and K-tile instead of six 32x32x16 ones: the same products, a shape
+# under which the chip holds a higher clock; csrc/igemm_dma_x3.hip); 32 / 0 = the 32x32x16 body (default: the paired body is faster
+# per launch on the middle layers and not at all in the whole step).  The
+# environment variable is applied by _lib.load() like every DG_OPT_*; this constant is what tests restore the option to.
+X3_MFMA = int(__import__("os").environ.get("DG_OPT_X3_MFMA", "0"))
 
 
 def _plane_code_ok(code):

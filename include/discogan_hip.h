@@ -61,6 +61,8 @@ const char* dg_last_error(void);
  * "no_dma" 1: convolutions with two bf16 operands stay on the register-staged tiles instead of the LDS-DMA kernel;
  * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one; 1: keep the input-grads with <= 128
  *   output channels on the register-staged tiles instead of the window kernels (same-box A/B);
+ * "x3_mfma" 16: the f32x3 plane kernel's 256 x 256 tile on the 16x16x32 MFMA with the planes paired along k instead of the
+ *   default 32x32x16 body (same products; measured not faster in the whole step);
  * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results). */
 int dg_set_option(const char* name, int value);
 

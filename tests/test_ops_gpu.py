@@ -284,8 +284,12 @@ X3_SHAPES = DMA_SHAPES + [
 
 @pytest.mark.parametrize("N,C,K,H", X3_SHAPES)
 @pytest.mark.parametrize("splitk", [0, 1, 3])
-def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
-    """mfma_dtype="f32x3" with PLANE operands: the three bf16 planes of both operands are written once (dg_f32_to_bf16x3) and
+@pytest.mark.parametrize("body", [32, 16])
+def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
+    """body 16: the 256 x 256 tile on v_mfma_f32_16x16x32_bf16 with the planes PAIRED along k (option "x3_mfma" 16: the same six
+    products, two per instruction, so a different summation order -- everything but the bit-identity with the register-staged
+    kernels is asserted).
+    mfma_dtype="f32x3" with PLANE operands: the three bf16 planes of both operands are written once (dg_f32_to_bf16x3) and
     igemm_dma_x3.hip stages them by LDS-DMA.  Same six MFMAs per product block and the same reduction order as the
     register-staged split of igemm.hip: bit-identical on an unsplit GEMM, fp32 tolerance against fp64 otherwise, and at most
     2x the exact-fp32 MFMA path's distance from fp64."""
@@ -298,6 +302,7 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
     L = _lib.load()
     _lib.set_option("bf16", 2)
     _lib.set_option("splitk", splitk)
+    _lib.set_option("x3_mfma", body)
     try:
         yreg, dxreg, dwreg = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
         M = N * (H // 2) ** 2
@@ -327,6 +332,7 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
         ops.planes_clear()
         _lib.set_option("splitk", 0)
         _lib.set_option("bf16", 0)
+        _lib.set_option("x3_mfma", ops.X3_MFMA)
     close(y, y64.float(), what="plane conv fwd")
     close(dx, dx64.float(), rtol=2e-4, what="plane conv dgrad")
     close(dw, dw64.float(), rtol=2e-4, what="plane conv wgrad")
@@ -338,7 +344,7 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk):
     close(y, yreg, what="plane vs register-staged fwd")
     close(dx, dxreg, rtol=2e-4, what="plane vs register-staged dgrad")
     close(dw, dwreg, rtol=2e-4, what="plane vs register-staged wgrad")
-    if splitk == 1:          # one slab and the same K walk: the same sequence of MFMAs per accumulator as the register-staged kernel
+    if splitk == 1 and body == 32:   # one slab and the same K walk: the same sequence of MFMAs per accumulator as the register-staged kernel
         assert torch.equal(dw, dwreg), "plane kernel vs register-staged split: weight gradient"
         if C % 64:           # (channel counts that are multiples of 64 run the four 16-channel tiles of a 128-byte line back to back)
             assert torch.equal(y, yreg), "plane kernel vs register-staged split: forward"

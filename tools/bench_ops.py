@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--dma_mfma", type=int, default=0, help="32: the LDS-DMA kernel's 32x32x16 body (default 16x16x32)")
     ap.add_argument("--no_dma", type=int, default=0, help="keep bf16-operand convs on the register-staged tiles")
     ap.add_argument("--x3planes", type=int, default=0, help="with --bf16 2: plane operands (igemm_dma_x3.hip), what the f32x3 trainer does; 2 = forward on the transposed weight planes")
+    ap.add_argument("--x3_mfma", type=int, default=0, help="16: the plane kernel's 16x16x32 body with planes paired along k (default 32x32x16)")
     ap.add_argument("--x3cm", type=int, default=0, help="with --x3planes: hand the window input-grad kernel (and the weight-grad) QUAD-CHUNK gradient planes, what the BatchNorm kernels write for it (ops.X3_CM)")
     ap.add_argument("--layers", default="", help="comma list of layer indices (1-based) to time; default all")
     ap.add_argument("--dbg_zero", type=int, default=0, help="timing experiment: drop the A (1) / B (2) / both (3) operand loads of the conv kernels")
@@ -57,6 +58,7 @@ def main():
     _lib.set_option("dbg_zero", a.dbg_zero)
     _lib.set_option("no_dma", a.no_dma)
     _lib.set_option("dma_mfma", a.dma_mfma)
+    _lib.set_option("x3_mfma", a.x3_mfma)
     ops.SHADOW = bool(a.shadow)
     ops.X3 = bool(a.x3planes)
     only = {int(v) for v in a.layers.split(",") if v}
