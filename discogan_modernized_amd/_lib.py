@@ -55,7 +55,8 @@ SIGNATURES = {
     "dg_conv4x4s2_c3_wgrad_act": (_i, [_p, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_bn_workspace_bytes": (_z, [_i, _i]),
     "dg_bn_train_stats": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
-    "dg_bn_stats_from_partials": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
+    "dg_bn_partials_workspace_bytes": (_z, [_i, _i]),
+    "dg_bn_stats_from_partials": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
     "dg_bn_act_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
     "dg_bn_act_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
     "dg_act_fwd": (_i, [_p, _p, _z, _i, _f, _p]),

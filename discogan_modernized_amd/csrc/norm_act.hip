@@ -262,6 +262,70 @@ __global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* 
     }
 }
 
+// Two-level form of the same merge for many partial rows.  Level 1: block (channel quad, row block rb of RB) takes rows
+// rb * 256 + t, + RB * 256, ... re-referenced to the global shift like the one-launch form and leaves its eight fp64 sums in
+// part[rb][0 = S, 1 = Q][C4].  Level 2: one thread per channel adds the RB rows in order and finishes.
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __restrict__ stat, int P, int rs, int C, int RB, double* __restrict__ part) {
+    __shared__ double red[256][8];
+    const int t = threadIdx.x, rb = blockIdx.y;
+    const int c4 = blockIdx.x * 4;
+    const int C4 = (C + 3) / 4 * 4;
+    double S[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
+    const f32x4 G4 = *(const f32x4*)(stat + 4 + c4);
+    for (int p = rb * 256 + t; p < P; p += RB * 256) {
+        const float* row = stat + (long)p * rs;
+        const double np = (double)row[0];
+        if (np > 0.0) {
+            const f32x4 sh = *(const f32x4*)(row + 4 + c4), s4 = *(const f32x4*)(row + 4 + C + c4), q4 = *(const f32x4*)(row + 4 + 2 * C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)sh[j] - (double)G4[j], s = (double)s4[j];
+                S[j] += s + np * d;
+                Q[j] += (double)q4[j] + d * (2.0 * s + np * d);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[t][j] = S[j];
+        red[t][4 + j] = Q[j];
+    }
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (t < half) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[t][j] += red[t + half][j];
+        }
+        __syncthreads();
+    }
+    if (t < 8) part[((long)rb * 2 + (t >> 2)) * C4 + c4 + (t & 3)] = red[0][t];
+}
+__global__ __launch_bounds__(64) void bn_partials_merge_kernel(const double* __restrict__ part, int RB, const float* __restrict__ stat, int M, int C,
+                                                               float eps, float momentum, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                               float* __restrict__ saved) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int C4 = (C + 3) / 4 * 4;
+    double S = 0.0, Q = 0.0;
+    for (int rb = 0; rb < RB; ++rb) {
+        S += part[((long)rb * 2 + 0) * C4 + c];
+        Q += part[((long)rb * 2 + 1) * C4 + c];
+    }
+    if (c == 0 && nbt) nbt[0] += 1;
+    const double dm = S / M;
+    const double mean = (double)stat[4 + c] + dm;
+    double var = Q / M - dm * dm;
+    if (var < 0.0) var = 0.0;
+    saved[c] = (float)mean;
+    saved[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
 typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
 // TI / TO: element types of y and z.  Z16 (fp32 z only) = 1: also write a bf16 (RNE) shadow of z for the bf16 matrix path;
 // = 3: the three bf16 planes of z for the f32x3 matrix path (dg_split3; planes `pstride` elements apart).  cm != 0: the planes
@@ -722,12 +786,33 @@ extern "C" int dg_bn_train_stats_t(const void* y, int io_bf16, int M, int C, flo
     return bn_train_stats_impl<float>((const float*)y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
 }
 
+static int bn_partials_row_blocks(int P) {
+    if (P < 4096) return 1;          // (tools/bench_partials.py: 16384 x 64: 83 -> 28 us, 4096 x 128: 25 -> 15 us; below that one launch wins)
+    const int rb = P / 512;
+    return rb < 2 ? 2 : (rb > 64 ? 64 : rb);
+}
+extern "C" size_t dg_bn_partials_workspace_bytes(int P, int C) {
+    const int rb = bn_partials_row_blocks(P);
+    return rb > 1 ? (size_t)rb * 2 * (size_t)((C + 3) / 4 * 4) * sizeof(double) : 0;
+}
 extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C, float eps, float momentum,
                                          float* running_mean, float* running_var, int64_t* nbt, float* saved,
-                                         dg_stream_t stream) {
+                                         void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(stat && saved && P >= 1, "dg_bn_stats_from_partials: bad argument");
     DG_CHECK_ARG(M >= 2, "dg_bn_stats_from_partials: Expected more than 1 value per channel when training (M=%d)", M);
     DG_CHECK_ARG(C >= 4 && C % 4 == 0, "dg_bn_stats_from_partials: C=%d must be a multiple of 4", C);
+    // few channels x many partial rows (the window input-grad at 64 channels: 16384 rows of 784 bytes = 12.8 MB for 16 blocks)
+    // is a latency-bound crawl in one launch (20.6 us average, 119 us worst over the 512 px step): from 4096 rows on the rows
+    // are first reduced by RB row blocks per channel quad, then merged -- two short launches, every sum still in a fixed order
+    const int RB = bn_partials_row_blocks(P);
+    if (RB > 1 && ws != nullptr && ws_bytes >= dg_bn_partials_workspace_bytes(P, C)) {
+        hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3((C + 3) / 4, RB), dim3(256), 0, (hipStream_t)stream, stat, P, 3 * C + 4, C, RB, (double*)ws);
+        DG_CHECK_LAUNCH("bn_partials_reduce");
+        hipLaunchKernelGGL(bn_partials_merge_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)ws, RB, stat, M, C, eps,
+                           momentum, running_mean, running_var, nbt, saved);
+        DG_CHECK_LAUNCH("bn_partials_merge");
+        return DG_OK;
+    }
     hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stat, P, 3 * C + 4,
                        M, C, eps, momentum, running_mean, running_var, nbt, saved);
     DG_CHECK_LAUNCH("bn_partials_finalize");

@@ -709,14 +709,19 @@ def bn_train_stats(y, running_mean, running_var, nbt, eps, momentum):
     return saved
 
 
+_PARTIALS_ONE_LAUNCH = __import__("os").environ.get("DG_BN_PARTIALS_ONE_LAUNCH", "0") == "1"     # same-box A/B of the two-level merge
+
+
 def bn_stats_from_partials(stat, y, running_mean, running_var, nbt, eps, momentum):
     """Same result as bn_train_stats(y, ...) from the partial rows a conv kernel emitted for y."""
     _check_dev(stat)
     n, c, h, w = y.shape
     saved = torch.empty((2, c), device=y.device, dtype=torch.float32)
-    _lib.check(_lib.load().dg_bn_stats_from_partials(_ptr(stat), stat.shape[0], n * h * w, c, eps, momentum,
-                                                     _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
-                                                     _stream()), "dg_bn_stats_from_partials")
+    L = _lib.load()
+    ws, wsb = (None, 0) if _PARTIALS_ONE_LAUNCH else _ws(L.dg_bn_partials_workspace_bytes(stat.shape[0], c), y.device)
+    _lib.check(L.dg_bn_stats_from_partials(_ptr(stat), stat.shape[0], n * h * w, c, eps, momentum,
+                                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
+                                           _ptr(ws), wsb, _stream()), "dg_bn_stats_from_partials")
     return saved
 
 

@@ -167,10 +167,13 @@ size_t dg_bn_workspace_bytes(int M, int C);
 int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* saved, void* ws, size_t ws_bytes, dg_stream_t s);
-/* same outputs as dg_bn_train_stats, from partial rows written by dg_conv_*_bnstats (M = N*H*W rows total) */
+/* same outputs as dg_bn_train_stats, from partial rows written by dg_conv_*_bnstats (M = N*H*W rows total).
+ * ws: dg_bn_partials_workspace_bytes(P, C) bytes (0 for P < 4096 rows) -- with it many rows are merged in two short launches
+ * (row blocks, then channels) instead of one latency-bound one; NULL / too small: the one-launch form. */
+size_t dg_bn_partials_workspace_bytes(int P, int C);
 int dg_bn_stats_from_partials(const float* stat, int P, int M, int C, float eps, float momentum,
                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                              float* saved, dg_stream_t s);
+                              float* saved, void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
                   const float* beta, int act, float slope, dg_stream_t s);
 /* dy = BN'(act'(dz)); dgamma/dbeta (+)= ; dy may alias dz */
