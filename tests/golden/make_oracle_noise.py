@@ -10,8 +10,9 @@ This script computes it once, here; the tests read the numbers (DG_LIVE_NOISE=1 
     python tests/golden/make_oracle_noise.py [--skip512]
 
 Runs: "SxN" = the standard sequential run of the tests (seed-1234 state, synthetic batch seed 0, iterations 0..3, Adam on the
-oracle's own gradients between them) for 16x4, 64x4, 128x2; "512x2_init" = iterations 0 (D-step) and 1 (G-step) from the
-seeded init without an optimiser step (test_masked_fp64_gradient_parity_512).  Values: relative L2 error of the fp32
+oracle's own gradients between them) for 16x4, 64x4, 128x2 and 512x2 (test_teacher_forced_iterations_512_f32x3);
+"512x2_init" = iterations 0 (D-step) and 1 (G-step) from the seeded init without an optimiser step
+(test_masked_fp64_gradient_parity_512).  Values: relative L2 error of the fp32
 gradient against the fp64 gradient on the same piecewise-linear function.  Data only.
 """
 import argparse
@@ -59,15 +60,18 @@ def run(S, N, iters, step):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip512", action="store_true")
+    ap.add_argument("--only512", action="store_true")
     a = ap.parse_args()
     path = os.path.join(HERE, "oracle_fp32_noise.json")
     runs = {}
     if os.path.exists(path):
         runs = json.load(open(path))["runs"]
-    for S, N in ((16, 4), (64, 4), (128, 2)):
-        runs[f"{S}x{N}"] = run(S, N, range(4), True)
+    if not a.only512:
+        for S, N in ((16, 4), (64, 4), (128, 2)):
+            runs[f"{S}x{N}"] = run(S, N, range(4), True)
     if not a.skip512:
         runs["512x2_init"] = run(512, 2, [0, 1], False)
+        runs["512x2"] = run(512, 2, range(4), True)
     meta = {"source": "oracle/discogan_ref.py fp32 vs fp64 on its own activation pattern (tests/kink_probe.py)",
             "torch": torch.__version__, "threads": torch.get_num_threads(), "seed_model": 1234, "seed_data": 0}
     with open(path, "w") as f:

@@ -443,6 +443,19 @@ def test_teacher_forced_iterations_f32x3(S, N, planes):
     _teacher_forced(S, N, 4, tr=tr, mfma_dtype="f32x3", noise_key=f"{S}x{N}")
 
 
+def test_teacher_forced_iterations_512_f32x3():
+    """The HEADLINE configuration's arithmetic (BASELINE configs[3] network: 512 px; mfma_dtype="f32x3" on plane operands,
+    quad-chunk planes, plane-only BatchNorm outputs, fused statistics) teacher-forced through iterations 0..3 -- D, G, G, D,
+    the post-Adam saturated-discriminator regime included -- at the bounds of the small sizes: losses 2e-4, D outputs 2e-3,
+    every gradient tensor within max(1e-4, 4 x the reference arithmetic's own fp32 error) of the fp64 oracle on the same
+    activation pattern, BatchNorm buffers, Adam op-wise (iterations 2-3 at 512 px)."""
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234, mfma_dtype="f32x3")
+    assert tr.x3_planes
+    _teacher_forced(512, 2, 4, tr=tr, mfma_dtype="f32x3", noise_key="512x2")
+    tr.close()
+    torch.cuda.empty_cache()
+
+
 def test_f32x3_plane_step_is_graph_neutral_and_deterministic():
     """The plane path under hipGraph replay (Adam writes the weight planes and their transposed copy inside the captured step;
     activation planes live in the graph's private pool): 9 iterations eager, eager again and replayed end bitwise identical."""
