@@ -110,8 +110,9 @@ SIGNATURES = {
     "dg_x3_transpose_planes": (_i, [_p, _p, _z, _p, _p, _p, _i, _p]),
     "dg_conv_dgrad_x3": (_i, [_p, _l, _i, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
     "dg_conv_wgrad_x3": (_i, [_p, _l, _i, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_mixed_bnstats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
+    "dg_conv_dgrad_mixed": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
     "dg_bn_train_stats_t": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
     "dg_bn_act_fwd_t": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _f, _p]),
     "dg_bn_act_bwd_t": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),

@@ -945,16 +945,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArg
             const float* sp = p.part + row * p.Ng + c;
             f32x4 v = *(const f32x4*)sp;
             for (int k = 1; k < p.splits; ++k) v += *(const f32x4*)(sp + k * slab);
-            float* dst;
+            long eoff;
             if (MODE == MODE_DGRAD_S2) {
                 const int parity = (int)(row / p.M);
                 const int m = (int)(row - (long)parity * p.M);
                 const int b = m & (p.Wo - 1), a = (m >> p.lgWo) & (p.Ho - 1), n = m >> (p.lgWo + p.lgHo);
-                dst = p.C + (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c;
+                eoff = (long)((n * p.H + 2 * a + (parity >> 1)) * p.W + 2 * b + (parity & 1)) * p.Cc + c;
             } else {
-                dst = p.C + row * p.Ng + c;
+                eoff = row * p.Ng + c;
             }
-            *(f32x4*)dst = v;
+            dg_store_out4(p.C, eoff, v, p.out16);      // statistics from the fp32 sums, whatever the output is rounded to
             const f32x4 d = v - sh;
             s += d;
             q += d * d;
@@ -1244,7 +1244,8 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)
         pl->stat_rows = a.splits > 1 ? reduce_stats_rchunks((long)zmul * a.M, a.Ng)
                                      : (pl->dma == 3 ? 4 * a.tilesM * 2 : zmul * a.tilesM * pl->wm);   // window kernel: (class, tile, wave row)
-    if (pl->dma == 1 || pl->dma == 4 || pl->dma == 5) pl->stat_rows = 0;      // the bf16 LDS-DMA kernels / the window forward kernel emit none
+    if (pl->dma == 4 && a.splits <= 1) pl->stat_rows = 4 * a.tilesM * 2;      // bf16 window input-grad kernel: (class, tile, wave row) like dma 3
+    if (pl->dma == 5) pl->stat_rows = 0;                                      // the window forward kernel emits none
 }
 
 template <int MODE, int WM, int WN, int KT>
@@ -1436,7 +1437,8 @@ extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, 
 // next to the fp32 tensor (dg_adam_step_flat_bf16 for weights, dg_bn_act_fwd_bf16 / dg_bn_act_bwd_bf16 / the c3 forward for
 // activations and gradients); the result is bit-identical to passing the fp32 tensors (same RNE rounding, same order).
 static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b16, void* out, int out16, int N, int H, int W, int C, int K,
-                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* stat = nullptr,
+                      size_t stat_floats = 0) {
     const char* who = op == 0 ? "dg_conv_fwd_mixed" : (op == 1 ? "dg_conv_dgrad_mixed" : "dg_conv_wgrad_mixed");
     ConvGeom g;
     int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
@@ -1477,15 +1479,29 @@ static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b
     if (pl.a.prec != 1 && (a16 || b16 || out16)) return dg_fail(DG_ERR_INVALID, "%s: this shape has no bf16 tile kernel", who);
     pl.a.A = (const float*)a_in; pl.a.B = (const float*)b_in; pl.a.C = (float*)out; pl.a.accumulate = accumulate;
     pl.a.out16 = out16;
+    if (stat) {     // fused BatchNorm partial statistics of the output (from the fp32 accumulators): rows from dg_conv_mixed_bnstats_rows
+        const int ncols = op == 0 ? K : C;
+        DG_CHECK_ARG(op != 2 && pl.stat_rows > 0 && stat_floats >= (size_t)pl.stat_rows * (3 * ncols + 4),
+                     "%s: statistics buffer too small or no fused statistics for this plan (ask dg_conv_mixed_bnstats_rows)", who);
+        pl.a.stat = stat;
+        pl.a.stat_rs = 3 * ncols + 4;
+    }
     return run_plan(who, pl, ws, ws_bytes, st);
 }
+extern "C" int dg_conv_mixed_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad, int a_bf16, int b_bf16) {
+    ConvGeom g;
+    if ((op != 0 && op != 1) || check_geom("dg_conv_mixed_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1 || stride != 2) return 0;
+    Plan pl;
+    make_plan(op, g, &pl, a_bf16, b_bf16);
+    return pl.stat_rows;
+}
 extern "C" int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, void* y, int y_bf16, int N, int H, int W, int C, int K,
-                                 int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_mixed(0, x, x_bf16, w, w_bf16, y, y_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+                                 int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_mixed(0, x, x_bf16, w, w_bf16, y, y_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream, stat, stat_floats);
 }
 extern "C" int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, int K,
-                                   int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_mixed(1, dy, dy_bf16, w, w_bf16, dx, dx_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream);
+                                   int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_mixed(1, dy, dy_bf16, w, w_bf16, dx, dx_bf16, N, H, W, C, K, stride, pad, 0, ws, ws_bytes, (hipStream_t)stream, stat, stat_floats);
 }
 extern "C" int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
                                    int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {

@@ -525,6 +525,73 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void igemm_dma_ker
     __builtin_amdgcn_s_barrier();
     if (stp) stp[3] = clock64();
 
+    // ---- fused BatchNorm statistics (igemm.hip's scheme): one partial row per (tile, wave row) = 32 FM output rows, shifted by the
+    //      wave tile's first row; merged by bn_partials_finalize.  ~3 VALU instructions per accumulator value: invisible next to a
+    //      K loop of hundreds of microseconds, and it removes a whole read pass over the conv output (dg_bn_train_stats).
+    if ((MODE == MODE_FWD || MODE == MODE_DGRAD_S2) && p.stat != nullptr && p.part == nullptr) {
+        const int row0 = m0 + wm * (32 * FM);
+        const int nrows = min(32 * FM, p.M - row0);
+        const int prow = ((MODE == MODE_DGRAD_S2 ? parity : 0) * p.tilesM + tm) * WM + wm;
+        float* srow = p.stat + (long)prow * p.stat_rs;
+        if (wn == 0 && tn == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
+        if constexpr (M16) {          // acc16[bi][bj][e] = row 16 bi + 4 l4 + e, column 16 bj + l15 of the wave tile
+            if (nrows > 0) {
+#pragma unroll
+                for (int bj = 0; bj < BNB; ++bj) {
+                    const float sh = __shfl(acc16[0][bj][0], l15, 64);
+                    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                    for (int bi = 0; bi < AM; ++bi)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int lr = bi * 16 + 4 * l4 + e;
+                            if (lr < nrows) {
+                                const float d = acc16[bi][bj][e] - sh;
+                                ssum += d;
+                                ssq += d * d;
+                            }
+                        }
+                    ssum += __shfl_xor(ssum, 16, 64);
+                    ssq += __shfl_xor(ssq, 16, 64);
+                    ssum += __shfl_xor(ssum, 32, 64);
+                    ssq += __shfl_xor(ssq, 32, 64);
+                    const int n = n0 + wn * (32 * FN) + bj * 16 + l15;
+                    if (l4 == 0 && n < p.Ng) {
+                        srow[4 + n] = sh;
+                        srow[4 + p.Ng + n] = ssum;
+                        srow[4 + 2 * p.Ng + n] = ssq;
+                    }
+                }
+            }
+        } else
+        if (nrows > 0) {
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const float sh = __shfl(acc[0][jn][0], l31, 64);
+                float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (lr < nrows) {
+                            const float d = acc[i][jn][r] - sh;
+                            ssum += d;
+                            ssq += d * d;
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                const int n = n0 + wn * (32 * FN) + jn * 32 + l31;
+                if (lh == 0 && n < p.Ng) {
+                    srow[4 + n] = sh;
+                    srow[4 + p.Ng + n] = ssum;
+                    srow[4 + 2 * p.Ng + n] = ssq;
+                }
+            }
+        }
+    }
+
     // ---- epilogue (igemm.hip): acc[i][jn][r] = row (r&3)+8*(r>>2)+4*lh, col jn*32+l31 of the wave's 32x64 block i,
     // transposed through a private [32][68] LDS region per wave, float4 stores with 16 lanes per 256-B row segment
     const bool to_part = p.part != nullptr;

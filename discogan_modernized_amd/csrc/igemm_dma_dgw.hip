@@ -270,6 +270,42 @@ __global__ __launch_bounds__(512, 2) void igemm_bf16_dgw_kernel(const IgemmArgs 
     __builtin_amdgcn_s_barrier();
     if (stp) stp[3] = clock64();
 
+    // ---- fused BatchNorm statistics (igemm.hip's scheme; from the fp32 accumulators, before any rounding of the output to bf16): one partial row per (parity class, tile, wave row) ---------------------
+    if (p.stat != nullptr && p.part == nullptr) {
+        const int row0 = m0 + wm * (32 * FM);
+        const int nrows = min(32 * FM, p.M - row0);
+        const int prow = ((ph * 2 + pw) * p.tilesM + tm) * 2 + wm;
+        float* srow = p.stat + (long)prow * p.stat_rs;
+        const int cbase = NCLS == 4 ? 0 : (wn & 1) * 64;            // first column of this wave inside its class
+        if (cbase == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
+        if (nrows > 0) {
+#pragma unroll
+            for (int jn = 0; jn < FN; ++jn) {
+                const float sh = __shfl(acc[0][jn][0], l31, 64);
+                float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (lr < nrows) {
+                            const float d = acc[i][jn][r] - sh;
+                            ssum += d;
+                            ssq += d * d;
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                const int n = cbase + jn * 32 + l31;
+                if (lh == 0 && n < Cc) {
+                    srow[4 + n] = sh;
+                    srow[4 + Cc + n] = ssum;
+                    srow[4 + 2 * Cc + n] = ssq;
+                }
+            }
+        }
+    }
+
     // ---- epilogue: the wave's 128 pixels x 64 columns of class (ph, pw); rows -> out pixel (2a + ph, 2b + pw) -----------------
     const bool to_part = p.part != nullptr;
     float* const eps = (float*)smem + wave * (32 * 68);

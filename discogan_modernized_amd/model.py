@@ -33,6 +33,15 @@ from . import ops
 FUSE_BN_STATS = {"0": False, "1": True, "split": "split"}[__import__("os").environ.get("DG_FUSE_BN", "0")]
 
 
+def _fuse_stats():
+    """Statistics from the conv kernels on the paths other than f32x3 planes?  bf16 matrix path (shadow operands / bf16-stored
+    feature maps): yes since round 3 (ops.FUSE_STATS16, DG_FUSE_BN16=0 switches it off) -- the bf16 kernels run 100-200 us per
+    launch at 512 px and the statistics pass is 3.7 % of that step; exact-fp32 path: DG_FUSE_BN (off: measured slower)."""
+    if ops.SHADOW or ops.ACT16:
+        return True if ops.FUSE_STATS16 else False
+    return FUSE_BN_STATS
+
+
 def stage_channels(image_size: int):
     n = int(round(math.log2(image_size))) - 2
     if n < 1 or 2 ** (n + 2) != image_size:
@@ -254,8 +263,8 @@ def _run_fused_steps(layers, x):
         act_mod = layers[j] if j < n and isinstance(layers[j], _Act) else None
         act = act_mod.act if act_mod is not None else ops.ACT_NONE
         slope = act_mod.negative_slope if act_mod is not None else 0.0
-        if bn is not None and bn.training and FUSE_BN_STATS and conv.emits_bn_stats and not ops.X3:
-            y, st = conv(x, want_stats=FUSE_BN_STATS)       # BN statistics from the conv / split-K reduce kernel
+        if bn is not None and bn.training and not ops.X3 and _fuse_stats() and conv.emits_bn_stats:
+            y, st = conv(x, want_stats=_fuse_stats())       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
             nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
@@ -311,8 +320,8 @@ class Discriminator(_FlatGradMixin, nn.Module):
         yield
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
-            if bn.training and FUSE_BN_STATS and not ops.X3:
-                y, st = conv(h, want_stats=FUSE_BN_STATS)   # BN statistics from the conv / split-K reduce kernel
+            if bn.training and not ops.X3 and _fuse_stats():
+                y, st = conv(h, want_stats=_fuse_stats())   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
                 _, dy_cm, _, dy_po = _plane_hints(conv, h, None, z_is_output=True)      # z is a feature map: it keeps its fp32 copy

@@ -304,6 +304,10 @@ X3_FWW = __import__("os").environ.get("DG_X3_FWW", "0") == "1"
 # path of the 64 px network the same idea lengthened 140 us kernels by more than the pass it saved: model.FUSE_BN_STATS stays off
 # there; the plane kernels run for hundreds of microseconds per tile and do not notice ~400 VALU instructions per wave.)
 X3_FUSE_STATS = __import__("os").environ.get("DG_X3_FUSE_STATS", "1") != "0"
+# FUSE_STATS16: with model.FUSE_BN_STATS on (DG_FUSE_BN=1), the bf16 matrix path takes its BatchNorm statistics from the bf16 conv
+# kernels' fp32 accumulators too (LDS-DMA kernel, window input-grad, register-staged tiles, split-K reduction: stat argument of
+# dg_conv_fwd_mixed / _dgrad_mixed) instead of dropping to the exact-fp32 kernels for the fused layers.
+FUSE_STATS16 = __import__("os").environ.get("DG_FUSE_BN16", "1") != "0"
 # X3_MFMA: the MFMA shape of the plane kernel's 256 x 256 tile (library option "x3_mfma").  16 = v_mfma_f32_16x16x32_bf16 with the
 # planes paired along k (three instructions per 16 x 16 block and K-tile instead of six 32x32x16 ones: the same products, a shape
 # under which the chip holds a higher clock; csrc/igemm_dma_x3.hip); 32 / 0 = the 32x32x16 body (default: the paired body is faster
@@ -457,7 +461,7 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     if k == 1:
         mixed = _is16(x)
         x16 = int(mixed)
-    elif rows == 0 and _bf16_ok(0, n, h, wd, c, k, stride, pad):
+    elif (rows == 0 or FUSE_STATS16) and _bf16_ok(0, n, h, wd, c, k, stride, pad):
         xa, x16 = _mixed_operand(x)
         wsh = weight_shadow(w)
         if wsh is not None:
@@ -469,9 +473,11 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     y = empty_nhwc(n, k, ho, wo, x.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * n * ho * wo * k * c * 16):
         if mixed:
-            stat = None
+            mrows = L.dg_conv_mixed_bnstats_rows(0, n, h, wd, c, k, stride, pad, x16, w16) if (want_stats and FUSE_STATS16) else 0
+            stat = torch.empty((mrows, 3 * k + 4), device=x.device, dtype=torch.float32) if mrows > 0 else None
             _lib.check(L.dg_conv_fwd_mixed(_ptr(xa), x16, _ptr(wa), w16, _ptr(y), o16, n, h, wd, c, k,
-                                           stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_fwd_mixed")
+                                           stride, pad, _ptr(stat), stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()),
+                       "dg_conv_fwd_mixed")
         elif rows > 0:
             stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
             _lib.check(L.dg_conv_fwd_bnstats(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, _ptr(stat), stat.numel(),
@@ -514,7 +520,7 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     if k == 1:
         o16 = int(_act_dtype(c) == torch.bfloat16)
         mixed = bool(o16)
-    elif rows == 0 and _bf16_ok(1, n, h, wd, c, k, stride, pad):
+    elif (rows == 0 or FUSE_STATS16) and _bf16_ok(1, n, h, wd, c, k, stride, pad):
         if k % 8 == 0:
             da, d16 = _mixed_operand(dy)
         wsh = weight_shadow(w)
@@ -527,9 +533,11 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     dx = empty_nhwc(n, c, h, wd, dy.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * n * dy.shape[2] * dy.shape[3] * k * c * 16):
         if mixed:
-            stat = None
+            mrows = L.dg_conv_mixed_bnstats_rows(1, n, h, wd, c, k, stride, pad, d16, w16) if (want_stats and FUSE_STATS16 and k > 1) else 0
+            stat = torch.empty((mrows, 3 * c + 4), device=dy.device, dtype=torch.float32) if mrows > 0 else None
             _lib.check(L.dg_conv_dgrad_mixed(_ptr(da), d16, _ptr(wa), w16, _ptr(dx), o16, n, h, wd, c, k,
-                                             stride, pad, _ptr(ws), wsb, _stream()), "dg_conv_dgrad_mixed")
+                                             stride, pad, _ptr(stat), stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()),
+                       "dg_conv_dgrad_mixed")
         elif rows > 0:
             stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)
             _lib.check(L.dg_conv_dgrad_bnstats(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, _ptr(stat), stat.numel(),

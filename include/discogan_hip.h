@@ -297,10 +297,14 @@ int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16
                        const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                        int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad);
+/* stat (may be NULL): fused BatchNorm partial statistics of the OUTPUT, taken from the fp32 accumulators before the output is
+ * rounded: dg_conv_mixed_bnstats_rows(op, ..., operand flags) rows of 3 * columns + 4 floats (0 rows: this plan emits none),
+ * merged by dg_bn_stats_from_partials */
+int dg_conv_mixed_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad, int a_bf16, int b_bf16);
 int dg_conv_fwd_mixed(const void* x, int x_bf16, const void* w, int w_bf16, void* y, int y_bf16, int N, int H, int W, int C, int K,
-                      int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+                      int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_dgrad_mixed(const void* dy, int dy_bf16, const void* w, int w_bf16, void* dx, int dx_bf16, int N, int H, int W, int C, int K,
-                        int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream);
+                        int stride, int pad, float* stat, size_t stat_floats, void* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, int x_bf16, float* dw, int N, int H, int W, int C, int K,
                         int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
 

@@ -796,6 +796,8 @@ def test_bf16_shadow_operands_are_bitwise_neutral(monkeypatch):
     from discogan_modernized_amd import _lib
     A, B = synthetic_batch(4, 64, 0, DEV)
     res = []
+    # statistics from the conv kernels' accumulators exist on the shadow path only (stat argument of dg_conv_*_mixed): compare like with like
+    monkeypatch.setattr(ops, "FUSE_STATS16", False)
     # the LDS-DMA kernel (both operands shadowed, big layers) sums in another order: keep every conv on the register-staged
     # tiles for the bitwise comparison; test_bf16_lds_dma_step_matches_register_staged covers the other kernel
     _lib.set_option("no_dma", 1)

@@ -1176,3 +1176,49 @@ def test_plane_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
     close(rm2, rm1, rtol=1e-5, atol=1e-7, what="running mean")
     close(rv2, rv1, rtol=1e-5, atol=1e-7, what="running var")
     assert int(nb1) == int(nb2) == 1
+
+
+@pytest.mark.parametrize("N,C,K,H,op", [(2, 64, 256, 64, 0), (1, 256, 512, 32, 0), (32, 512, 1024, 16, 0), (2, 64, 128, 64, 0),
+                                        (2, 256, 64, 64, 1), (1, 128, 256, 128, 1), (2, 512, 256, 32, 1), (32, 1024, 512, 16, 1)])
+def test_bf16_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
+    """bf16 matrix path with bf16-stored feature maps (BASELINE configs[4]): the bf16 conv kernels (LDS-DMA kernel, window input-grad
+    kernel, register-staged tiles, split-K reduction) emit the BatchNorm partial rows of their output from the fp32 ACCUMULATORS,
+    before the output is rounded to bf16 (stat argument of dg_conv_fwd_mixed / dg_conv_dgrad_mixed).  Merged, they must equal the
+    statistics of the separate pass over the UNROUNDED (fp32) output of the same kernel to fp32 rounding, the stored bf16 output
+    must not change, and against the statistics of the rounded output they differ by no more than the rounding carries."""
+    x, w = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    dy = rnd(N, K, H // 2, H // 2, seed=3)
+    xg, wg, dyg = nhwc(x).bfloat16(), krsc(w), nhwc(dy).bfloat16()
+    xg, dyg = xg.contiguous(memory_format=torch.channels_last), dyg.contiguous(memory_format=torch.channels_last)
+    L = _lib.load()
+    _lib.set_option("bf16", 1)
+    ops.SHADOW = True
+    try:
+        wg._dg_bf16, wg._dg_bf16_ver = wg.detach().bfloat16(), wg._version
+        run = (lambda **kw: ops.conv_fwd(xg, wg, 2, 1, **kw)) if op == 0 else (lambda **kw: ops.conv_dgrad(dyg, wg, (H, H), 2, 1, **kw))
+        ops.ACT16 = True
+        y16, stat = run(want_stats=True)
+        y16_plain = run()
+        ops.ACT16 = False
+        y32 = run()                                            # the same kernel, fp32 output
+        assert stat is not None and y16.dtype == torch.bfloat16 and y32.dtype == torch.float32
+        ch = y16.shape[1]
+        mk = lambda: (torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64))
+        (rm1, rv1, nb1), (rm2, rv2, nb2), (rm3, rv3, nb3) = mk(), mk(), mk()
+        s_sep = ops.bn_train_stats(y32, rm1, rv1, nb1, 1e-5, 0.1)
+        s_fus = ops.bn_stats_from_partials(stat, y16, rm2, rv2, nb2, 1e-5, 0.1)
+        s_rnd = ops.bn_train_stats(y16, rm3, rv3, nb3, 1e-5, 0.1)
+    finally:
+        ops.ACT16 = False
+        ops.SHADOW = False
+        ops.shadow_clear()
+        _lib.set_option("bf16", 0)
+    assert torch.equal(y16, y16_plain), "the stored output must not depend on the statistics epilogue"
+    close(s_fus[0], s_sep[0], rtol=1e-5, atol=1e-6, what="fused mean vs separate pass over the fp32 output")
+    close(s_fus[1], s_sep[1], rtol=1e-5, atol=1e-6, what="fused invstd")
+    close(rm2, rm1, rtol=1e-5, atol=1e-7, what="running mean")
+    close(rv2, rv1, rtol=1e-5, atol=1e-7, what="running var")
+    sd = 1.0 / s_sep[1]
+    assert float(((s_fus[0] - s_rnd[0]).abs() / sd).max()) < 2e-3, "mean vs statistics of the bf16-rounded output"
+    close(s_fus[1], s_rnd[1], rtol=5e-3, what="invstd vs statistics of the bf16-rounded output")
+    assert int(nb2) == 1
