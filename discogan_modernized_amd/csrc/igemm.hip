@@ -62,7 +62,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // 16-byte load, no conversion on the way into LDS.  Numerically identical to rounding the fp32 tensor here (same RNE).
 template <int MODE, int WM, int WN, int KT, bool BUF, int PREC, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
-    static_assert(!(A16 || B16) || (BUF && PREC == 1), "bf16 sources exist for the bf16 tile kernels only");
+    static_assert(!(A16 || B16) || (BUF && (PREC == 1 || PREC == 2)), "bf16 sources exist for the bf16 tile kernels only");
+    // PLN (PREC 2 with A16 and B16): BOTH operands arrive as bf16 PLANE TRIPLES (a_plane / b_plane bytes apart), written once by their
+    // producers -- the loader fetches three 16-byte vectors of 8 bf16 per item and stores them to the LDS planes as they are: no
+    // fp32 -> 3 x bf16 split in this kernel (5.5 VALU instructions per operand element, a quarter of the register-staged f32x3
+    // kernel's instruction stream on the 64 -> 128 channel forward, whose matrix pipes were 63 % busy).  Forward form only.
+    constexpr bool PLN = PREC == 2 && A16 && B16;
+    static_assert(!(PREC == 2 && (A16 != B16)), "f32x3: both operands split in the kernel, or both as plane triples");
+    static_assert(!PLN || MODE == MODE_FWD, "the plane-reading register-staged tiles serve the forward form");
     constexpr int AEG = A16 ? 8 : 4, BEG = B16 ? 8 : 4;     // elements per 16-byte load granule
     constexpr int AEB = A16 ? 2 : 4, BEB = B16 ? 2 : 4;     // bytes per element in HBM
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -232,6 +239,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // every load through it is dropped by the range check while the instruction stream stays (guide, section 7)
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, BUF ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, BUF ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
+    // PLN: one descriptor per plane (an offset that runs off the end of a plane must not land in the next one)
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (PLN ? p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (PLN ? 2 * p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (PLN ? p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (PLN ? 2 * p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
     int a_ob[NVA], a_inv[NVA], b_ob[NVB];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
@@ -293,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     auto fwd_s = [&]() { const int b = tap & 3; return ((b & 1) << 1) | (b >> 1); };
 
     f32x4 ra[2][NVA], rb[2][NVB];   // two register sets: tiles t+1 (waiting to be written to LDS) and t+2 (in flight)
+    f32x4 ra1[2][PLN ? NVA : 1], ra2[2][PLN ? NVA : 1], rb1[2][PLN ? NVB : 1], rb2[2][PLN ? NVB : 1];   // PLN: the mid / lo planes
 
     // Branch-free tile loads: an invalid (padding / out-of-range) vector loads from the tensor base and
     // is zeroed by a select, so the whole K-loop body is ONE basic block and the address arithmetic,
@@ -307,7 +320,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         if (BUF && MODE == MODE_FWD) {
             const int r = fwd_r(), sx = fwd_s();
             const int soff = ((r * W + sx) * Cc + chunk * KT) * AEB;                // wave-uniform
-            ra[set][i] = ld4b(rA, (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1));
+            const int voff = (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1);
+            ra[set][i] = ld4b(rA, voff);
+            if constexpr (PLN) {
+                ra1[set][i] = ld4b(rA1, voff);
+                ra2[set][i] = ld4b(rA2, voff);
+            }
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
@@ -354,7 +372,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     };
     auto load_B = [&](int set, int i, int it) {
         if (BUF && MODE == MODE_FWD) {
-            rb[set][i] = ld4b(rB, b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * BEB);
+            const int voff = b_ob[i] + (((fwd_r() * 4 + fwd_s()) * Cc) + chunk * KT) * BEB;
+            rb[set][i] = ld4b(rB, voff);
+            if constexpr (PLN) {
+                rb1[set][i] = ld4b(rB1, voff);
+                rb2[set][i] = ld4b(rB2, voff);
+            }
         } else if (BUF && MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
             const int r = ph == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 2 : 0);
@@ -562,13 +585,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     auto sth_A = [&](char* stage, int set, int i) {
         const int row = arow0 + i * A_RSTEP;
         char* dst = stage + (A_KM ? (row * LDAH + acq * AEG) * 2 : kc_off(row, LDAH, acq * AEG));
-        if constexpr (A16) *(f32x4*)dst = ra[set][i];            // already bf16: 8 elements, one ds_write_b128
+        if constexpr (PLN) {
+            *(f32x4*)dst = ra[set][i];
+            *(f32x4*)(dst + APL_BYTES) = ra1[set][i];
+            *(f32x4*)(dst + 2 * APL_BYTES) = ra2[set][i];
+        } else if constexpr (A16) *(f32x4*)dst = ra[set][i];            // already bf16: 8 elements, one ds_write_b128
         else split_store(dst, APL_BYTES, ra[set][i]);
     };
     auto sth_B = [&](char* stage, int set, int i) {
         const int row = brow0 + i * B_RSTEP;
         char* dst = stage + AH_BYTES + (B_KM ? (row * LDBH + bcq * BEG) * 2 : kc_off(row, LDBH, bcq * BEG));
-        if constexpr (B16) *(f32x4*)dst = rb[set][i];
+        if constexpr (PLN) {
+            *(f32x4*)dst = rb[set][i];
+            *(f32x4*)(dst + BPL_BYTES) = rb1[set][i];
+            *(f32x4*)(dst + 2 * BPL_BYTES) = rb2[set][i];
+        } else if constexpr (B16) *(f32x4*)dst = rb[set][i];
         else split_store(dst, BPL_BYTES, rb[set][i]);
     };
     // transposed fragment read: lane l = 16g + 4q + p supplies row (k0 + q), columns c0 + 16*(g&1) + 4p .. +3 and
@@ -588,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     //   PREC 2: per load item   {hi planes + store, residuals, mid planes + store, residuals, lo planes + store, re-load}
     // MFMA q of the tile: PREC 1 k16 step q/4, accumulators (q/2)&1, q&1; PREC 2 plane pair q/4 of the six.
     constexpr int NMF = (KT / 16) * 4 * (PREC == 2 ? 6 : 1);          // MFMAs per K-tile per wave
-    constexpr int SPI = PREC == 2 ? 6 : 2;                             // staging steps per load item
+    constexpr int SPI = PLN ? 4 : (PREC == 2 ? 6 : 2);                 // staging steps per load item (PLN: three plane stores, re-load)
     constexpr int NST = NLD * SPI;
     constexpr int SPM = (NST + NMF - 1) / NMF;                         // staging steps behind each MFMA
     // PREC 2 fragments live across tiles: set (tile parity) is multiplied while the next tile's set is fetched right
@@ -626,12 +657,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             int plane;
             if (isA) {
                 const int row = arow0 + ii * A_RSTEP;
-                dst = nxt + (A_KM ? (row * LDAH + acq * 4) * 2 : kc_off(row, LDAH, acq * 4));
+                dst = nxt + (A_KM ? (row * LDAH + acq * AEG) * 2 : kc_off(row, LDAH, acq * AEG));
                 plane = APL_BYTES;
             } else {
                 const int row = brow0 + ii * B_RSTEP;
-                dst = nxt + AH_BYTES + (B_KM ? (row * LDBH + bcq * 4) * 2 : kc_off(row, LDBH, bcq * 4));
+                dst = nxt + AH_BYTES + (B_KM ? (row * LDBH + bcq * BEG) * 2 : kc_off(row, LDBH, bcq * BEG));
                 plane = BPL_BYTES;
+            }
+            if constexpr (PLN) {
+                if (ph == 0) *(f32x4*)dst = v;
+                else if (ph == 1) *(f32x4*)(dst + plane) = isA ? ra1[p_ ^ 1][ii] : rb1[p_ ^ 1][ii];
+                else if (ph == 2) *(f32x4*)(dst + 2 * plane) = isA ? ra2[p_ ^ 1][ii] : rb2[p_ ^ 1][ii];
+                else if (isA) load_A(p_ ^ 1, ii, itn);
+                else load_B(p_ ^ 1, ii, itn);
+                return;
             }
             if (ph == 0) {
                 th0 = pk2(v[0], v[1]); th1 = pk2(v[2], v[3]);
@@ -1120,7 +1159,7 @@ static int choose_splits(int base_wgs, int nIt, int dflt_target = 0) {
 }
 
 // op: 0 fwd, 1 dgrad, 2 wgrad;  a16 / b16: that operand is a bf16 tensor (only honoured on the bf16 tile path)
-static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 = 0) {
+static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 = 0, int allow_fww = 1) {
     IgemmArgs& a = pl->a;
     a = IgemmArgs();
     a.N = g.N; a.H = g.H; a.W = g.W; a.Cc = g.C; a.K = g.K;
@@ -1214,7 +1253,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         }
         // forward with <= 128 output channels: the input window of one (chunk, parity class) in LDS, re-used by the class's four taps
         // (igemm_dma_x3_fww.hip); whole output rows per 256-pixel tile, transposed weight planes; no split-K
-        else if (pl->mode == MODE_FWD && g.stride == 2 && g.pad == 1 && g.K <= 128 && g.K % 8 == 0 && g.C % 16 == 0 && g.Wo >= 32 &&
+        else if (allow_fww && pl->mode == MODE_FWD && g.stride == 2 && g.pad == 1 && g.K <= 128 && g.K % 8 == 0 && g.C % 16 == 0 && g.Wo >= 32 &&
                  g.Wo <= 128 && (g.Ho * g.Wo) % 256 == 0 && dg_get_option(DG_OPT_DMA_MFMA) != 1) {
             pl->dma = 5;
             pl->ncls = 4;
@@ -1265,6 +1304,10 @@ static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
         if (a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, true>), dim3(grid), dim3(256), 0, st, a); return; }
         if (!a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, false, true>), dim3(grid), dim3(256), 0, st, a); return; }
         if (a.a16 && !a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, false>), dim3(grid), dim3(256), 0, st, a); return; }
+    }
+    if constexpr (PREC == 2 && MODE == MODE_FWD && WM == 2 && WN == 2) {
+        // both operands as plane triples (a16 = b16 = 3): the loader copies the planes, no split in the kernel
+        if (a.a16 == 3 && a.b16 == 3) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 2, true, true>), dim3(grid), dim3(256), 0, st, a); return; }
     }
     hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), dim3(grid), dim3(256), 0, st, a);
 }
@@ -1522,6 +1565,12 @@ extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int 
 // a3 / b3 point at plane 0 (hi) of an operand; planes 1 (mid) and 2 (lo) follow a_plane / b_plane BYTES further on (>= the
 // tensor's 2 * numel; a weight inside a flat parameter group has the group's plane distance).  Written by dg_f32_to_bf16x3 or
 // by the fused producers (dg_adam_step_flat_x3, dg_bn_act_fwd_x3, dg_bn_act_bwd_x3); outputs are fp32.
+// forward, stride 2, no LDS-DMA plane kernel for the shape (fewer than 192 output channels or rows): the register-staged 128 x 128
+// tiles can read plane triples (16-byte granules of 8 bf16: C % 8 == 0; buffer-descriptor kernels only)
+static bool x3_register_staged_planes_ok(int op, const ConvGeom& g, const Plan& pl) {
+    return op == 0 && g.stride == 2 && pl.a.prec == 2 && pl.mode == MODE_FWD && pl.wm == 2 && pl.wn == 2 && pl.kt == 16 && g.C % 16 == 0 &&
+           pl.a.abytes != 0 && pl.a.bbytes != 0;
+}
 static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_plane, int b_transposed, float* out, int N, int H, int W, int C, int K,
                    int stride, int pad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int a_layout = 0, float* stat = nullptr,
                    size_t stat_floats = 0) {
@@ -1533,9 +1582,13 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 2, "%s: plane operands need option bf16 = 2", who);
     DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no plane form", who);
     Plan pl;
-    make_plan(op, g, &pl, 3, 3);
-    if (pl.dma != 2 && pl.dma != 3 && pl.dma != 5) return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
-    if (pl.dma == 5 && !b_transposed) return dg_fail(DG_ERR_INVALID, "%s: the window forward kernel reads the TRANSPOSED weight planes (dg_x3_transpose_planes)", who);
+    // forward with plain (not transposed) weight planes where the window forward kernel would apply: the register-staged tiles read
+    // the planes instead (igemm_kernel<.., PREC 2, A16, B16>)
+    make_plan(op, g, &pl, 3, 3, (op == 0 && !b_transposed) ? 0 : 1);
+    const bool rs_planes = pl.dma == 0 && x3_register_staged_planes_ok(op, g, pl);
+    if (pl.dma != 2 && pl.dma != 3 && pl.dma != 5 && !rs_planes)
+        return dg_fail(DG_ERR_INVALID, "%s: this shape has no plane kernel (ask dg_conv_x3_planes_ok)", who);
+    DG_CHECK_ARG(!(rs_planes && b_transposed), "%s: the register-staged plane reader takes the PLAIN weight planes", who);
     DG_CHECK_ARG(a_plane >= (long)pl.a.abytes && b_plane >= (long)pl.a.bbytes && a_plane % 16 == 0 && b_plane % 16 == 0,
                  "%s: plane distances %ld / %ld (operands are %u / %u bytes per plane)", who, a_plane, b_plane, pl.a.abytes, pl.a.bbytes);
     pl.a.A = (const float*)a3; pl.a.B = (const float*)b3; pl.a.C = out; pl.a.accumulate = accumulate;
@@ -1579,14 +1632,16 @@ extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, int dy_layout, c
     return conv_x3(2, dy3, dy_plane, x3, x_plane, 0, dw, N, H, W, C, K, stride, pad, accumulate, ws, ws_bytes, (hipStream_t)stream, dy_layout);
 }
 // does this (op, shape) have a plane kernel under option bf16 = 2?  (host planning aid)  0: no; 1: yes; 3: yes -- the window
-// FORWARD kernel, which needs the transposed weight planes (w_transposed = 1 of dg_conv_fwd_x3); 2: yes, and it is the
-// window input-grad kernel, which wants its gradient operand in the quad-chunk layout (plane_layout 1 of dg_bn_act_*_x3)
+// FORWARD kernel with the transposed weight planes (w_transposed = 1 of dg_conv_fwd_x3), the register-staged plane reader with the
+// plain ones; 4: yes -- the register-staged tiles read the (plain) planes; 2: yes, and it is the window input-grad kernel, which
+// wants its gradient operand in the quad-chunk layout (plane_layout 1 of dg_bn_act_*_x3)
 extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_x3_planes_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
     if (dg_get_option(DG_OPT_BF16) != 2) return 0;
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
+    if (pl.dma == 0 && x3_register_staged_planes_ok(op, g, pl)) return 4;
     return pl.dma == 5 ? 3 : (pl.dma == 3 ? (K % 64 == 0 ? 2 : 1) : (pl.dma == 2 ? 1 : 0));
 }
 

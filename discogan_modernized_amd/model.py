@@ -233,7 +233,8 @@ def _first_layer_planes(x, nxt):
     if not (ops.X3 and C3_PLANES and isinstance(nxt, Conv2d) and nxt.stride == 2):
         return False
     n, _, h, w = x.shape
-    if ops._x3_ok(0, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1) and getattr(nxt.weight, "_dg_x3", (None, 0, None))[2] is not None:
+    if ops._x3_ok(0, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1) and \
+            (ops.X3_RSP or getattr(nxt.weight, "_dg_x3", (None, 0, None))[2] is not None):
         return True
     return torch.is_grad_enabled() and nxt.weight.requires_grad and ops._x3_ok(2, n, h // 2, w // 2, nxt.in_channels, nxt.out_channels, 2, 1)
 

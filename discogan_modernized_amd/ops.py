@@ -316,8 +316,17 @@ FUSE_STATS16 = __import__("os").environ.get("DG_FUSE_BN16", "1") != "0"
 X3_MFMA = int(__import__("os").environ.get("DG_OPT_X3_MFMA", "0"))
 
 
+# X3_RSP (off: measured 45 % SLOWER): forward convs without an LDS-DMA plane kernel (fewer than 192 output channels: the 64 -> 128
+# layer and, same GEMM, the input-grad of the 128 -> 64 transposed conv) on the register-staged 128 x 128 tiles READING the plane
+# triples their producers wrote (dg_conv_x3_planes_ok codes 3 / 4: igemm_kernel<.., PREC 2, A16, B16>) instead of splitting fp32
+# operands inside the kernel.  Bit-identical, a quarter fewer instructions -- and 1.36 instead of 0.94 ms at 512 px / batch 32: a
+# 16-channel K-tile of a pixel-major plane is a 32-byte piece of a 128-byte line, three planes make it three times as many load
+# instructions of half the useful width (the fp32 operand: 64-byte pieces).  DG_X3_RSP=1 switches it on.  DESIGN.md 3.1.
+X3_RSP = __import__("os").environ.get("DG_X3_RSP", "0") == "1"
+
+
 def _plane_code_ok(code):
-    return code >= 1 and (code != 3 or X3_FWW)
+    return code in (1, 2) or (code == 3 and (X3_FWW or X3_RSP)) or (code == 4 and X3_RSP)
 _PLANE_TAB = {}
 
 
@@ -444,9 +453,12 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
     code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (X3 and k > 1) else 0
-    if code >= 1:
+    if _plane_code_ok(code):
         wp, wdist, wt = weight_planes(w, transposed=True)
-        if code != 3 or (wt and X3_FWW):         # 3 = the window forward kernel: it reads the TRANSPOSED weight planes only
+        if code == 4 or (code == 3 and not (wt and X3_FWW)):
+            # the register-staged tiles read the PLAIN planes (3 with transposed planes and X3_FWW: the window forward kernel)
+            wp, wdist, wt = (*weight_planes(w)[:2], 0) if X3_RSP else (None, 0, 0)
+        if wp is not None:
             xp, xd, _ = planes_of(x)
             y = empty_nhwc(n, k, ho, wo, x.device)
             srows = L.dg_conv_x3_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0

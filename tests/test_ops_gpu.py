@@ -306,7 +306,7 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
     try:
         yreg, dxreg, dwreg = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
         M = N * (H // 2) ** 2
-        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == int(K >= 192 and M >= 192)
+        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == (1 if (K >= 192 and M >= 192) else 4)     # 4: register-staged tiles read the planes
         assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == int(C >= 192 and M >= 192)
         assert L.dg_conv_x3_planes_ok(2, N, H, H, C, K, 2, 1) == 1
         ops.X3 = True
@@ -1222,3 +1222,45 @@ def test_bf16_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
     assert float(((s_fus[0] - s_rnd[0]).abs() / sd).max()) < 2e-3, "mean vs statistics of the bf16-rounded output"
     close(s_fus[1], s_rnd[1], rtol=5e-3, what="invstd vs statistics of the bf16-rounded output")
     assert int(nb2) == 1
+
+
+X3_RSP_SHAPES = [
+    (1, 64, 128, 256),     # the benchmark layer (window-forward shape: code 3)
+    (3, 48, 96, 32),       # Wo = 16: no window kernel (code 4); 3 chunks, 96 of 128 columns
+    (2, 128, 64, 64),      # one 128 x 128 tile column half used
+    (5, 32, 160, 16),      # Wo = 8, two column tiles (160 = 128 + 32), ragged rows (5 x 64 = 320 = 2.5 tiles)
+    (32, 512, 128, 8),     # deep reduction (8192): split-K
+]
+
+
+@pytest.mark.parametrize("N,C,K,H", X3_RSP_SHAPES)
+@pytest.mark.parametrize("splitk", [0, 1])
+def test_conv_f32x3_register_staged_tiles_read_planes(N, C, K, H, splitk, monkeypatch):
+    """Forward convs with fewer than 192 output channels on the f32x3 plane path (ops.X3_RSP): the register-staged 128 x 128 tiles
+    load the operands' PLANE TRIPLES (igemm_kernel<.., PREC 2, A16, B16>) instead of splitting fp32 operands in the kernel.  The
+    planes are exactly what the in-kernel split computes and the MFMA sequence is the same: BIT-IDENTICAL to the splitting kernel,
+    borders, ragged tiles and split-K included."""
+    x, w = rnd(N, C, H, H, seed=1), rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C))
+    y64 = TF.conv2d(x.double(), w.double(), stride=2, padding=1)
+    xg, wg = nhwc(x), krsc(w)
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    _lib.set_option("splitk", splitk)
+    try:
+        yreg = ops.conv_fwd(xg, wg, 2, 1)                     # fp32 operands, split in the kernel
+        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) in (3, 4)
+        ops.X3 = True
+        monkeypatch.setattr(ops, "X3_RSP", False)
+        y_off = ops.conv_fwd(xg, wg, 2, 1)
+        assert len(ops._PLANE_TAB) == 0 and torch.equal(y_off, yreg)       # switch off: nothing is split into planes
+        monkeypatch.setattr(ops, "X3_RSP", True)
+        y = ops.conv_fwd(xg, wg, 2, 1)
+        torch.cuda.synchronize()
+        assert len(ops._PLANE_TAB) == 1                        # x was split into planes once: the plane reader ran
+    finally:
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("bf16", 0)
+        _lib.set_option("splitk", 0)
+    close(y, y64.float(), what="register-staged plane reader")
+    assert torch.equal(y, yreg), "plane reader vs in-kernel split"
