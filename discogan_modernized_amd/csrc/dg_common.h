@@ -34,7 +34,7 @@ static inline bool dg_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline size_t dg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int dg_get_option(int idx);
-enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_COUNT = 11 };
+enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_DGW_PERSIST = 11, DG_OPT_COUNT = 12 };
 
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ float dg_wave_sum(float v) {

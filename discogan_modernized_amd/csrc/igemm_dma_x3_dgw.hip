@@ -37,8 +37,12 @@ __device__ __forceinline__ void dgw_static_for(std::integer_sequence<int, Q...>,
 }
 
 // NCLS: parity classes per workgroup (4: 64 columns each, 2: 128 columns each, ph = blockIdx parity)
-template <int NCLS>
-__global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p) {
+// PERSIST: the grid is one workgroup per CU and every workgroup walks the tiles bid = blockIdx.x, + gridDim.x, ...; the DMA of the
+// NEXT tile's first window and weight tiles is issued BEFORE the finished tile's statistics / epilogue, which run out of the other
+// window stage: with one workgroup per CU (150 KB of LDS) nothing else hides a tile's prologue (stamps, round 2: 9.5 us of an 84 us
+// workgroup before the first MFMA, 8.3 us of epilogue).
+template <int NCLS, bool PERSIST>
+__global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p, const int nblocks) {
     constexpr int WN = 4, FM = 4, FN = 2, KT = 16;      // 2 x 4 waves of 128 x 64
     constexpr int CW = 256 / NCLS;                      // columns per class
     constexpr int WPMAX = 17;                           // window pieces (32 rows each) per plane: (R + 2)(Wo + 2) <= 544 rows
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     constexpr int B_OFF = 0, A_OFF = 2 * BST;           // weight stages first: their fragment reads then fit ds_read's 16-bit offsets
     constexpr int LDS_BYTES = 2 * AST + 2 * BST;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(8 * 32 * 68 * 4 <= LDS_BYTES, "epilogue transpose regions live in the operand stages");
+    constexpr int EPI_OFF = A_OFF + AST;                // epilogue transposes: 8 waves x [16][68] floats in window stage 1 (free after the K loop;
+    static_assert(8 * 16 * 68 * 4 <= AST, "epilogue transpose regions live in window stage 1");     // the next tile's prologue fills stage 0 and the weight stages)
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -66,37 +71,41 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- blockIdx -> (pixel tile, ph for NCLS == 2, split) ----------------------------------------------------------
+    // ---- block index -> (pixel tile, ph for NCLS == 2, split) -------------------------------------------------------------
     // Vertically adjacent pixel tiles share two of their (R + 2) window rows and the ZM workgroups of a tile share the whole
     // window: workgroups are dealt to the 8 XCDs round robin, so XCD x takes the tiles [x tilesM / 8, (x + 1) tilesM / 8) in
     // order (the ph workgroups of a tile back to back) and the shared rows are L2 hits instead of a second fabric fetch.
+    // (PERSIST: gridDim.x is a multiple of 8 whenever tilesM is, so a workgroup's tiles stay on its XCD's share.)
     constexpr int ZM = 4 / NCLS;
-    int bid = blockIdx.x;
-    int tm, zph, split;
-    if ((p.tilesM & 7) == 0) {
-        const int per = p.tilesM >> 3, x = bid & 7;
-        int j = bid >> 3;
-        zph = j % ZM;
-        j /= ZM;
-        tm = x * per + j % per;
-        split = j / per;
-    } else {
-        tm = bid % p.tilesM;
-        bid /= p.tilesM;
-        zph = bid % ZM;
-        split = bid / ZM;
-    }
-    const int m0 = tm * 256;
-    const int cb = split * p.itPerSplit;                       // chunk range of this split
-    const int ce = min(p.nIt, cb + p.itPerSplit);
-
     const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
     const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
-    // tile = R rows x Wo pixels of image n, rows a0 .. a0 + R - 1; window = rows a0 - 1 .. a0 + R, columns -1 .. Wo
     const int WW = Wo + 2;
-    const int n_img = m0 >> lgHW, a0 = (m0 >> lgWo) & (Ho - 1);
     const int WR = (256 / Wo + 2) * WW;                       // window rows
     const int wpieces = (WR + 31) >> 5;
+    int tm, zph, split, m0, cb, ce, n_img, a0;
+    auto decode = [&](int bid) {
+        if ((p.tilesM & 7) == 0) {
+            const int per = p.tilesM >> 3, x = bid & 7;
+            int j = bid >> 3;
+            zph = j % ZM;
+            j /= ZM;
+            tm = x * per + j % per;
+            split = j / per;
+        } else {
+            tm = bid % p.tilesM;
+            bid /= p.tilesM;
+            zph = bid % ZM;
+            split = bid / ZM;
+        }
+        m0 = tm * 256;
+        cb = split * p.itPerSplit;                             // chunk range of this split
+        ce = min(p.nIt, cb + p.itPerSplit);
+        // tile = R rows x Wo pixels of image n, rows a0 .. a0 + R - 1; window = rows a0 - 1 .. a0 + R, columns -1 .. Wo
+        n_img = m0 >> lgHW;
+        a0 = (m0 >> lgWo) & (Ho - 1);
+    };
+    int bid_cur = blockIdx.x;
+    decode(bid_cur);
 
     constexpr int OOR = (int)0x80000000;
     __amdgpu_buffer_rsrc_t rA[3], rB[3];
@@ -111,32 +120,47 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     // piece pc covers window rows 32 pc .. 32 pc + 31; lane L lands in (row 32 pc + L / 2, slot L % 2), fetches granule
     // slot ^ ((row >> 3) & 1) of gradient pixel (a0 - 1 + row / WW, row % WW - 1); outside the image or the window: zeros
     int w_ob[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int pc = wave + 8 * j;
-        const int row = pc * 32 + (lane >> 1);
-        const int g = (lane & 1) ^ ((row >> 3) & 1);
-        const int wr = row / WW, wc = row - wr * WW;
-        const int a = a0 - 1 + wr, b = wc - 1;
-        const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
-        const int pix = (n_img * Ho + a) * Wo + b;
-        // quad-chunk planes [pixels / 4][K / 16][4][16]: the chunk of 4 consecutive pixels is one 128-byte line -- a window row
-        // of a chunk uses every byte of the lines it touches
-        w_ob[j] = ok ? (p.a_cm ? ((pix >> 2) * (4 * K) + (pix & 3) * 16 + g * 8) * 2 : (pix * K + g * 8) * 2) : OOR;
-    }
-    // ---- weight DMA descriptors: tile [16 k][256 columns], column = class-local-index * CW + c; one piece per plane ----
-    // piece = k rows 2 w, 2 w + 1; lane L lands in (k row 2 w + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
-    // the tap (r, s) of (class, t) is part of the per-lane offset: one offset per t
     int b_base, b_ph, b_pw;
-    {
-        const int krow = wave * 2 + (lane >> 5);
-        const int gc = (lane & 31) ^ kmswz(krow);
-        const int col = gc * 8;
-        const int bcls = col / CW, cc = col - bcls * CW;
-        b_ph = NCLS == 4 ? (bcls >> 1) : zph;
-        b_pw = NCLS == 4 ? (bcls & 1) : bcls;
-        b_base = cc < Cc ? (krow * 16 * Cc + cc) * 2 : OOR;
-    }
+    // class of this wave's columns and, per tap t, the window-row shift dyo * WW + dxo of that class
+    const int cls = NCLS == 4 ? wn : (wn >> 1);
+    int ph, pw, shift[4];
+    auto tile_setup = [&]() {          // everything that depends on (tm, zph): called after decode()
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int pc = wave + 8 * j;
+            const int row = pc * 32 + (lane >> 1);
+            const int g = (lane & 1) ^ ((row >> 3) & 1);
+            const int wr = row / WW, wc = row - wr * WW;
+            const int a = a0 - 1 + wr, b = wc - 1;
+            const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
+            const int pix = (n_img * Ho + a) * Wo + b;
+            // quad-chunk planes [pixels / 4][K / 16][4][16]: the chunk of 4 consecutive pixels is one 128-byte line -- a window row
+            // of a chunk uses every byte of the lines it touches
+            w_ob[j] = ok ? (p.a_cm ? ((pix >> 2) * (4 * K) + (pix & 3) * 16 + g * 8) * 2 : (pix * K + g * 8) * 2) : OOR;
+        }
+        // ---- weight DMA descriptors: tile [16 k][256 columns], column = class-local-index * CW + c; one piece per plane ----
+        // piece = k rows 2 w, 2 w + 1; lane L lands in (k row 2 w + L / 32, slot L % 32), fetches granule slot ^ kmswz(k row);
+        // the tap (r, s) of (class, t) is part of the per-lane offset: one offset per t
+        {
+            const int krow = wave * 2 + (lane >> 5);
+            const int gc = (lane & 31) ^ kmswz(krow);
+            const int col = gc * 8;
+            const int bcls = col / CW, cc = col - bcls * CW;
+            b_ph = NCLS == 4 ? (bcls >> 1) : zph;
+            b_pw = NCLS == 4 ? (bcls & 1) : bcls;
+            b_base = cc < Cc ? (krow * 16 * Cc + cc) * 2 : OOR;
+        }
+        ph = NCLS == 4 ? (cls >> 1) : zph;
+        pw = NCLS == 4 ? (cls & 1) : cls;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = t >> 1, tx = t & 1;
+            const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
+            const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
+            shift[t] = dyo * WW + dxo;
+        }
+    };
+    tile_setup();
 
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
     auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int lds_off, int voff) {
@@ -167,17 +191,6 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     };
 
     // ---- fragment reads ----------------------------------------------------------------------------------------------
-    // class of this wave's columns and, per tap t, the window-row shift dyo * WW + dxo of that class
-    const int cls = NCLS == 4 ? wn : (wn >> 1);
-    const int ph = NCLS == 4 ? (cls >> 1) : zph, pw = NCLS == 4 ? (cls & 1) : cls;
-    int shift[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ty = t >> 1, tx = t & 1;
-        const int dyo = ph == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 0 : 1);
-        const int dxo = pw == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 0 : 1);
-        shift[t] = dyo * WW + dxo;
-    }
     // window row of lane 0's pixel in the wave's 32-pixel block i (wave-uniform; a block never straddles an image row: Wo >= 32)
     int srow[FM];
 #pragma unroll
@@ -212,12 +225,6 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
     };
 
     f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- DMA-side state: the step (wc, wt) whose weight tile is issued next; clamped to the last step -------------------
     int wc = cb, wt = 0;
@@ -228,26 +235,20 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
         wt = wrap ? 0 : wt;
         wc += wrap;
     };
-
-    // ---- prologue: window of the first chunk, weight tiles of steps 0 and 1 ----------------------------------------------
-    if (cb < ce) {
+    // ---- prologue DMA of the tile decode() / tile_setup() describe: window of the first chunk, weight tiles of steps 0 and 1 ------
+    auto issue_prologue = [&]() {
+        wc = cb;
+        wt = 0;
+        if (cb < ce) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) issue_window(0, pl, cb);
-        issue_weights(0, wc, wt);
-        advance();
-        issue_weights(1, wc, wt);
-        advance();
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // all but the second weight tile
-    }
-    __builtin_amdgcn_s_barrier();
-    if (stp) stp[2] = clock64();
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) fetchA(0, pl, i, 0);
-    }
+            for (int pl = 0; pl < 3; ++pl) issue_window(0, pl, cb);
+            issue_weights(0, wc, wt);
+            advance();
+            issue_weights(1, wc, wt);
+            advance();
+        }
+    };
+    issue_prologue();
 
     // ---- one step (chunk c in window stage AS, tap T; weight stage T & 1): 48 MFMAs per wave, schedule of igemm_dma_x3.hip ----
     // next step: tap T + 1 of the same window, or tap 0 of the next chunk's window (stage AS ^ 1, complete since the
@@ -289,99 +290,158 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_dgw_kernel(const IgemmArgs p)
         fetchA(NAS, 1, 3, NT);
         fetchA(NAS, 2, 3, NT);
     };
-    for (int c = cb; c < ce; c += 2) {
-        dgw_static_for(std::make_integer_sequence<int, 8>{}, [&](auto B_) {
-            constexpr int bi = decltype(B_)::value;
-            if (c + bi / 4 < ce) body(std::integral_constant<int, bi / 4>{}, std::integral_constant<int, bi % 4>{}, c + bi / 4);
-        });
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (stp) stp[3] = clock64();
+    for (;;) {
+        // ---- the tile's first window and weight tiles have been issued (before the loop / before the previous tile's epilogue) ----
+        // (vmcnt(0): the previous tile's epilogue stores are in the same counter and return out of order with the loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stp) stp[2] = clock64();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fetchB(0, pl, j, 0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fetchA(0, pl, i, 0);
+        }
+        for (int c = cb; c < ce; c += 2) {
+            dgw_static_for(std::make_integer_sequence<int, 8>{}, [&](auto B_) {
+                constexpr int bi = decltype(B_)::value;
+                if (c + bi / 4 < ce) body(std::integral_constant<int, bi / 4>{}, std::integral_constant<int, bi % 4>{}, c + bi / 4);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stp) stp[3] = clock64();
 
-    // ---- fused BatchNorm statistics (igemm.hip's scheme): one partial row per (parity class, tile, wave row) ---------------------
-    if (p.stat != nullptr && p.part == nullptr) {
-        const int row0 = m0 + wm * (32 * FM);
-        const int nrows = min(32 * FM, p.M - row0);
-        const int prow = ((ph * 2 + pw) * p.tilesM + tm) * 2 + wm;
-        float* srow = p.stat + (long)prow * p.stat_rs;
-        const int cbase = NCLS == 4 ? 0 : (wn & 1) * 64;            // first column of this wave inside its class
-        if (cbase == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
-        if (nrows > 0) {
+        // what the statistics and the epilogue of the FINISHED tile need, before decode() / tile_setup() move on to the next one
+        const int e_m0 = m0, e_tm = tm, e_split = split, e_ph = ph, e_pw = pw;
+        const int nbid = bid_cur + (int)gridDim.x;
+        const bool more = PERSIST && nbid < nblocks;                   // workgroup-uniform
+        if (more) {
+            // every read of the operand stages is complete (barrier above): the next tile's first window goes to window stage 0, its
+            // first two weight tiles to the weight stages; the epilogue below works in window stage 1
+            bid_cur = nbid;
+            decode(nbid);
+            tile_setup();
+            issue_prologue();
+        }
+
+        // ---- fused BatchNorm statistics (igemm.hip's scheme): one partial row per (parity class, tile, wave row) -----------------
+        if (p.stat != nullptr && p.part == nullptr) {
+            const int row0 = e_m0 + wm * (32 * FM);
+            const int nrows = min(32 * FM, p.M - row0);
+            const int prow = ((e_ph * 2 + e_pw) * p.tilesM + e_tm) * 2 + wm;
+            float* srow = p.stat + (long)prow * p.stat_rs;
+            const int cbase = NCLS == 4 ? 0 : (wn & 1) * 64;            // first column of this wave inside its class
+            if (cbase == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
+            if (nrows > 0) {
 #pragma unroll
-            for (int jn = 0; jn < FN; ++jn) {
-                const float sh = __shfl(acc[0][jn][0], l31, 64);
-                float ssum = 0.f, ssq = 0.f;
+                for (int jn = 0; jn < FN; ++jn) {
+                    const float sh = __shfl(acc[0][jn][0], l31, 64);
+                    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                    for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (lr < nrows) {
-                            const float d = acc[i][jn][r] - sh;
-                            ssum += d;
-                            ssq += d * d;
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (lr < nrows) {
+                                const float d = acc[i][jn][r] - sh;
+                                ssum += d;
+                                ssq += d * d;
+                            }
                         }
+                    ssum += __shfl_xor(ssum, 32, 64);
+                    ssq += __shfl_xor(ssq, 32, 64);
+                    const int n = cbase + jn * 32 + l31;
+                    if (lh == 0 && n < Cc) {
+                        srow[4 + n] = sh;
+                        srow[4 + Cc + n] = ssum;
+                        srow[4 + 2 * Cc + n] = ssq;
                     }
-                ssum += __shfl_xor(ssum, 32, 64);
-                ssq += __shfl_xor(ssq, 32, 64);
-                const int n = cbase + jn * 32 + l31;
-                if (lh == 0 && n < Cc) {
-                    srow[4 + n] = sh;
-                    srow[4 + Cc + n] = ssum;
-                    srow[4 + 2 * Cc + n] = ssq;
                 }
             }
         }
-    }
 
-    // ---- epilogue: the wave's 128 pixels x 64 columns of class (ph, pw); rows -> out pixel (2a + ph, 2b + pw) -----------------
-    const bool to_part = p.part != nullptr;
-    float* const eps = (float*)smem + wave * (32 * 68);
-    const int erow = lane >> 4, ec4 = (lane & 15) * 4;
-    const int ccol = (NCLS == 4 ? 0 : (wn & 1) * 64) + ec4;            // column inside the class
-    const int parity = ph * 2 + pw;
+        // ---- epilogue: the wave's 128 pixels x 64 columns of class (ph, pw); rows -> out pixel (2a + ph, 2b + pw) -------------
+        // transposed through a private [16][68] LDS region per wave, 16 rows (half an accumulator block) at a time
+        const bool to_part = p.part != nullptr;
+        float* const eps = (float*)(smem + EPI_OFF) + wave * (16 * 68);
+        const int erow = lane >> 4, ec4 = (lane & 15) * 4;
+        const int ccol = (NCLS == 4 ? 0 : (wn & 1) * 64) + ec4;            // column inside the class
+        const int parity = e_ph * 2 + e_pw;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+        for (int i = 0; i < FM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            eps[lr * 68 + l31] = acc[i][0][r];
-            eps[lr * 68 + 32 + l31] = acc[i][1][r];
-        }
+            for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = t * 4 + erow;
-            f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
-            const int m = m0 + wm * (32 * FM) + i * 32 + row;
-            if (m >= p.M || ccol >= Cc) continue;
-            float* dst;
-            long eoff;
-            if (to_part) {
-                dst = p.part;
-                eoff = (((long)split * 4 + parity) * p.M + m) * Cc + ccol;
-            } else {
-                const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
-                dst = p.C;
-                eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ccol;
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = hf * 8 + r8;
+                    const int lr = (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;      // row inside the half: acc row (r&3) + 8 (r>>2) + 4 lh, minus 16 hf
+                    eps[lr * 68 + l31] = acc[i][0][r];
+                    eps[lr * 68 + 32 + l31] = acc[i][1][r];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = t * 4 + erow;
+                    f32x4 v = *(const f32x4*)(eps + row * 68 + ec4);
+                    const int m = e_m0 + wm * (32 * FM) + i * 32 + hf * 16 + row;
+                    if (m >= p.M || ccol >= Cc) continue;
+                    float* dst;
+                    long eoff;
+                    if (to_part) {
+                        dst = p.part;
+                        eoff = (((long)e_split * 4 + parity) * p.M + m) * Cc + ccol;
+                    } else {
+                        const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
+                        dst = p.C;
+                        eoff = (long)((n * H + 2 * a + e_ph) * W + 2 * b + e_pw) * Cc + ccol;
+                    }
+                    if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
+                    *(f32x4*)(dst + eoff) = v;
+                }
             }
-            if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
-            *(f32x4*)(dst + eoff) = v;
         }
-    }
-    if (stp) {
-        stp[4] = clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stp[5] = wall_clock64();
-        stp[7] = clock64();
+        if (stp) {
+            stp[4] = clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stp[5] = wall_clock64();
+            stp[7] = clock64();
+        }
+        if (!more) break;
     }
 }
 
-// host: launch for a plan made by igemm.hip (ncls = 4 / 2); grid = pixel tiles x (4 / ncls) x splits
+// host: launch for a plan made by igemm.hip (ncls = 4 / 2); blocks = pixel tiles x (4 / ncls) x splits, one workgroup each.  Option
+// "dgw_persist" 1 with more blocks than CUs (each workgroup owns a CU: 150 KB of LDS): one persistent workgroup per CU walks them --
+// bit-identical, and measured NOT faster (same-box A/B at 512 px / batch 32: input-grad 0.694 / 0.686 -> 0.714 / 0.718 ms at 64
+// channels, 0.599 / 0.597 -> 0.602 / 0.601 at 128; whole step 292.8 / 292.1 -> 292.2 / 291.4 images/s): in steady state the tile
+// prologue is not the 9.5 us the stamps of a cold launch showed, and the wait for the epilogue's stores at the top of the tile
+// loop takes back what the early DMA gains.  DESIGN.md 3.1.
 int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st) {
-    const int grid = a.tilesM * (4 / ncls) * a.splits;
-    if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4>), dim3(grid), dim3(512), 0, st, a);
-    else if (ncls == 2) hipLaunchKernelGGL((igemm_x3_dgw_kernel<2>), dim3(grid), dim3(512), 0, st, a);
+    const int nblocks = a.tilesM * (4 / ncls) * a.splits;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) ncu = -1;
+        else ncu = prop.multiProcessorCount;
+    }
+    const bool persist = dg_get_option(DG_OPT_DGW_PERSIST) == 1 && ncu > 0 && nblocks > ncu && a.stamps == nullptr;
+    if (persist) {
+        const int grid = ncu & ~7 ? (ncu & ~7) : ncu;       // a multiple of 8: a workgroup's tiles stay on its XCD's share
+        if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4, true>), dim3(grid), dim3(512), 0, st, a, nblocks);
+        else if (ncls == 2) hipLaunchKernelGGL((igemm_x3_dgw_kernel<2, true>), dim3(grid), dim3(512), 0, st, a, nblocks);
+        else return 0;
+        return 1;
+    }
+    if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4, false>), dim3(nblocks), dim3(512), 0, st, a, nblocks);
+    else if (ncls == 2) hipLaunchKernelGGL((igemm_x3_dgw_kernel<2, false>), dim3(nblocks), dim3(512), 0, st, a, nblocks);
     else return 0;
     return 1;
 }

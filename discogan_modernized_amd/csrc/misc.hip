@@ -29,6 +29,7 @@ extern "C" int dg_set_option(const char* name, int value) {
     else if (!strcmp(name, "no_dma")) g_options[DG_OPT_NO_DMA] = value;   // 1: bf16-operand convs stay on the register-staged tiles (igemm.hip) instead of the LDS-DMA kernel
     else if (!strcmp(name, "dma_mfma")) g_options[DG_OPT_DMA_MFMA] = value;   // 32: the LDS-DMA kernel's 32x32x16 body instead of 16x16x32; 1: no window kernels (A/B)
     else if (!strcmp(name, "x3_mfma")) g_options[DG_OPT_X3_MFMA] = value;   // 16: the f32x3 plane kernel's 16x16x32 body (planes paired along k) instead of 32x32x16
+    else if (!strcmp(name, "dgw_persist")) g_options[DG_OPT_DGW_PERSIST] = value;   // 1: the f32x3 window input-grad kernel as one persistent workgroup per CU (measured not faster)
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)
     else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);
     return DG_OK;

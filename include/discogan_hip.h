@@ -63,6 +63,8 @@ const char* dg_last_error(void);
  *   output channels on the register-staged tiles instead of the window kernels (same-box A/B);
  * "x3_mfma" 16: the f32x3 plane kernel's 256 x 256 tile on the 16x16x32 MFMA with the planes paired along k instead of the
  *   default 32x32x16 body (same products; measured not faster in the whole step);
+ * "dgw_persist" 1: the f32x3 window input-grad kernel as one persistent workgroup per CU when there are more tiles than CUs (the
+ *   next tile's first DMA is issued in front of the finished tile's epilogue; bit-identical, measured not faster);
  * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results). */
 int dg_set_option(const char* name, int value);
 

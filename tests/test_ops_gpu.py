@@ -1264,3 +1264,40 @@ def test_conv_f32x3_register_staged_tiles_read_planes(N, C, K, H, splitk, monkey
         _lib.set_option("splitk", 0)
     close(y, y64.float(), what="register-staged plane reader")
     assert torch.equal(y, yreg), "plane reader vs in-kernel split"
+
+
+@pytest.mark.parametrize("N,C,K,H,splitk", [(8, 64, 128, 256, 0), (16, 128, 256, 128, 0), (40, 64, 64, 64, 2), (5, 40, 64, 256, 0)])
+def test_window_input_grad_persistent_workgroups(N, C, K, H, splitk):
+    """Option "dgw_persist" 1, more tiles than CUs: the f32x3 window input-grad kernel runs ONE persistent workgroup per CU that walks
+    the tiles and issues the next tile's first window / weight DMA in front of the finished tile's statistics and epilogue (which
+    work in the other window stage).  Same products in the same order per tile: output and fused BatchNorm partial rows
+    BIT-IDENTICAL to one workgroup per tile (the default: the persistent form measured no faster), 4- and 2-class forms, split-K, a
+    ragged channel count."""
+    w, dy = rnd(K, C, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * C)), rnd(N, K, H // 2, H // 2, seed=3)
+    wg, dyg = krsc(w), nhwc(dy)
+    L = _lib.load()
+    _lib.set_option("bf16", 2)
+    _lib.set_option("splitk", splitk)
+    ops.X3 = True
+    try:
+        assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == 2
+        res = []
+        for mode in (0, 1):
+            _lib.set_option("dgw_persist", mode)
+            dx, stat = ops.conv_dgrad(dyg, wg, (H, H), 2, 1, want_stats=True)
+            dx2 = ops.conv_dgrad(dyg, wg, (H, H), 2, 1)
+            torch.cuda.synchronize()
+            res.append((dx.clone(), None if stat is None else stat.clone(), dx2.clone()))
+    finally:
+        _lib.set_option("dgw_persist", 0)
+        ops.X3 = False
+        ops.planes_clear()
+        _lib.set_option("splitk", 0)
+        _lib.set_option("bf16", 0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]), "persistent vs one workgroup per tile"
+    assert (res[0][1] is None) == (res[1][1] is None)
+    if res[0][1] is not None:
+        # (columns 1..3 of a partial row are padding nobody writes)
+        assert torch.equal(res[0][1][:, 0], res[1][1][:, 0]) and torch.equal(res[0][1][:, 4:], res[1][1][:, 4:]), "partial statistics rows"
+    dx64 = TF.conv_transpose2d(dy.double(), w.double(), stride=2, padding=1)
+    close(res[1][0], dx64.float(), rtol=2e-4, what="persistent window input-grad")
