@@ -316,7 +316,7 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
         assert len(ops._PLANE_TAB) == 2                                  # x and dy were split once each
         # the forward form on the TRANSPOSED weight planes (what a weight of a flat Adam group gets): the same MFMAs in the
         # same order, only the weight tile's path into LDS differs -> bit-identical
-        if L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1):
+        if L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == 1:
             buf = wg._dg_x3[0]
             wg._dg_x3, wg._dg_x3_ver = (buf, 0, torch.zeros_like(buf)), None
             yt = ops.conv_fwd(xg, wg, 2, 1)
