@@ -1226,7 +1226,7 @@ def test_bf16_kernels_emit_batchnorm_partial_statistics(N, C, K, H, op):
 
 X3_RSP_SHAPES = [
     (1, 64, 128, 256),     # the benchmark layer (window-forward shape: code 3)
-    (3, 48, 96, 32),       # Wo = 16: no window kernel (code 4); 3 chunks, 96 of 128 columns
+    (3, 96, 96, 32),       # Wo = 16: no window kernel (code 4); 6 chunks, 96 of 128 columns
     (2, 128, 64, 64),      # one 128 x 128 tile column half used
     (5, 32, 160, 16),      # Wo = 8, two column tiles (160 = 128 + 32), ragged rows (5 x 64 = 320 = 2.5 tiles)
     (32, 512, 128, 8),     # deep reduction (8192): split-K
