@@ -390,7 +390,7 @@ class DiscoGANTrainer:
         if self.skip_dead_work and not dstep:
             for p in self.optim_dis.params:               # a G-step froze the D parameters: give them back
                 p.requires_grad_(True)
-        if self.async_wgrad:
+        if self.async_wgrad and self.wgrad_stream is not None:      # (bench.py's instrumented single-stream pass takes the stream away)
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:
             # the backward kernels of the A-side chain ran on the side stream and wrote the flat gradient
