@@ -23,23 +23,33 @@ from . import ops
 
 
 # BatchNorm statistics can come out of the producing conv kernel's epilogue (dg_conv_*_bnstats) instead of a
-# separate read pass.  Measured on MI355X (round 1): with the two-stream schedule the separate HBM-bound
-# statistics pass overlaps the other chain's MFMA kernels for free, while the fused form lengthens the
-# MFMA kernels' tails: 15.21 vs 14.95 ms/step at 64 px / batch 256, 182.5 vs 182.9 at 512 px.
-#   False   : always the separate statistics pass (default; fastest under the two-stream schedule)
+# separate read pass.  Measured on MI355X: with the two-stream schedule the separate HBM-bound statistics pass overlaps the
+# other chain's MFMA kernels almost for free, while the fused form lengthens the MFMA kernels' tails and needs its partial rows
+# merged: 15.21 vs 14.95 ms/step at 64 px / batch 256 (round 1, exact fp32: 140 us kernels) -- but 164.9 vs 165.6 ms at 512 px /
+# batch 32 (round 3, same-box A/B, alternating: 194.0 / 194.0 against 193.2 / 193.1 images/s; 800 us kernels).
+#   "auto"  : exact-fp32 path: fused where the conv launch is at least 40 GFLOP (every interior layer at 512 px / batch 32 is 69 or
+#             137; the 64 px / batch 256 layers are 14) -- the default
+#   False   : always the separate statistics pass
 #   "split" : fused only for layers whose conv plan uses split-K -- the statistics then come out of the
-#             split-K reduction kernel (measured 15.14 ms/step: still slower than the separate pass)
+#             split-K reduction kernel (measured 15.14 ms/step at 64 px: still slower than the separate pass)
 #   True    : fused everywhere
-FUSE_BN_STATS = {"0": False, "1": True, "split": "split"}[__import__("os").environ.get("DG_FUSE_BN", "0")]
+FUSE_BN_STATS = {"auto": "auto", "0": False, "1": True, "split": "split"}[__import__("os").environ.get("DG_FUSE_BN", "auto")]
+FUSE_BN_MIN_FLOP = 4e10
 
 
-def _fuse_stats():
+def _fuse_stats(conv=None, x=None):
     """Statistics from the conv kernels on the paths other than f32x3 planes?  bf16 matrix path (shadow operands / bf16-stored
     feature maps): yes since round 3 (ops.FUSE_STATS16, DG_FUSE_BN16=0 switches it off) -- the bf16 kernels run 100-200 us per
-    launch at 512 px and the statistics pass is 3.7 % of that step; exact-fp32 path: DG_FUSE_BN (off: measured slower)."""
+    launch at 512 px and the statistics pass is 3.7 % of that step; exact-fp32 path: DG_FUSE_BN, by default by the size of the launch."""
     if ops.SHADOW or ops.ACT16:
         return True if ops.FUSE_STATS16 else False
-    return FUSE_BN_STATS
+    if FUSE_BN_STATS != "auto":
+        return FUSE_BN_STATS
+    if conv is None or x is None:
+        return False
+    n, _, h, w = x.shape
+    pixels = h * w if isinstance(conv, ConvTranspose2d) else (h * w) // 4        # GEMM rows per image (x 4 parity classes folded in)
+    return 2.0 * n * pixels * 16 * conv.in_channels * conv.out_channels >= FUSE_BN_MIN_FLOP
 
 
 def stage_channels(image_size: int):
@@ -264,8 +274,8 @@ def _run_fused_steps(layers, x):
         act_mod = layers[j] if j < n and isinstance(layers[j], _Act) else None
         act = act_mod.act if act_mod is not None else ops.ACT_NONE
         slope = act_mod.negative_slope if act_mod is not None else 0.0
-        if bn is not None and bn.training and not ops.X3 and _fuse_stats() and conv.emits_bn_stats:
-            y, st = conv(x, want_stats=_fuse_stats())       # BN statistics from the conv / split-K reduce kernel
+        if bn is not None and bn.training and not ops.X3 and _fuse_stats(conv, x) and conv.emits_bn_stats:
+            y, st = conv(x, want_stats=_fuse_stats(conv, x))       # BN statistics from the conv / split-K reduce kernel
             x = bn(y, act, slope, st)
         elif bn is not None:
             nxt = layers[j + (1 if act_mod is not None else 0)] if j + (1 if act_mod is not None else 0) < n else None
@@ -321,8 +331,8 @@ class Discriminator(_FlatGradMixin, nn.Module):
         yield
         for i in range(2, self.n_stages + 1):
             relu, bn, conv = getattr(self, f"relu{i}"), getattr(self, f"bn{i}"), getattr(self, f"conv{i}")
-            if bn.training and not ops.X3 and _fuse_stats():
-                y, st = conv(h, want_stats=_fuse_stats())   # BN statistics from the conv / split-K reduce kernel
+            if bn.training and not ops.X3 and _fuse_stats(conv, h):
+                y, st = conv(h, want_stats=_fuse_stats(conv, h))   # BN statistics from the conv / split-K reduce kernel
                 h = bn(y, ops.ACT_LEAKY, relu.negative_slope, st)
             else:
                 _, dy_cm, _, dy_po = _plane_hints(conv, h, None, z_is_output=True)      # z is a feature map: it keeps its fp32 copy

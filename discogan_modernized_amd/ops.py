@@ -301,10 +301,10 @@ X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
 X3_FWW = __import__("os").environ.get("DG_X3_FWW", "0") == "1"
 # X3_FUSE_STATS: on the plane path the BatchNorm batch statistics come out of the producing conv kernel's epilogue (or its split-K
 # reduction) as partial rows, merged by dg_bn_stats_from_partials -- no separate read pass over the conv output.  (On the exact-fp32
-# path of the 64 px network the same idea lengthened 140 us kernels by more than the pass it saved: model.FUSE_BN_STATS stays off
-# there; the plane kernels run for hundreds of microseconds per tile and do not notice ~400 VALU instructions per wave.)
+# path of the 64 px network the same idea lengthened 140 us kernels by more than the pass it saved: model.FUSE_BN_STATS fuses only
+# launches of 40 GFLOP and more there; the plane kernels run for hundreds of microseconds per tile and do not notice ~400 VALU instructions per wave.)
 X3_FUSE_STATS = __import__("os").environ.get("DG_X3_FUSE_STATS", "1") != "0"
-# FUSE_STATS16: with model.FUSE_BN_STATS on (DG_FUSE_BN=1), the bf16 matrix path takes its BatchNorm statistics from the bf16 conv
+# FUSE_STATS16: the bf16 matrix path takes its BatchNorm statistics from the bf16 conv
 # kernels' fp32 accumulators too (LDS-DMA kernel, window input-grad, register-staged tiles, split-K reduction: stat argument of
 # dg_conv_fwd_mixed / _dgrad_mixed) instead of dropping to the exact-fp32 kernels for the fused layers.
 FUSE_STATS16 = __import__("os").environ.get("DG_FUSE_BN16", "1") != "0"
