@@ -60,6 +60,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // A16 / B16 (PREC 1 only): that operand already is bf16 in HBM (a shadow copy its producer wrote: the Adam kernel for
 // weights, bn_act_fwd / bn_bwd_apply / c3_fwd for activations and gradients) -- half the operand bytes, 8 elements per
 // 16-byte load, no conversion on the way into LDS.  Numerically identical to rounding the fp32 tensor here (same RNE).
+// option "dbg_zero" bit 3 (value 8): the f32x3 forward walks 16-channel chunks with the taps inside (the order before round 3) -- A/B switch
+__device__ __forceinline__ bool dg_get_subwalk(const IgemmArgs& p) { return (p.dbg_zero & 8) == 0; }
 template <int MODE, int WM, int WN, int KT, bool BUF, int PREC, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     static_assert(!(A16 || B16) || (BUF && (PREC == 1 || PREC == 2)), "bf16 sources exist for the bf16 tile kernels only");
@@ -294,9 +296,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // taps that read the same input pixels (s and s+2 shift by one output column, r and r+2 by one output row) are
     // then 1 and 4 K-tiles apart instead of 2*kchunks and 8*kchunks, so the re-reads hit the XCD's L2 more often
     // (PMC FETCH_SIZE, profiles/).  `tap` counts 0..15 in that order; (fwd_r, fwd_s) is the filter position.
+    // f32x3 forward with whole 64-channel groups (PREC 2: a 16-channel K-tile is a 64-byte HALF of a pixel's 128-byte line):
+    // the walk is 64-channel group major, taps inside, and the group's FOUR K-tiles innermost, so the two halves of a line are
+    // requested by back-to-back tiles (the order of igemm_dma_x3.hip: there the same change was worth 8-14 %); `chunk` stays the
+    // 16-channel chunk index the offsets use, = cgrp * SUBF + sub
+    const int SUBF = (PREC == 2 && MODE == MODE_FWD && (Cc & 63) == 0 && dg_get_subwalk(p)) ? 4 : 1;
+    int sub = 0, cgrp = 0;
     if (MODE == MODE_FWD) {
-        chunk = it_begin >> 4;
-        tap = it_begin & 15;
+        sub = it_begin % SUBF;
+        tap = (it_begin / SUBF) & 15;
+        cgrp = it_begin / (SUBF * 16);
+        chunk = cgrp * SUBF + sub;
     } else if (MODE == MODE_DGRAD_S2) {     // same idea: the 2x2 taps of a parity class are adjacent K-tiles
         chunk = it_begin >> 2;
         tap = it_begin & 3;
@@ -425,10 +435,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // (tap, chunk) advance without control flow; `go` = 0 freezes the state on the last iteration
     auto advance = [&](int go) {
         if (MODE == MODE_FWD) {
-            tap += go;
+            sub += go;
+            const int w1 = (sub == SUBF) ? 1 : 0;
+            sub = w1 ? 0 : sub;
+            tap += w1;
             const int wrap = (tap == 16) ? 1 : 0;
             tap = wrap ? 0 : tap;
-            chunk += wrap;
+            cgrp += wrap;
+            chunk = cgrp * SUBF + sub;
         } else if (MODE == MODE_DGRAD_S2) {
             tap += go;
             const int wrap = (tap == 4) ? 1 : 0;
