@@ -65,7 +65,9 @@ const char* dg_last_error(void);
  *   default 32x32x16 body (same products; measured not faster in the whole step);
  * "dgw_persist" 1: the f32x3 window input-grad kernel as one persistent workgroup per CU when there are more tiles than CUs (the
  *   next tile's first DMA is issued in front of the finished tile's epilogue; bit-identical, measured not faster);
- * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results). */
+ * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results); bit 2 (4): the window forward kernel walks its
+ *   super-chunks chunk-major, bit 3 (8): the register-staged f32x3 forward walks 16-channel chunks with the taps inside (the order
+ *   before round 3) -- both correct results in another summation order (same-box A/B switches). */
 int dg_set_option(const char* name, int value);
 
 /* ---- interior convolutions: implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------
