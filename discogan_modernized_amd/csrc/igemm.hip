@@ -124,7 +124,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     int bid = blockIdx.x;
     int tn, tm, parity = 0, split;
-    if (p.xcd_group == 2) {
+    if (p.xcd_group == 3) {
+        // ONE column tile (forward with <= 128 output channels): vertically adjacent row tiles share half of their input rows (a
+        // 4x4 / stride-2 window reaches one input row into the tile above and below).  Dealt round robin, neighbours land on
+        // different XCDs and every input row crosses the fabric twice (counters: 1.67x the algorithmic bytes after the group walk);
+        // here XCD x takes the row tiles [x tilesM / 8, (x + 1) tilesM / 8) in order, like the window kernels.
+        const int per = p.tilesM >> 3, x = bid & 7, j = bid >> 3;
+        tn = 0;
+        tm = x * per + j % per;
+        split = j / per;
+    } else if (p.xcd_group == 2) {
         // Weight-dominated layers (deep stages: the B operand is tens to hundreds of MB, A a few MB): the row tiles
         // that stream the SAME weight columns / K-slice are the ones that must share an L2 -- the G = tilesM row tiles
         // of one (column tile, parity, split) get blockIdx values 8 apart (one XCD, one dispatch window).
@@ -1283,15 +1292,18 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
     // measured (PMC, MB per launch beyond L2, 64 px layers): forward 83 -> 76, weight-grad 222 -> 90, input-grad with
     // the 256x64 tile 135 -> 104, input-grad with 128x128 tiles 64 -> 76 (worse: left in plain order)
-    a.xcd_group = ((a.tilesM * a.splits) % 8 == 0 && dg_get_option(DG_OPT_RESERVED) == 0 &&
+    const int xopt = dg_get_option(DG_OPT_RESERVED);       // "no_xcd_group": 1 = plain order everywhere, 3 = only mode 3 below off
+    a.xcd_group = ((a.tilesM * a.splits) % 8 == 0 && (xopt == 0 || xopt == 3) &&
                    !(pl->mode == MODE_DGRAD_S2 && pl->wm != 4)) ? 1 : 0;   // option "no_xcd_group" switches it off
     {   // weight-dominated layers: share the B operand instead (mode 2, see the kernel)
         const long a_bytes = (long)a.M * (pl->mode == MODE_FWD ? 16L * g.C : (pl->mode == MODE_DGRAD_S2 ? 4L * g.K : g.K)) * 4;
         const long b_bytes = (long)g.K * 16 * g.C * 4 / (pl->mode == MODE_DGRAD_S2 ? 4 : 1);
-        if ((pl->mode == MODE_FWD || pl->mode == MODE_DGRAD_S2) && dg_get_option(DG_OPT_RESERVED) == 0 && b_bytes > a_bytes &&
+        if ((pl->mode == MODE_FWD || pl->mode == MODE_DGRAD_S2) && (xopt == 0 || xopt == 3) && b_bytes > a_bytes &&
             a.tilesM > 1 && a.tilesM <= 64 && (a.tilesN * zmul * a.splits) % 8 == 0)
             a.xcd_group = 2;
     }
+    if (pl->mode == MODE_FWD && pl->dma == 0 && a.tilesN == 1 && (a.tilesM & 7) == 0 && g.stride == 2 && a.xcd_group == 1 && xopt != 3)
+        a.xcd_group = 3;              // (option "no_xcd_group" 3: keep the round-robin order -- same-box A/B)
     pl->ws_bytes = a.splits > 1 ? (size_t)a.splits * zmul * a.M * a.Ng * sizeof(float) : 0;
     pl->stat_rows = 0;
     if ((pl->mode == MODE_FWD && g.stride == 2) || pl->mode == MODE_DGRAD_S2)

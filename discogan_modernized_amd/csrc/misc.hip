@@ -23,7 +23,7 @@ extern "C" int dg_set_option(const char* name, int value) {
     else if (!strcmp(name, "kt")) g_options[DG_OPT_KT] = value;
     else if (!strcmp(name, "target_wgs")) g_options[DG_OPT_TARGET_WGS] = value;
     else if (!strcmp(name, "split_below")) g_options[DG_OPT_SPLIT_BELOW] = value;
-    else if (!strcmp(name, "no_xcd_group")) g_options[DG_OPT_RESERVED] = value;   // 1: plain blockIdx -> tile order
+    else if (!strcmp(name, "no_xcd_group")) g_options[DG_OPT_RESERVED] = value;   // 1: plain blockIdx -> tile order; 3: only the per-XCD row-tile blocks of single-column forward convs off
     else if (!strcmp(name, "bf16")) g_options[DG_OPT_BF16] = value;   // 1: interior conv GEMMs on bf16 MFMA, fp32 accumulate; 2: fp32 operands as three bf16 planes
     else if (!strcmp(name, "dbg_zero")) g_options[DG_OPT_DBG_ZERO] = value;   // timing experiments only: drop operand loads (wrong results)
     else if (!strcmp(name, "no_dma")) g_options[DG_OPT_NO_DMA] = value;   // 1: bf16-operand convs stay on the register-staged tiles (igemm.hip) instead of the LDS-DMA kernel

@@ -52,7 +52,8 @@ const char* dg_last_error(void);
  * "kt" 16|32: K-tile of the conv kernels;  "splitk" n: force n K-splits;  "target_wgs" n: workgroups a split
  * grid aims for (512);  "split_below" n: split K only when the tile grid has fewer workgroups (256);
  * "pointer_path" 1: use the 64-bit addressing kernels that tensors >= 2 GiB fall back to;
- * "no_xcd_group" 1: plain blockIdx -> tile order (default: workgroups sharing operand rows are placed on one XCD);
+ * "no_xcd_group" 1: plain blockIdx -> tile order (default: workgroups sharing operand rows are placed on one XCD); 3: only the
+ *   row-tile blocks per XCD of single-column forward convs off (same-box A/B);
  * "bf16" 1: the interior conv GEMMs (dg_conv_fwd/_dgrad/_wgrad and their named wrappers) round both operands to
  * bf16 and multiply on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor stays fp32 (BASELINE
  * configs[4]).  The result equals the fp32 op applied to the rounded operands up to summation order.  With "bf16" 1 the
