@@ -29,6 +29,29 @@ SIGNATURES = {
     "dg_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_workspace_bytes_p": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_bnstats_rows_p": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_plan_splits_p": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
+    "dg_conv_dgrad_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
+    "dg_conv_wgrad_g": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_c3_fwd_p": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dg_conv4x4s2_c3_dgrad_p": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_c3_wgrad_p": (_i, [_p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv4x4s2_c3_fwd_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dg_conv4x4s2_c3_dgrad_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dg_conv4x4s2_c3_wgrad_g": (_i, [_i, _i, _p, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_bn_train_stats_g": (_i, [_i, _i, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _z, _p]),
+    "dg_bn_act_fwd_g": (_i, [_i, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p]),
+    "dg_bn_act_bwd_g": (_i, [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _z, _p]),
+    "dg_act_fwd_g": (_i, [_i, _p, _p, _z, _i, _f, _p]),
+    "dg_act_bwd_g": (_i, [_i, _p, _p, _p, _z, _i, _f, _p]),
+    "dg_mse_fwd_g": (_i, [_i, _p, _p, _z, _p, _p, _z, _p]),
+    "dg_mse_bwd_g": (_i, [_i, _p, _p, _z, _p, _p, _p]),
+    "dg_bce_fwd_g": (_i, [_i, _p, _i, _p, _p, _p]),
+    "dg_bce_bwd_g": (_i, [_i, _p, _i, _p, _p, _p, _p]),
+    "dg_fm_fwd_g": (_i, [_i, _p, _p, _i, _z, _p, _p, _p, _z, _p]),
+    "dg_fm_bwd_g": (_i, [_i, _p, _i, _z, _p, _p, _p, _p]),
     "dg_conv_fwd_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "dg_conv_dgrad_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "dg_conv_plan_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),

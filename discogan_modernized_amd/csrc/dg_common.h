@@ -34,7 +34,34 @@ static inline bool dg_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline size_t dg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int dg_get_option(int idx);
+// Arithmetic of the conv products for the CURRENT call (DG_PREC_*): the `prec` argument of the *_g / *_p entry points -- held in a
+// thread-local for the duration of that call (DgPrecScope) so that planning helpers and the edge kernels' launchers see it -- else the
+// process default dg_set_option("bf16", n), which only the entry points WITHOUT the argument fall back to.
+int dg_cur_prec();
+struct DgPrecScope {
+    int old;
+    explicit DgPrecScope(int prec);
+    ~DgPrecScope();
+};
 enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_DGW_PERSIST = 11, DG_OPT_COUNT = 12 };
+
+// ---- grouped launches (round 4): one tensor per problem, picked by a block index (wave-uniform: scalar loads) ------------------
+struct DgPtrs {
+    const void* p[DG_MAX_GROUPS];
+};
+static inline DgPtrs dg_ptrs(const void* const* arr, int n) {
+    DgPtrs r;
+    for (int i = 0; i < DG_MAX_GROUPS; ++i) r.p[i] = (arr != nullptr && i < n) ? arr[i] : nullptr;
+    return r;
+}
+static inline DgPtrs dg_ptrs1(const void* p0) {
+    DgPtrs r;
+    for (int i = 0; i < DG_MAX_GROUPS; ++i) r.p[i] = nullptr;
+    r.p[0] = p0;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ T* dg_pick(const DgPtrs& t, int g) { return (T*)t.p[g]; }
 
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ float dg_wave_sum(float v) {

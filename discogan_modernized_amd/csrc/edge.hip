@@ -197,9 +197,12 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
 // of a k32 step and the weights are split into their three bf16 planes in registers (24 significand bits), six MFMAs per block
 // (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): 72 MFMAs of 16 cycles per tile and wave instead of 96 of 32.
 template <bool IN16, bool MF16 = false, bool X3 = false>
-__global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                  float* __restrict__ dx, int N, int H, int W, int act,
+__global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs dys, const DgPtrs ws_, const DgPtrs dxs, int N, int H, int W, int act,
                                                                   int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
+    // grouped launch (dg_conv4x4s2_c3_dgrad_g): blockIdx.y = problem
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.y);
+    const float* __restrict__ w = dg_pick<const float>(ws_, blockIdx.y);
+    float* __restrict__ dx = dg_pick<float>(dxs, blockIdx.y);
     static_assert(!MF16 || IN16, "the bf16 MFMA form takes a bf16 dy");
     static_assert(!X3 || (!IN16 && !MF16), "the f32x3 form takes an fp32 dy");
     typedef __bf16 bf16x8_d __attribute__((ext_vector_type(8)));
@@ -345,19 +348,39 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const float* _
 }
 
 extern "C" size_t dg_c3_dgrad_workspace_bytes(int K) { return K == CD_K ? (size_t)CD_NK * 16 * sizeof(float) : 0; }
-static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+// groups > 1 (dg_conv4x4s2_c3_dgrad_g): the scatter form only (K == 64, fp32 dy)
+static int c3_dgrad_run(int groups, const float* const* dy_nhwc, int dy_bf16, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,
                         int act, void* ws, size_t ws_bytes, dg_stream_t stream);
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
                                      int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return c3_dgrad_run(dy_nhwc, 0, w, dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
+    return c3_dgrad_run(1, &dy_nhwc, 0, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
 }
 extern "C" int dg_conv4x4s2_c3_dgrad_t(const void* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
                                        int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return c3_dgrad_run((const float*)dy_nhwc, dy_bf16, w, dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
+    const float* dyp = (const float*)dy_nhwc;
+    return c3_dgrad_run(1, &dyp, dy_bf16, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
 }
-static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+extern "C" int dg_conv4x4s2_c3_dgrad_p(const void* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                                       int act, int prec, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_dgrad_p: prec=%d", prec);
+    DgPrecScope scope(prec);
+    const float* dyp = (const float*)dy_nhwc;
+    return c3_dgrad_run(1, &dyp, dy_bf16, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
+}
+extern "C" int dg_conv4x4s2_c3_dgrad_g(int groups, const float* const* dy_nhwc, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,
+                                       int act, int prec, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && dy_nhwc && w && dx_nchw, "dg_conv4x4s2_c3_dgrad_g: bad group / null table");
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_dgrad_g: prec=%d", prec);
+    DG_CHECK_ARG(K == CD_K && dg_get_option(DG_OPT_KT) != 16, "dg_conv4x4s2_c3_dgrad_g: the grouped form is the scatter kernel (K == 64)");
+    DgPrecScope scope(prec);
+    return c3_dgrad_run(groups, dy_nhwc, 0, w, dx_nchw, N, H, W, K, act, nullptr, 0, stream);
+}
+static int c3_dgrad_run(int groups, const float* const* dy_tab, int dy_bf16, const float* const* w_tab, float* const* dx_tab, int N, int H, int W, int K,
                         int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    DG_CHECK_ARG(dy_nhwc && w && dx_nchw, "dg_conv4x4s2_c3_dgrad: null pointer");
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(dy_tab[i] && w_tab[i] && dx_tab[i], "dg_conv4x4s2_c3_dgrad: null pointer");
+    const float* dy_nhwc = dy_tab[0];
+    const float* w = w_tab[0];
+    float* dx_nchw = dx_tab[0];
     DG_CHECK_ARG(!dy_bf16 || (K == CD_K && dg_get_option(DG_OPT_KT) != 16), "dg_conv4x4s2_c3_dgrad_t: a bf16 dy needs K == 64 (scatter form)");
     DG_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0, "dg_conv4x4s2_c3_dgrad: bad N/K (%d,%d)", N, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_dgrad: H,W must be powers of two");
@@ -370,22 +393,25 @@ static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float
             const int tiles_r = (Ho + CS_TR - 1) / CS_TR, tiles_c = (Wo + CS_TC - 1) / CS_TC;
             const long ntiles = (long)N * tiles_r * tiles_c;
             DG_CHECK_ARG(ntiles < (1L << 30), "dg_conv4x4s2_c3_dgrad: too many tiles");
-            const int grid = (int)(ntiles < 512 ? ntiles : 512);
-            if (dy_bf16 && dg_get_option(DG_OPT_BF16) == 1)      // bf16 matrix path: bf16 MFMA
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, true>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+            const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512), groups);
+            const DgPtrs pd = dg_ptrs((const void* const*)dy_tab, groups), pw = dg_ptrs((const void* const*)w_tab, groups),
+                         px = dg_ptrs((const void* const*)dx_tab, groups);
+            if (dy_bf16 && dg_cur_prec() == 1)      // bf16 matrix path: bf16 MFMA
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, true>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
             else if (dy_bf16)
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, false>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
-            else if (dg_get_option(DG_OPT_BF16) == 2)           // f32x3 path: fp32-accurate products on the bf16 MFMA
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false, true>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+            else if (dg_cur_prec() == 2)           // f32x3 path: fp32-accurate products on the bf16 MFMA
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false, true>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
             else
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false>), dim3(grid), dim3(256), 0, st, dy_nhwc, w, dx_nchw, N, H, W, act,
+                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
                                    tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
             DG_CHECK_LAUNCH("c3_dgrad_scatter");
             return DG_OK;
         }
+        DG_CHECK_ARG(groups == 1, "dg_conv4x4s2_c3_dgrad: the gather form takes one problem");
         const int tiles_r = (Ho + CD_TR - 1) / CD_TR, tiles_c = (Wo + CD_TC - 1) / CD_TC;
         const long ntiles = (long)N * tiles_r * tiles_c;
         DG_CHECK_ARG(ntiles < (1L << 31), "dg_conv4x4s2_c3_dgrad: too many tiles");
@@ -399,6 +425,7 @@ static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float
         DG_CHECK_LAUNCH("c3_dgrad_mfma");
         return DG_OK;
     }
+    DG_CHECK_ARG(groups == 1, "dg_conv4x4s2_c3_dgrad: the VALU form takes one problem");
     const long nquad = (long)N * Ho * Wo;
     hipLaunchKernelGGL(c3_dgrad_valu_kernel, dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, st, dy_nhwc, w,
                        dx_nchw, N, H, W, K, dg_ilog2(Ho), dg_ilog2(Wo), act);
@@ -420,9 +447,12 @@ static int c3_dgrad_run(const float* dy_nhwc, int dy_bf16, const float* w, float
 // channel 2p + nb), so a lane owns two adjacent channels of a pixel and stores them as one dword: one 128-B store per
 // pixel row instead of two, half the bytes.
 template <int ACT, bool OUT16>
-__global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
+__global__ __launch_bounds__(256, 2) void c3_fwd_mfma_kernel(const DgPtrs xs, const DgPtrs ws_, const DgPtrs ys, int N, int H, int W, int lgHo, int lgWo,
                                                              long npix, int ngroups, float slope, int xbytes) {
+    // grouped launch (dg_conv4x4s2_c3_fwd_g): blockIdx.y = problem
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
+    const float* __restrict__ w = dg_pick<const float>(ws_, blockIdx.y);
+    float* __restrict__ y = dg_pick<float>(ys, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -540,10 +570,13 @@ typedef float f32x2_g __attribute__((ext_vector_type(2)));
 // replaced by 6 more bytes per element here.  The two accumulator blocks then hold the even / odd channels (like OUT16), so a lane
 // stores an 8-byte fp32 pair and one packed bf16 pair per plane.
 template <int ACT, bool OUT16, bool X3 = false, bool PL = false>
-__global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                 float* __restrict__ y, int N, int H, int W, int lgHo, int lgWo,
+__global__ __launch_bounds__(256, 2) void c3_fwd_bf16mfma_kernel(const DgPtrs xs, const DgPtrs ws_, const DgPtrs ys, int N, int H, int W, int lgHo, int lgWo,
                                                                  long npix, int ngroups, float slope, int xbytes,
                                                                  __bf16* __restrict__ planes = nullptr, long pstride = 0) {
+    // grouped launch (dg_conv4x4s2_c3_fwd_g): blockIdx.y = problem (the plane output exists in the one-problem form only)
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
+    const float* __restrict__ w = dg_pick<const float>(ws_, blockIdx.y);
+    float* __restrict__ y = dg_pick<float>(ys, blockIdx.y);
     static_assert(!PL || (X3 && !OUT16), "planes are written by the f32x3 form with an fp32 output");
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -678,7 +711,6 @@ extern "C" int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float
     DG_CHECK_ARG(x_nchw && w && y_nhwc && y_planes, "dg_conv4x4s2_c3_fwd_x3: null pointer");
     DG_CHECK_ARG(K == CF_K, "dg_conv4x4s2_c3_fwd_x3: K must be %d", CF_K);
     DG_CHECK_ARG(N >= 1 && dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd_x3: H, W must be powers of two");
-    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 2, "dg_conv4x4s2_c3_fwd_x3: plane output needs option bf16 = 2");
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd_x3: bad act %d", act);
     const int Ho = H / 2, Wo = W / 2;
     const long npix = (long)N * Ho * Wo;
@@ -690,7 +722,7 @@ extern "C" int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float
     if (wgs < 1) wgs = 1;
     hipStream_t st = (hipStream_t)stream;
 #define CFPL_LAUNCH(ACT)                                                                                                          \
-    hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true, true>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W, \
+    hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true, true>), dim3((unsigned)wgs), dim3(256), 0, st, dg_ptrs1(x_nchw), dg_ptrs1(w), dg_ptrs1(y_nhwc), N, H, W, \
                        dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4), (__bf16*)y_planes, (long)plane_elems)
     if (act == DG_ACT_LEAKY) { CFPL_LAUNCH(DG_ACT_LEAKY); }
     else if (act == DG_ACT_RELU) { CFPL_LAUNCH(DG_ACT_RELU); }
@@ -700,9 +732,11 @@ extern "C" int dg_conv4x4s2_c3_fwd_x3(const float* x_nchw, const float* w, float
     return DG_OK;
 }
 
-extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc_v, int y_bf16, int N, int H, int W, int act,
-                                     float slope, hipStream_t st) {
-    float* y_nhwc = (float*)y_nhwc_v;
+// the K == 64 streaming kernels, `groups` problems per launch (blockIdx.y); arithmetic = dg_cur_prec()
+extern "C" int dg_c3_fwd_mfma_launch_g(int groups, const float* const* x_tab, const float* const* w_tab, void* const* y_tab, int y_bf16, int N, int H, int W,
+                                       int act, float slope, hipStream_t st) {
+    const DgPtrs x_nchw = dg_ptrs((const void* const*)x_tab, groups), w = dg_ptrs((const void* const*)w_tab, groups),
+                 y_nhwc = dg_ptrs((const void* const*)y_tab, groups);
     const int Ho = H / 2, Wo = W / 2;
     const long npix = (long)N * Ho * Wo;
     const long ngroups = (npix + 31) / 32;
@@ -717,11 +751,11 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
     { static const hipError_t once = hipFuncSetAttribute((const void*)c3_fwd_mfma_kernel<ACT, O16>,                    \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);      \
       (void)once; }                                                                                                     \
-    hipLaunchKernelGGL((c3_fwd_mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W, \
+    hipLaunchKernelGGL((c3_fwd_mfma_kernel<ACT, O16>), dim3((unsigned)wgs, groups), dim3(256), 96 * 1024, st, x_nchw, w, y_nhwc, N, H, W, \
                        dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
-    if (dg_get_option(DG_OPT_BF16) == 2 && dg_get_option(DG_OPT_KT) != 16 && !y_bf16) {   // f32x3 path: fp32-accurate products on the bf16 MFMA
+    if (dg_cur_prec() == 2 && dg_get_option(DG_OPT_KT) != 16 && !y_bf16) {   // f32x3 path: fp32-accurate products on the bf16 MFMA
 #define CFX3_LAUNCH(ACT)                                                                                                    \
-        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W, \
+        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, false, true>), dim3((unsigned)wgs, groups), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W, \
                            dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
         if (act == DG_ACT_LEAKY) { CFX3_LAUNCH(DG_ACT_LEAKY); }
         else if (act == DG_ACT_RELU) { CFX3_LAUNCH(DG_ACT_RELU); }
@@ -729,9 +763,9 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
 #undef CFX3_LAUNCH
         return DG_OK;
     }
-    if (dg_get_option(DG_OPT_BF16) == 1 && dg_get_option(DG_OPT_KT) != 16) {     // bf16 matrix path ("kt" 16 keeps the fp32-MFMA kernel testable there)
+    if (dg_cur_prec() == 1 && dg_get_option(DG_OPT_KT) != 16) {     // bf16 matrix path ("kt" 16 keeps the fp32-MFMA kernel testable there)
 #define CF16_LAUNCH(ACT, O16)                                                                                              \
-        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, O16>), dim3((unsigned)wgs), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W,    \
+        hipLaunchKernelGGL((c3_fwd_bf16mfma_kernel<ACT, O16>), dim3((unsigned)wgs, groups), dim3(256), 0, st, x_nchw, w, y_nhwc, N, H, W,    \
                            dg_ilog2(Ho), dg_ilog2(Wo), npix, (int)ngroups, slope, (int)((long)N * 3 * H * W * 4))
         if (y_bf16) {
             if (act == DG_ACT_LEAKY) { CF16_LAUNCH(DG_ACT_LEAKY, true); }
@@ -757,6 +791,10 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
 #undef CF_LAUNCH
     return DG_OK;
 }
+extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc_v, int y_bf16, int N, int H, int W, int act,
+                                     float slope, hipStream_t st) {
+    return dg_c3_fwd_mfma_launch_g(1, &x_nchw, &w, &y_nhwc_v, y_bf16, N, H, W, act, slope, st);
+}
 
 // ---- weight gradient -------------------------------------------------------------------------------------
 // dw[k][c][r][s] (+)= sum_{pixels} dy[pix][k] * x[n,c,2oy-1+r,2ox-1+s]
@@ -771,10 +809,14 @@ extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* 
 // IN16 (BUF only): dy and act_out are bf16.  A lane then loads ONE dword = channels (2 l31, 2 l31 + 1) of its pixel, so MFMA
 //       block i holds the channels of parity i: block i, row rho <-> channel 2 rho + i.
 template <bool BUF, bool FACT, bool IN16 = false>
-__global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               float* __restrict__ part, int N, int H, int W, int K,
+__global__ __launch_bounds__(256, 2) void c3_wgrad_mfma_kernel(const DgPtrs dys, const DgPtrs xs, const DgPtrs parts, int N, int H, int W, int K,
                                                                int lgHo, int lgWo, long npix, int pix_per_wave,
-                                                               const float* __restrict__ act_out, float slope) {
+                                                               const DgPtrs act_outs, float slope) {
+    // grouped launch (dg_conv4x4s2_c3_wgrad_g): blockIdx.z = problem
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.z);
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.z);
+    float* __restrict__ part = dg_pick<float>(parts, blockIdx.z);
+    const float* __restrict__ act_out = dg_pick<const float>(act_outs, blockIdx.z);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -1055,9 +1097,13 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_bf16mfma_kernel(const float* 
 // kernel above needs 96 of 64, with coalesced image loads instead of its 24-lines-per-instruction gathers.
 #define CWL_WOMAX 256
 template <bool FACT, bool X3 = false>
-__global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                              float* __restrict__ part, int N, int H, int W, int K,
-                                                              long npix, int rows_per_wg, const float* __restrict__ act_out, float slope) {
+__global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const DgPtrs dys, const DgPtrs xs, const DgPtrs parts, int N, int H, int W, int K,
+                                                              long npix, int rows_per_wg, const DgPtrs act_outs, float slope) {
+    // grouped launch (dg_conv4x4s2_c3_wgrad_g): blockIdx.z = problem
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.z);
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.z);
+    float* __restrict__ part = dg_pick<float>(parts, blockIdx.z);
+    const float* __restrict__ act_out = dg_pick<const float>(act_outs, blockIdx.z);
     constexpr int ROWE = CWL_WOMAX + 8;                       // elements per LDS array row (zero tail)
     typedef typename std::conditional<X3, float, __bf16>::type ET;           // element type of the staged image rows
     __shared__ __attribute__((aligned(16))) ET img[2][4][12][ROWE];          // [stage][s][c * 4 + r][ox]
@@ -1287,8 +1333,9 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const flo
 }
 
 // fixed-order reduction over slabs: block = 16 outputs x 16 slab lanes
-__global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                              int nslabs, int total, int accumulate) {
+__global__ __launch_bounds__(256) void c3_wgrad_reduce_kernel(const DgPtrs parts, const DgPtrs dws, int nslabs, int total, int accumulate) {
+    const float* __restrict__ part = dg_pick<const float>(parts, blockIdx.y);      // grouped launch: blockIdx.y = problem
+    float* __restrict__ dw = dg_pick<float>(dws, blockIdx.y);
     __shared__ float red[16][17];
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
@@ -1321,32 +1368,77 @@ extern "C" size_t dg_c3_wgrad_workspace_bytes(int N, int H, int W, int K) {
     c3_wgrad_plan(npix, &nb, &ppw);
     return (size_t)nb * K * 48 * sizeof(float);
 }
-static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
-                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, int io_bf16 = 0);
+// groups problems per launch; share > 1: `share` consecutive problems accumulate into the same dw (one main launch over all problems,
+// then one reduction launch per member in problem order, each adding to what the previous one left)
+static int c3_wgrad_run(const char* who, int groups, int share, const float* const* dy_tab, const float* const* ao_tab, int act, float slope,
+                        const float* const* x_tab, float* const* dw_tab, int N, int H, int W, int K, int accumulate, void* const* ws_tab, size_t ws_bytes,
+                        dg_stream_t stream, int io_bf16 = 0);
 extern "C" int dg_conv4x4s2_c3_wgrad_t(const void* dy_nhwc, const void* act_out_nhwc, int io_bf16, int act, float slope,
                                        const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
                                        void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(act == DG_ACT_NONE || ((act == DG_ACT_LEAKY || act == DG_ACT_RELU) && act_out_nhwc),
                  "dg_conv4x4s2_c3_wgrad_t: act %d needs the saved activation output (LeakyReLU / ReLU only)", act);
-    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_t", (const float*)dy_nhwc, act == DG_ACT_NONE ? nullptr : (const float*)act_out_nhwc, act,
-                        act == DG_ACT_RELU ? 0.f : slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream, io_bf16);
+    const float* dyp = (const float*)dy_nhwc;
+    const float* aop = act == DG_ACT_NONE ? nullptr : (const float*)act_out_nhwc;
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_t", 1, 1, &dyp, &aop, act, act == DG_ACT_RELU ? 0.f : slope, &x_nchw, &dw, N, H, W, K, accumulate, &ws,
+                        ws_bytes, stream, io_bf16);
 }
 extern "C" int dg_conv4x4s2_c3_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw, int N, int H, int W, int K,
                                      int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad", dy_nhwc, nullptr, DG_ACT_NONE, 0.f, x_nchw, dw, N, H, W, K, accumulate, ws,
-                        ws_bytes, stream);
+    const float* aop = nullptr;
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad", 1, 1, &dy_nhwc, &aop, DG_ACT_NONE, 0.f, &x_nchw, &dw, N, H, W, K, accumulate, &ws, ws_bytes, stream);
 }
 extern "C" int dg_conv4x4s2_c3_wgrad_act(const float* dy_nhwc, const float* act_out_nhwc, int act, float slope,
                                          const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
                                          void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(act == DG_ACT_NONE || ((act == DG_ACT_LEAKY || act == DG_ACT_RELU) && act_out_nhwc),
                  "dg_conv4x4s2_c3_wgrad_act: act %d needs the saved activation output (LeakyReLU / ReLU only)", act);
-    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_act", dy_nhwc, act == DG_ACT_NONE ? nullptr : act_out_nhwc, act,
-                        act == DG_ACT_RELU ? 0.f : slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream);
+    const float* aop = act == DG_ACT_NONE ? nullptr : act_out_nhwc;
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_act", 1, 1, &dy_nhwc, &aop, act, act == DG_ACT_RELU ? 0.f : slope, &x_nchw, &dw, N, H, W, K, accumulate, &ws,
+                        ws_bytes, stream);
 }
-static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_out, int act, float slope, const float* x_nchw,
-                        float* dw, int N, int H, int W, int K, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, int io_bf16) {
-    DG_CHECK_ARG(dy_nhwc && x_nchw && dw, "%s: null pointer", who);
+extern "C" int dg_conv4x4s2_c3_wgrad_p(const void* dy_nhwc, const void* act_out_nhwc, int io_bf16, int act, float slope,
+                                       const float* x_nchw, float* dw, int N, int H, int W, int K, int prec, int accumulate,
+                                       void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_wgrad_p: prec=%d", prec);
+    DgPrecScope scope(prec);
+    return dg_conv4x4s2_c3_wgrad_t(dy_nhwc, act_out_nhwc, io_bf16, act, slope, x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream);
+}
+extern "C" int dg_conv4x4s2_c3_wgrad_g(int groups, int share, const float* const* dy_nhwc, const float* const* act_out_nhwc, int act, float slope,
+                                       const float* const* x_nchw, float* const* dw, int N, int H, int W, int K, int prec, int accumulate,
+                                       void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && dy_nhwc && x_nchw && dw && ws, "dg_conv4x4s2_c3_wgrad_g: bad group / null table");
+    DG_CHECK_ARG(share >= 1 && groups % share == 0, "dg_conv4x4s2_c3_wgrad_g: share=%d", share);
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_wgrad_g: prec=%d", prec);
+    DG_CHECK_ARG(act == DG_ACT_NONE || ((act == DG_ACT_LEAKY || act == DG_ACT_RELU) && act_out_nhwc),
+                 "dg_conv4x4s2_c3_wgrad_g: act %d needs the saved activation outputs (LeakyReLU / ReLU only)", act);
+    const float* none[DG_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    DgPrecScope scope(prec);
+    return c3_wgrad_run("dg_conv4x4s2_c3_wgrad_g", groups, share, dy_nhwc, act == DG_ACT_NONE ? none : act_out_nhwc, act, act == DG_ACT_RELU ? 0.f : slope,
+                        x_nchw, dw, N, H, W, K, accumulate, ws, ws_bytes, stream);
+}
+static int c3_wgrad_reduce_g(int groups, int share, void* const* ws_tab, float* const* dw_tab, int nb, int total, int accumulate, hipStream_t st) {
+    const int nout = groups / share;
+    for (int j = 0; j < share; ++j) {
+        const void* pp[DG_MAX_GROUPS];
+        const void* dd[DG_MAX_GROUPS];
+        for (int z = 0; z < nout; ++z) { pp[z] = ws_tab[z * share + j]; dd[z] = dw_tab[z * share + j]; }
+        hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16, nout), dim3(256), 0, st, dg_ptrs(pp, nout), dg_ptrs(dd, nout), nb, total,
+                           (accumulate || j > 0) ? 1 : 0);
+        DG_CHECK_LAUNCH("c3_wgrad_reduce");
+    }
+    return DG_OK;
+}
+static int c3_wgrad_run(const char* who, int groups, int share, const float* const* dy_tab, const float* const* ao_tab, int act, float slope,
+                        const float* const* x_tab, float* const* dw_tab, int N, int H, int W, int K, int accumulate, void* const* ws_tab, size_t ws_bytes,
+                        dg_stream_t stream, int io_bf16) {
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(dy_tab[i] && x_tab[i] && dw_tab[i], "%s: null pointer", who);
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(dw_tab[i] == dw_tab[i / share * share], "%s: problems of one share set must name the same dw", who);
+    const float* dy_nhwc = dy_tab[0];
+    const float* x_nchw = x_tab[0];
+    const float* act_out = ao_tab[0];
+    void* ws = ws_tab[0];
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG((ao_tab[i] != nullptr) == (act_out != nullptr), "%s: activation outputs for all problems or none", who);
     DG_CHECK_ARG(N >= 1 && K >= 64 && K % 64 == 0, "%s: K=%d must be a multiple of 64", who, K);
     DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "%s: H,W must be powers of two", who);
     DG_CHECK_ARG((long)N * 3 * H * W < (1L << 31), "%s: tensor too large", who);
@@ -1354,41 +1446,39 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
     int nb, ppw;
     c3_wgrad_plan(npix, &nb, &ppw);
     const size_t need = (size_t)nb * K * 48 * sizeof(float);
-    if (ws == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
+    for (int i = 0; i < groups; ++i)
+        if (ws_tab[i] == nullptr || ws_bytes < need) return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const bool buf = npix * K * 4 < (1L << 30) && (long)N * 3 * H * W * 4 < (1L << 30) && dg_get_option(DG_OPT_POINTER_PATH) == 0;
     const bool fact = act_out != nullptr;
+    const DgPtrs pdy = dg_ptrs((const void* const*)dy_tab, groups), px = dg_ptrs((const void* const*)x_tab, groups),
+                 pws = dg_ptrs((const void* const*)ws_tab, groups), pao = dg_ptrs((const void* const*)ao_tab, groups);
+    const dim3 grid(nb, K / 64, groups);
 #define CW_LAUNCH(B, F)                                                                                                  \
-    hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, \
-                       K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope)
+    hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W, \
+                       K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, pao, slope)
     if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
-    if (!io_bf16 && buf && dg_get_option(DG_OPT_BF16) == 2 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
+    if (!io_bf16 && buf && dg_cur_prec() == 2 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
         // f32x3 path: fp32-accurate plane products on the bf16 MFMA, image rows staged through LDS (fp32)
         const int nrows = N * (H / 2);
         const int rpw = (nrows + nb - 1) / nb;
         if (fact)
-            hipLaunchKernelGGL((c3_wgrad_lds_kernel<true, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                               npix, rpw, act_out, slope);
+            hipLaunchKernelGGL((c3_wgrad_lds_kernel<true, true>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W, K, npix, rpw, pao, slope);
         else
-            hipLaunchKernelGGL((c3_wgrad_lds_kernel<false, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                               npix, rpw, act_out, slope);
+            hipLaunchKernelGGL((c3_wgrad_lds_kernel<false, true>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W, K, npix, rpw, pao, slope);
         DG_CHECK_LAUNCH("c3_wgrad_lds_x3");
-        const int total = K * 48;
-        hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);
-        DG_CHECK_LAUNCH("c3_wgrad_reduce");
-        return DG_OK;
+        return c3_wgrad_reduce_g(groups, share, ws_tab, dw_tab, nb, K * 48, accumulate, st);
     }
-    if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
+    if (io_bf16 && dg_cur_prec() == 1 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
         // bf16 matrix path, image rows staged through LDS: the same nb slabs, a contiguous range of output rows per workgroup
         const int nrows = N * (H / 2);
         const int rpw = (nrows + nb - 1) / nb;
         if (fact)
-            hipLaunchKernelGGL(c3_wgrad_lds_kernel<true>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                               npix, rpw, act_out, slope);
+            hipLaunchKernelGGL(c3_wgrad_lds_kernel<true>, grid, dim3(256), 0, st, pdy, px, pws, N, H, W, K, npix, rpw, pao, slope);
         else
-            hipLaunchKernelGGL(c3_wgrad_lds_kernel<false>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W, K,
-                               npix, rpw, act_out, slope);
-    } else if (io_bf16 && dg_get_option(DG_OPT_BF16) == 1) {        // bf16 matrix path: bf16 MFMA, per-lane gathers
+            hipLaunchKernelGGL(c3_wgrad_lds_kernel<false>, grid, dim3(256), 0, st, pdy, px, pws, N, H, W, K, npix, rpw, pao, slope);
+    } else if (io_bf16 && dg_cur_prec() == 1) {        // bf16 matrix path: bf16 MFMA, per-lane gathers
+        DG_CHECK_ARG(groups == 1, "%s: this kernel takes one problem", who);
         if (fact)
             hipLaunchKernelGGL(c3_wgrad_bf16mfma_kernel<true>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
                                K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
@@ -1396,19 +1486,16 @@ static int c3_wgrad_run(const char* who, const float* dy_nhwc, const float* act_
             hipLaunchKernelGGL(c3_wgrad_bf16mfma_kernel<false>, dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
                                K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
     } else if (io_bf16 && fact) {
-        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, true, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
-                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, true, true>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W,
+                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, pao, slope);
     } else if (io_bf16) {
-        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, false, true>), dim3(nb, K / 64), dim3(256), 0, st, dy_nhwc, x_nchw, (float*)ws, N, H, W,
-                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, act_out, slope);
+        hipLaunchKernelGGL((c3_wgrad_mfma_kernel<true, false, true>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W,
+                           K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, pao, slope);
     } else if (buf && fact) CW_LAUNCH(true, true);
     else if (buf) CW_LAUNCH(true, false);
     else if (fact) CW_LAUNCH(false, true);
     else CW_LAUNCH(false, false);
 #undef CW_LAUNCH
     DG_CHECK_LAUNCH("c3_wgrad_mfma");
-    const int total = K * 48;
-    hipLaunchKernelGGL(c3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, dw, nb, total, accumulate);
-    DG_CHECK_LAUNCH("c3_wgrad_reduce");
-    return DG_OK;
+    return c3_wgrad_reduce_g(groups, share, ws_tab, dw_tab, nb, K * 48, accumulate, st);
 }

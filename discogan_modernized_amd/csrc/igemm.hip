@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    // grouped launch (dg_conv_*_g): blockIdx.z = problem index; the problems share geometry and plan, only the tensors differ
+    const int grp = blockIdx.z;
+    const float* const pA = dg_group_ptr(p.A, p.gdA, grp);
+    const float* const pB = dg_group_ptr(p.B, p.gdB, grp);
+    float* const pC = dg_group_ptr(p.C, p.gdC, grp);
+    float* const pPart = dg_group_ptr(p.part, p.gdPart, grp);
+    float* const pStat = dg_group_ptr(p.stat, p.gdStat, grp);
     long long* const stp = (p.stamps != nullptr && tid == 0) ? p.stamps + (long)blockIdx.x * 8 : nullptr;
     if (stp) {
         stp[0] = wall_clock64();
@@ -177,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     const int it_begin = split * p.itPerSplit;
     const int it_end = min(p.nIt, it_begin + p.itPerSplit);
 
-    const float* __restrict__ Ag = p.A;
-    const float* __restrict__ Bg = p.B;
+    const float* __restrict__ Ag = pA;
+    const float* __restrict__ Bg = pB;
     const int H = p.H, W = p.W, Cc = p.Cc, K = p.K, Ho = p.Ho, Wo = p.Wo;
     const int lgWo = p.lgWo, lgHW = p.lgWo + p.lgHo;
 
@@ -248,13 +255,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int OOR = (int)0x80000000;     // any offset with this bit set is beyond a < 2 GiB tensor
     // p.dbg_zero (timing experiments only, tools/bench_ops.py --dbg_zero): bit 0 / 1 give the A / B descriptor zero records, so
     // every load through it is dropped by the range check while the instruction stream stays (guide, section 7)
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, BUF ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, BUF ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)pA, 0, BUF ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)pB, 0, BUF ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
     // PLN: one descriptor per plane (an offset that runs off the end of a plane must not land in the next one)
-    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (PLN ? p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (PLN ? 2 * p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (PLN ? p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (PLN ? 2 * p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pA + (PLN ? p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pA + (PLN ? 2 * p.a_plane : 0)), 0, PLN ? ((p.dbg_zero & 1) ? 0 : (int)p.abytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pB + (PLN ? p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)pB + (PLN ? 2 * p.b_plane : 0)), 0, PLN ? ((p.dbg_zero & 2) ? 0 : (int)p.bbytes) : 0, 0x00020000);
     int a_ob[NVA], a_inv[NVA], b_ob[NVB];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
@@ -823,11 +830,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     if (stp) stp[3] = clock64();
     // ---- fused BatchNorm statistics: one partial row per (tile, wave row), shifted by the wave tile's
     //      first row so that sum/sumsq never cancel catastrophically; merged by bn_partials_finalize.
-    if ((MODE == MODE_FWD || MODE == MODE_DGRAD_S2) && p.stat != nullptr && p.part == nullptr) {
+    if ((MODE == MODE_FWD || MODE == MODE_DGRAD_S2) && pStat != nullptr && pPart == nullptr) {
         const int row0 = m0 + wm * 64;
         const int nrows = min(64, p.M - row0);
         const int prow = ((MODE == MODE_DGRAD_S2 ? parity : 0) * p.tilesM + tm) * WM + wm;
-        float* srow = p.stat + (long)prow * p.stat_rs;
+        float* srow = pStat + (long)prow * p.stat_rs;
         if (wn == 0 && tn == 0 && lane == 0) srow[0] = (float)max(nrows, 0);
         if (nrows > 0) {
 #pragma unroll
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     // Transposed through the (now idle) LDS, one private [32][68] region per wave, so that every lane stores
     // float4 and 16 lanes cover one 256-B output row segment: 16 store instructions per wave instead of 64
     // dword stores (the epilogue is store-ISSUE bound; stamps: 4.6-22 us -> see DESIGN.md 3.1).
-    const bool to_part = p.part != nullptr;
+    const bool to_part = pPart != nullptr;
     float* const eps = smem + wave * (32 * 68);
     const int erow = lane >> 4, ec4 = (lane & 15) * 4;
     const int ncol = n0 + wn * 64 + ec4;
@@ -884,14 +891,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             if (to_part) {
                 const long srow = (MODE == MODE_DGRAD_S2) ? ((long)split * 4 + parity) * p.M + m
                                                           : (long)split * p.M + m;
-                dst = p.part;
+                dst = pPart;
                 eoff = srow * p.Ng + ncol;
             } else if (MODE == MODE_DGRAD_S2) {
                 const int b = m & (Wo - 1), a = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
-                dst = p.C;
+                dst = pC;
                 eoff = (long)((n * H + 2 * a + ph) * W + 2 * b + pw) * Cc + ncol;
             } else {
-                dst = p.C;
+                dst = pC;
                 eoff = (long)m * p.Ng + ncol;
             }
             if (!to_part && p.accumulate) v += *(const f32x4*)(dst + eoff);
@@ -915,24 +922,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 }
 
 // Sum split-K slabs in a fixed order and scatter to the real output.
+// Grouped launches: blockIdx.z = OUTPUT problem z; with p.share = s > 1 (weight gradients of passes that share the weights) it adds the
+// slab sums of problems z*s .. z*s + s - 1 to problem z*s's output one after the other -- the value `s` accumulating launches leave.
 template <int MODE>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, long total4) {
     const int ng4 = p.Ng >> 2;
     const long slab = (long)(MODE == MODE_DGRAD_S2 ? 4 : 1) * p.M * p.Ng;
+    const int share = p.share > 1 ? p.share : 1;
+    const int g0 = blockIdx.z * share;
+    float* const pC = dg_group_ptr(p.C, p.gdC, g0);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         const long row = idx / ng4;
         const int c4 = (int)(idx - row * ng4);
-        const float* src = p.part + row * p.Ng + c4 * 4;
-        f32x4 s = *(const f32x4*)src;
-        int k = 1;
-        for (; k + 7 < p.splits; k += 8) {      // 8 slab loads in flight, summed in slab order (fixed -> deterministic)
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (k + u) * slab);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
         long eoff;
         if (MODE == MODE_DGRAD_S2) {
             const int parity = (int)(row / p.M);
@@ -942,47 +943,82 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs p, l
         } else {
             eoff = row * p.Ng + c4 * 4;
         }
-        if (p.accumulate) s += *(const f32x4*)(p.C + eoff);
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        bool have = false;
+        if (p.accumulate) { out = *(const f32x4*)(pC + eoff); have = true; }
+        for (int j = 0; j < share; ++j) {
+            const float* src = dg_group_ptr(p.part, p.gdPart, g0 + j) + row * p.Ng + c4 * 4;
+            f32x4 s = *(const f32x4*)src;
+            int k = 1;
+            for (; k + 7 < p.splits; k += 8) {      // 8 slab loads in flight, summed in slab order (fixed -> deterministic)
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (k + u) * slab);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < p.splits; ++k) s += *(const f32x4*)(src + k * slab);
+            if (have) s += out;
+            out = s;
+            have = true;
+        }
+        f32x4 s = out;
         if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
         if (p.act != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
         }
-        dg_store_out4(p.C, eoff, s, p.out16);
+        dg_store_out4(pC, eoff, s, p.out16);
     }
 }
 
 // Small outputs (heads, deep weight gradients): the serial form above would leave a few dozen workgroups walking
 // up to 64 slabs each.  Here a block is 16 float4 outputs x 16 slab lanes; lane j sums slabs j, j+16, ... and the
-// 16 lane sums are added in lane order by one thread (fixed order -> deterministic).
+// 16 lane sums are added in lane order by one thread (fixed order -> deterministic).  blockIdx.z / p.share as above.
 __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const IgemmArgs p, long total4) {
     __shared__ f32x4 red[16][16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const long idx = (long)blockIdx.x * 16 + tx;
     const int ng4 = p.Ng >> 2;
     const long slab = (long)p.M * p.Ng;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int share = p.share > 1 ? p.share : 1;
+    const int g0 = blockIdx.z * share;
+    float* const pC = dg_group_ptr(p.C, p.gdC, g0);
     long row = 0;
     int c4 = 0;
     if (idx < total4) {
         row = idx / ng4;
         c4 = (int)(idx - row * ng4);
-        const float* src = p.part + row * p.Ng + c4 * 4;
-        for (int k = ty; k < p.splits; k += 16) s += *(const f32x4*)(src + k * slab);
     }
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && idx < total4) {
+    const long eoff = row * p.Ng + c4 * 4;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    bool have = false;
+    if (ty == 0 && idx < total4 && p.accumulate) { out = *(const f32x4*)(pC + eoff); have = true; }
+    for (int j = 0; j < share; ++j) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (idx < total4) {
+            const float* src = dg_group_ptr(p.part, p.gdPart, g0 + j) + row * p.Ng + c4 * 4;
+            for (int k = ty; k < p.splits; k += 16) s += *(const f32x4*)(src + k * slab);
+        }
+        if (j > 0) __syncthreads();
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && idx < total4) {
 #pragma unroll
-        for (int j = 1; j < 16; ++j) s += red[j][tx];
-        const long eoff = row * p.Ng + c4 * 4;
-        if (p.accumulate) s += *(const f32x4*)(p.C + eoff);
+            for (int u = 1; u < 16; ++u) s += red[u][tx];
+            if (have) s += out;
+            out = s;
+            have = true;
+        }
+    }
+    if (ty == 0 && idx < total4) {
+        f32x4 s = out;
         if (p.bias != nullptr) s += *(const f32x4*)(p.bias + (c4 * 4) % p.bias_mod);
         if (p.act != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = dg_apply_act(s[e], p.act, p.slope);
         }
-        dg_store_out4(p.C, eoff, s, p.out16);
+        dg_store_out4(pC, eoff, s, p.out16);
     }
 }
 
@@ -992,6 +1028,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArgs p, int rchunks) {
     __shared__ f32x4 red[2][8][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int grp = blockIdx.z;                         // grouped launch: problem index
+    float* const pC = dg_group_ptr(p.C, p.gdC, grp);
+    const float* const pPart = dg_group_ptr(p.part, p.gdPart, grp);
+    float* const pStat = dg_group_ptr(p.stat, p.gdStat, grp);
     const int c = (blockIdx.x * 32 + tx) * 4;
     const long R = (long)(MODE == MODE_DGRAD_S2 ? 4 : 1) * p.M;
     const long slab = R * p.Ng;
@@ -1000,11 +1040,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArg
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
     const bool cok = c < p.Ng;
     if (cok && r0 < r1) {
-        const float* src = p.part + r0 * p.Ng + c;
+        const float* src = pPart + r0 * p.Ng + c;
         sh = *(const f32x4*)src;
         for (int k = 1; k < p.splits; ++k) sh += *(const f32x4*)(src + k * slab);
         for (long row = r0 + ty; row < r1; row += 8) {
-            const float* sp = p.part + row * p.Ng + c;
+            const float* sp = pPart + row * p.Ng + c;
             f32x4 v = *(const f32x4*)sp;
             for (int k = 1; k < p.splits; ++k) v += *(const f32x4*)(sp + k * slab);
             long eoff;
@@ -1016,7 +1056,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArg
             } else {
                 eoff = row * p.Ng + c;
             }
-            dg_store_out4(p.C, eoff, v, p.out16);      // statistics from the fp32 sums, whatever the output is rounded to
+            dg_store_out4(pC, eoff, v, p.out16);      // statistics from the fp32 sums, whatever the output is rounded to
             const f32x4 d = v - sh;
             s += d;
             q += d * d;
@@ -1026,7 +1066,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const IgemmArg
     red[1][ty][tx] = q;
     __syncthreads();
     if (ty == 0) {
-        float* srow = p.stat + (long)blockIdx.y * p.stat_rs;
+        float* srow = pStat + (long)blockIdx.y * p.stat_rs;
         if (blockIdx.x == 0 && tx == 0) srow[0] = (float)max(0L, r1 - r0);
         if (cok && r0 < r1) {
 #pragma unroll
@@ -1047,10 +1087,13 @@ __device__ __forceinline__ f32x4 dg_ld4(const float* p) { return *(const f32x4*)
 __device__ __forceinline__ f32x4 dg_ld4(const __bf16* p) { return __builtin_convertvector(*(const dg_bf16x4*)p, f32x4); }
 __device__ __forceinline__ void dg_st4(float* p, const f32x4& v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void dg_st4(__bf16* p, const f32x4& v) { *(dg_bf16x4*)p = __builtin_convertvector(v, dg_bf16x4); }
+// grouped launches: blockIdx.y = problem (DgPtrs: one tensor per problem)
 template <typename XT>
-__global__ __launch_bounds__(256) void head1_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y, int J) {
+__global__ __launch_bounds__(256) void head1_fwd_kernel(const DgPtrs xs, const DgPtrs ws, const DgPtrs ys, int J) {
     __shared__ float red[4];
+    const XT* __restrict__ x = dg_pick<const XT>(xs, blockIdx.y);
+    const float* __restrict__ w = dg_pick<const float>(ws, blockIdx.y);
+    float* __restrict__ y = dg_pick<float>(ys, blockIdx.y);
     const XT* xr = x + (long)blockIdx.x * J;
     float s = 0.f;
     for (int j = threadIdx.x * 4; j < J; j += 1024) {
@@ -1061,8 +1104,10 @@ __global__ __launch_bounds__(256) void head1_fwd_kernel(const XT* __restrict__ x
     if (threadIdx.x == 0) y[blockIdx.x] = s;
 }
 template <typename XT>
-__global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                          XT* __restrict__ dx, int N, int J) {
+__global__ __launch_bounds__(256) void head1_dgrad_kernel(const DgPtrs dys, const DgPtrs ws, const DgPtrs dxs, int N, int J) {
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.y);
+    const float* __restrict__ w = dg_pick<const float>(ws, blockIdx.y);
+    XT* __restrict__ dx = dg_pick<XT>(dxs, blockIdx.y);
     const long total4 = (long)N * (J >> 2);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         const int n = (int)(idx / (J >> 2));
@@ -1075,9 +1120,11 @@ __global__ __launch_bounds__(256) void head1_dgrad_kernel(const float* __restric
 // 16 float4 lanes along J x 16 batch lanes; each batch lane walks n = lane, lane+16, ... (4 loads in flight),
 // fixed-order tree over the batch lanes through LDS (deterministic).
 template <typename XT>
-__global__ __launch_bounds__(256) void head1_wgrad_kernel(const float* __restrict__ dy, const XT* __restrict__ x,
-                                                          float* __restrict__ dw, int N, int J, int accumulate) {
+__global__ __launch_bounds__(256) void head1_wgrad_kernel(const DgPtrs dys, const DgPtrs xs, const DgPtrs dws, int N, int J, int accumulate) {
     __shared__ f32x4 red[256];
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.y);
+    const XT* __restrict__ x = dg_pick<const XT>(xs, blockIdx.y);
+    float* __restrict__ dw = dg_pick<float>(dws, blockIdx.y);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j4 = blockIdx.x * 16 + tx;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -1196,7 +1243,7 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     pl->wm = 2; pl->wn = 2; pl->kt = (kt_opt == 16 || (kt_opt == 0 && op == 2)) ? 16 : 32;
     // bf16 MFMA operands (option "bf16"): bf16 LDS tiles, K-tile 64 (32 with the 256x64 tile, whose LDS would
     // otherwise allow one workgroup per CU only); needs the buffer-descriptor kernels and whole K-tiles per tap
-    const int popt = dg_get_option(DG_OPT_BF16);      // 0 exact fp32 MFMA, 1 bf16 operands, 2 fp32 as three bf16 planes
+    const int popt = dg_cur_prec();      // this call's arithmetic: 0 exact fp32 MFMA, 1 bf16 operands, 2 fp32 as three bf16 planes
     bool want_bf16 = popt == 1;
     const bool want_x3 = popt == 2;
     if (want_bf16 && op == 0 && g.C % 64 != 0) want_bf16 = false;
@@ -1315,27 +1362,27 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
 
 template <int MODE, int WM, int WN, int KT>
 static void launch_igemm(const IgemmArgs& a, int zmul, hipStream_t st) {
-    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    const dim3 grid(a.tilesM * a.tilesN * zmul * a.splits, 1, a.groups > 1 ? a.groups : 1);     // z: problem of a grouped launch
     if (MODE != MODE_FWD_C3 && a.abytes != 0 && a.bbytes != 0)
-        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, 0>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, MODE != MODE_FWD_C3, 0>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false, 0>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, false, 0>), grid, dim3(256), 0, st, a);
 }
 // bf16 operand tiles (PREC 1) / fp32 as three bf16 planes (PREC 2): buffer-descriptor kernels only
 template <int MODE, int WM, int WN, int KT, int PREC>
 static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
-    const int grid = a.tilesM * a.tilesN * zmul * a.splits;
+    const dim3 grid(a.tilesM * a.tilesN * zmul * a.splits, 1, a.groups > 1 ? a.groups : 1);     // z: problem of a grouped launch
     if constexpr (PREC == 1) {
         // bf16 shadow operands: weights (B of forward / input-grad) alone, or both operands
-        if (a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, true>), dim3(grid), dim3(256), 0, st, a); return; }
-        if (!a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, false, true>), dim3(grid), dim3(256), 0, st, a); return; }
-        if (a.a16 && !a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, false>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, true>), grid, dim3(256), 0, st, a); return; }
+        if (!a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, false, true>), grid, dim3(256), 0, st, a); return; }
+        if (a.a16 && !a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, false>), grid, dim3(256), 0, st, a); return; }
     }
     if constexpr (PREC == 2 && MODE == MODE_FWD && WM == 2 && WN == 2) {
         // both operands as plane triples (a16 = b16 = 3): the loader copies the planes, no split in the kernel
-        if (a.a16 == 3 && a.b16 == 3) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 2, true, true>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (a.a16 == 3 && a.b16 == 3) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 2, true, true>), grid, dim3(256), 0, st, a); return; }
     }
-    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), grid, dim3(256), 0, st, a);
 }
 
 static long long* g_stamp_buf = nullptr;
@@ -1359,6 +1406,9 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         a.part = (float*)ws;
     }
     const int zmul = pl.mode == MODE_DGRAD_S2 ? 4 : 1;
+    const int ngrp = a.groups > 1 ? a.groups : 1;
+    const int nout = ngrp / (a.share > 1 ? a.share : 1);      // outputs of the split-K reduction (share: problems summed into one tensor)
+    if (pl.dma && ngrp > 1) return dg_fail(DG_ERR_INVALID, "%s: the LDS-DMA kernels take no grouped launch", who);
     if (pl.dma) {
         const int ok = pl.dma == 5 ? dg_igemm_x3_fww_launch(a, st)
                      : pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
@@ -1396,7 +1446,7 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     }
     if (a.splits > 1 && a.stat != nullptr) {
         const int rc = pl.stat_rows;
-        dim3 grid((a.Ng + 127) / 128, rc);
+        dim3 grid((a.Ng + 127) / 128, rc, ngrp);
         if (pl.mode == MODE_DGRAD_S2) hipLaunchKernelGGL(splitk_reduce_stats_kernel<MODE_DGRAD_S2>, grid, dim3(256), 0, st, a, rc);
         else hipLaunchKernelGGL(splitk_reduce_stats_kernel<MODE_FWD>, grid, dim3(256), 0, st, a, rc);
         DG_CHECK_LAUNCH("splitk_reduce_stats");
@@ -1405,13 +1455,13 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
         int grid = (int)((total4 + 255) / 256);
         if (grid > 4096) grid = 4096;
         if (pl.mode != MODE_DGRAD_S2 && a.splits >= 8 && total4 <= 65536) {
-            hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, a, total4);
+            hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)((total4 + 15) / 16), 1, nout), dim3(256), 0, st, a, total4);
             DG_CHECK_LAUNCH("splitk_reduce_small");
             return DG_OK;
         }
         switch (pl.mode) {
-            case MODE_DGRAD_S2: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_DGRAD_S2>, dim3(grid), dim3(256), 0, st, a, total4); break;
-            default: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_FWD>, dim3(grid), dim3(256), 0, st, a, total4); break;
+            case MODE_DGRAD_S2: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_DGRAD_S2>, dim3(grid, 1, nout), dim3(256), 0, st, a, total4); break;
+            default: hipLaunchKernelGGL(splitk_reduce_kernel<MODE_FWD>, dim3(grid, 1, nout), dim3(256), 0, st, a, total4); break;
         }
         DG_CHECK_LAUNCH("splitk_reduce");
     }
@@ -1425,80 +1475,162 @@ extern "C" size_t dg_conv_workspace_bytes(int op, int N, int H, int W, int C, in
     Plan pl;
     make_plan(op, g, &pl);
     size_t ws = pl.ws_bytes;
-    if (dg_get_option(DG_OPT_BF16) == 1) {      // the bf16-operand forms (dg_conv_*_mixed) may plan a different tile / split
+    if (dg_cur_prec() == 1) {      // the bf16-operand forms (dg_conv_*_mixed) may plan a different tile / split
         for (int v = 1; v < 4; ++v) {
             make_plan(op, g, &pl, v & 1, v >> 1);
             if (pl.ws_bytes > ws) ws = pl.ws_bytes;
         }
     }
-    if (dg_get_option(DG_OPT_BF16) == 2) {      // the plane-operand forms (dg_conv_*_x3)
+    if (dg_cur_prec() == 2) {      // the plane-operand forms (dg_conv_*_x3)
         make_plan(op, g, &pl, 3, 3);
         if (pl.ws_bytes > ws) ws = pl.ws_bytes;
     }
     return ws;
 }
 
+// ---- the three fp32-tensor ops, grouped form -------------------------------------------------------------------------------
+// `groups` problems of identical geometry go out as ONE launch per kernel of the plan (blockIdx.z = problem); a_in / b_in / out / ws /
+// stat hold one pointer per problem.  share (op 2 only): `share` consecutive problems accumulate into the same dw (out[z*share + j]
+// all equal): one main launch over all problems, the split-K reduction adds their slab sums in problem order.
+static int head1_g(int op, int groups, int share, const void* const* a_in, int a16, const void* const* b_in, int b16, void* const* out, int out16,
+                   int N, int C, int accumulate, hipStream_t st, const char* who) {
+    const int J = 16 * C;
+    if (op == 0) {
+        DG_CHECK_ARG(!b16 && !out16, "%s: K == 1 head: weights and the [N] output are fp32", who);
+        const dim3 grid(N, groups);
+        if (a16) hipLaunchKernelGGL(head1_fwd_kernel<__bf16>, grid, dim3(256), 0, st, dg_ptrs(a_in, groups), dg_ptrs(b_in, groups), dg_ptrs(out, groups), J);
+        else hipLaunchKernelGGL(head1_fwd_kernel<float>, grid, dim3(256), 0, st, dg_ptrs(a_in, groups), dg_ptrs(b_in, groups), dg_ptrs(out, groups), J);
+    } else if (op == 1) {
+        DG_CHECK_ARG(!a16 && !b16, "%s: K == 1 head: dy and the weights are fp32", who);
+        const long total4 = (long)N * 4 * C;
+        int gx = (int)((total4 + 255) / 256);
+        if (gx > 2048) gx = 2048;
+        const dim3 grid(gx, groups);
+        if (out16) hipLaunchKernelGGL(head1_dgrad_kernel<__bf16>, grid, dim3(256), 0, st, dg_ptrs(a_in, groups), dg_ptrs(b_in, groups), dg_ptrs(out, groups), N, J);
+        else hipLaunchKernelGGL(head1_dgrad_kernel<float>, grid, dim3(256), 0, st, dg_ptrs(a_in, groups), dg_ptrs(b_in, groups), dg_ptrs(out, groups), N, J);
+    } else {
+        DG_CHECK_ARG(!a16, "%s: K == 1 head: dy is fp32", who);
+        // share > 1: member j of every output's problems per launch, in order (each launch accumulates into what the previous one left)
+        const int sh = share > 1 ? share : 1, nout = groups / sh;
+        for (int j = 0; j < sh; ++j) {
+            const void *aa[DG_MAX_GROUPS], *bb[DG_MAX_GROUPS], *oo[DG_MAX_GROUPS];
+            for (int z = 0; z < nout; ++z) { aa[z] = a_in[z * sh + j]; bb[z] = b_in[z * sh + j]; oo[z] = out[z * sh + j]; }
+            const dim3 grid((J / 4 + 15) / 16, nout);
+            const int acc = (accumulate || j > 0) ? 1 : 0;
+            if (b16) hipLaunchKernelGGL(head1_wgrad_kernel<__bf16>, grid, dim3(256), 0, st, dg_ptrs(aa, nout), dg_ptrs(bb, nout), dg_ptrs(oo, nout), N, J, acc);
+            else hipLaunchKernelGGL(head1_wgrad_kernel<float>, grid, dim3(256), 0, st, dg_ptrs(aa, nout), dg_ptrs(bb, nout), dg_ptrs(oo, nout), N, J, acc);
+        }
+    }
+    DG_CHECK_LAUNCH(who);
+    return DG_OK;
+}
+
+// fill the group fields of a plan's arguments from per-problem pointer arrays (problem 0's pointers are already set)
+static void set_group_deltas(IgemmArgs& a, int groups, const void* const* A, const void* const* B, void* const* C) {
+    a.groups = groups;
+    for (int g = 1; g < groups; ++g) {
+        a.gdA[g - 1] = (const char*)A[g] - (const char*)A[0];
+        a.gdB[g - 1] = (const char*)B[g] - (const char*)B[0];
+        a.gdC[g - 1] = (const char*)C[g] - (const char*)C[0];
+    }
+}
+
+static int conv_g(int op, int groups, int share, const float* const* a_in, const float* const* b_in, float* const* out, int N, int H, int W, int C,
+                  int K, int stride, int pad, int prec, int accumulate, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes,
+                  hipStream_t st, const char* who) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS, "%s: groups=%d (1..%d)", who, groups, DG_MAX_GROUPS);
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "%s: prec=%d (DG_PREC_F32 | DG_PREC_BF16 | DG_PREC_F32X3)", who, prec);
+    DG_CHECK_ARG(share <= 1 || (op == 2 && groups % share == 0), "%s: share=%d needs the weight gradient and groups %% share == 0", who, share);
+    ConvGeom g;
+    int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
+    if (rc) return rc;
+    DG_CHECK_ARG(a_in && b_in && out, "%s: null pointer table", who);
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(a_in[i] && b_in[i] && out[i], "%s: null pointer (problem %d)", who, i);
+    if (share > 1)
+        for (int i = 0; i < groups; ++i) DG_CHECK_ARG(out[i] == out[i / share * share], "%s: problems of one share set must name the same dw", who);
+    DgPrecScope scope(prec);
+    if (K == 1) {
+        DG_CHECK_ARG(stride == 1, "%s: K==1 only for the 4x4 head", who);
+        return head1_g(op, groups, share, (const void* const*)a_in, 0, (const void* const*)b_in, 0, (void* const*)out, 0, N, C, accumulate, st, who);
+    }
+    if (op == 0) DG_CHECK_ARG(C % 32 == 0, "%s: C=%d must be a multiple of 32", who, C);
+    if (op == 1 && stride == 2) DG_CHECK_ARG(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
+    Plan pl;
+    make_plan(op, g, &pl);
+    IgemmArgs& a = pl.a;
+    if (share > 1 && a.splits <= 1) {
+        // no reduction kernel to merge the shared outputs in: member j of every share set per launch, in order
+        const int nout = groups / share;
+        for (int j = 0; j < share; ++j) {
+            const float *aa[DG_MAX_GROUPS], *bb[DG_MAX_GROUPS];
+            float* oo[DG_MAX_GROUPS];
+            for (int z = 0; z < nout; ++z) { aa[z] = a_in[z * share + j]; bb[z] = b_in[z * share + j]; oo[z] = out[z * share + j]; }
+            rc = conv_g(op, nout, 1, aa, bb, oo, N, H, W, C, K, stride, pad, prec, (accumulate || j > 0) ? 1 : 0, nullptr, 0, ws, ws_bytes, st, who);
+            if (rc) return rc;
+        }
+        return DG_OK;
+    }
+    a.A = a_in[0]; a.B = b_in[0]; a.C = out[0]; a.accumulate = accumulate;
+    set_group_deltas(a, groups, (const void* const*)a_in, (const void* const*)b_in, (void* const*)out);
+    a.share = share > 1 ? share : 1;
+    if (stat != nullptr) {
+        const int ncols = op == 0 ? K : C;
+        DG_CHECK_ARG(op != 2 && pl.stat_rows > 0 && stat_floats >= (size_t)pl.stat_rows * (3 * ncols + 4),
+                     "%s: statistics buffer too small or no fused statistics for this plan (ask dg_conv_bnstats_rows_p)", who);
+        for (int i = 0; i < groups; ++i) DG_CHECK_ARG(stat[i], "%s: null statistics pointer (problem %d)", who, i);
+        a.stat = stat[0];
+        a.stat_rs = 3 * ncols + 4;
+        for (int i = 1; i < groups; ++i) a.gdStat[i - 1] = (const char*)stat[i] - (const char*)stat[0];
+    }
+    void* ws0 = nullptr;
+    if (a.splits > 1) {
+        DG_CHECK_ARG(ws != nullptr, "%s: this plan splits K and needs a workspace per problem", who);
+        for (int i = 0; i < groups; ++i)
+            if (ws[i] == nullptr || ws_bytes < pl.ws_bytes) return dg_fail(DG_ERR_WORKSPACE, "%s: workspace %zu < required %zu (problem %d)", who, ws_bytes, pl.ws_bytes, i);
+        ws0 = ws[0];
+        for (int i = 1; i < groups; ++i) a.gdPart[i - 1] = (const char*)ws[i] - (const char*)ws[0];
+    }
+    return run_plan(who, pl, ws0, ws_bytes, st);
+}
+
+extern "C" int dg_conv_fwd_g(int groups, const float* const* x, const float* const* w, float* const* y, int N, int H, int W, int C, int K, int stride,
+                             int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_g(0, groups, 1, x, w, y, N, H, W, C, K, stride, pad, prec, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd_g");
+}
+extern "C" int dg_conv_dgrad_g(int groups, const float* const* dy, const float* const* w, float* const* dx, int N, int H, int W, int C, int K, int stride,
+                               int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_g(1, groups, 1, dy, w, dx, N, H, W, C, K, stride, pad, prec, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad_g");
+}
+extern "C" int dg_conv_wgrad_g(int groups, int share, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W, int C, int K,
+                               int stride, int pad, int prec, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_g(2, groups, share, dy, x, dw, N, H, W, C, K, stride, pad, prec, accumulate, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad_g");
+}
+// planning queries with the arithmetic as an argument (the forms without it read the process default)
+extern "C" size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
+    DgPrecScope scope(prec);
+    return dg_conv_workspace_bytes(op, N, H, W, C, K, stride, pad);
+}
+extern "C" int dg_conv_bnstats_rows_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
+    DgPrecScope scope(prec);
+    return dg_conv_bnstats_rows(op, N, H, W, C, K, stride, pad);
+}
+extern "C" int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
+    DgPrecScope scope(prec);
+    return dg_conv_plan_splits(op, N, H, W, C, K, stride, pad);
+}
+
+// the one-problem forms without a precision argument: the process default arithmetic (dg_set_option("bf16"))
 extern "C" int dg_conv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
                            int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    ConvGeom g;
-    int rc = check_geom("dg_conv_fwd", N, H, W, C, K, stride, pad, &g);
-    if (rc) return rc;
-    DG_CHECK_ARG(x && w && y, "dg_conv_fwd: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (K == 1) {
-        DG_CHECK_ARG(stride == 1, "dg_conv_fwd: K==1 only for the 4x4 head");
-        hipLaunchKernelGGL(head1_fwd_kernel<float>, dim3(N), dim3(256), 0, st, x, w, y, 16 * C);
-        DG_CHECK_LAUNCH("head1_fwd");
-        return DG_OK;
-    }
-    DG_CHECK_ARG(C % 32 == 0, "dg_conv_fwd: C=%d must be a multiple of 32", C);
-    Plan pl;
-    make_plan(0, g, &pl);
-    pl.a.A = x; pl.a.B = w; pl.a.C = y;
-    return run_plan("dg_conv_fwd", pl, ws, ws_bytes, st);
+    return conv_g(0, 1, 1, &x, &w, &y, N, H, W, C, K, stride, pad, dg_cur_prec(), 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd");
 }
-
 extern "C" int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
                              int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    ConvGeom g;
-    int rc = check_geom("dg_conv_dgrad", N, H, W, C, K, stride, pad, &g);
-    if (rc) return rc;
-    DG_CHECK_ARG(dy && w && dx, "dg_conv_dgrad: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (K == 1) {
-        DG_CHECK_ARG(stride == 1, "dg_conv_dgrad: K==1 only for the 4x4 head");
-        const long total4 = (long)N * 4 * C;
-        int grid = (int)((total4 + 255) / 256);
-        if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(head1_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, dy, w, dx, N, 16 * C);
-        DG_CHECK_LAUNCH("head1_dgrad");
-        return DG_OK;
-    }
-    if (stride == 2) DG_CHECK_ARG(K % 32 == 0, "dg_conv_dgrad: K=%d must be a multiple of 32", K);
-    Plan pl;
-    make_plan(1, g, &pl);
-    pl.a.A = dy; pl.a.B = w; pl.a.C = dx;
-    return run_plan("dg_conv_dgrad", pl, ws, ws_bytes, st);
+    return conv_g(1, 1, 1, &dy, &w, &dx, N, H, W, C, K, stride, pad, dg_cur_prec(), 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad");
 }
-
 extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
                              int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    ConvGeom g;
-    int rc = check_geom("dg_conv_wgrad", N, H, W, C, K, stride, pad, &g);
-    if (rc) return rc;
-    DG_CHECK_ARG(dy && x && dw, "dg_conv_wgrad: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (K == 1) {
-        DG_CHECK_ARG(stride == 1, "dg_conv_wgrad: K==1 only for the 4x4 head");
-        const int J = 16 * C;
-        hipLaunchKernelGGL(head1_wgrad_kernel<float>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, dy, x, dw, N, J, accumulate);
-        DG_CHECK_LAUNCH("head1_wgrad");
-        return DG_OK;
-    }
-    Plan pl;
-    make_plan(2, g, &pl);
-    pl.a.A = dy; pl.a.B = x; pl.a.C = dw; pl.a.accumulate = accumulate;
-    return run_plan("dg_conv_wgrad", pl, ws, ws_bytes, st);
+    return conv_g(2, 1, 1, &dy, &x, &dw, N, H, W, C, K, stride, pad, dg_cur_prec(), accumulate, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad");
 }
 
 // ---- bf16 shadow operands (option "bf16" = 1 only) -------------------------------------------------------------------
@@ -1517,27 +1649,11 @@ static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b
         // the discriminator's 4x4 head (plain reductions): only the ACTIVATION side may be bf16 (x of forward / weight-grad, dx of
         // input-grad); the [N] vector and the weights are fp32
         DG_CHECK_ARG(stride == 1, "%s: K==1 only for the 4x4 head", who);
-        const int J = 16 * C;
-        if (op == 0) {
-            DG_CHECK_ARG(!b16 && !out16, "%s: K == 1 head: weights and the [N] output are fp32", who);
-            if (a16) hipLaunchKernelGGL(head1_fwd_kernel<__bf16>, dim3(N), dim3(256), 0, st, (const __bf16*)a_in, (const float*)b_in, (float*)out, J);
-            else hipLaunchKernelGGL(head1_fwd_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, J);
-        } else if (op == 1) {
-            DG_CHECK_ARG(!a16 && !b16, "%s: K == 1 head: dy and the weights are fp32", who);
-            const long total4 = (long)N * 4 * C;
-            int grid = (int)((total4 + 255) / 256);
-            if (grid > 2048) grid = 2048;
-            if (out16) hipLaunchKernelGGL(head1_dgrad_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (__bf16*)out, N, J);
-            else hipLaunchKernelGGL(head1_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, N, J);
-        } else {
-            DG_CHECK_ARG(!a16, "%s: K == 1 head: dy is fp32", who);
-            if (b16) hipLaunchKernelGGL(head1_wgrad_kernel<__bf16>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, (const float*)a_in, (const __bf16*)b_in, (float*)out, N, J, accumulate);
-            else hipLaunchKernelGGL(head1_wgrad_kernel<float>, dim3((J / 4 + 15) / 16), dim3(256), 0, st, (const float*)a_in, (const float*)b_in, (float*)out, N, J, accumulate);
-        }
-        DG_CHECK_LAUNCH(who);
-        return DG_OK;
+        return head1_g(op, 1, 1, &a_in, a16, &b_in, b16, &out, out16, N, C, accumulate, st, who);
     }
-    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 1 || (!a16 && !b16 && !out16), "%s: bf16 operands / outputs need option bf16 = 1", who);
+    // bf16 operands / outputs imply the bf16 matrix path for this call (no process-wide switch involved); an all-fp32 call keeps the
+    // caller's arithmetic
+    DgPrecScope scope((a16 || b16 || out16) ? DG_PREC_BF16 : dg_cur_prec());
     DG_CHECK_ARG(!(out16 && op == 2), "%s: the weight gradient is always fp32", who);
     if (op == 0) DG_CHECK_ARG(C % 32 == 0, "%s: C=%d must be a multiple of 32", who, C);
     if (op == 1 && stride == 2) DG_CHECK_ARG(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
@@ -1560,6 +1676,7 @@ static int conv_mixed(int op, const void* a_in, int a16, const void* b_in, int b
 extern "C" int dg_conv_mixed_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad, int a_bf16, int b_bf16) {
     ConvGeom g;
     if ((op != 0 && op != 1) || check_geom("dg_conv_mixed_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1 || stride != 2) return 0;
+    DgPrecScope scope(DG_PREC_BF16);
     Plan pl;
     make_plan(op, g, &pl, a_bf16, b_bf16);
     return pl.stat_rows;
@@ -1581,7 +1698,7 @@ extern "C" int dg_conv_wgrad_mixed(const void* dy, int dy_bf16, const void* x, i
 extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_bf16_operands_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
-    if (dg_get_option(DG_OPT_BF16) != 1) return 0;
+    DgPrecScope scope(DG_PREC_BF16);
     Plan pl;
     make_plan(op, g, &pl, 1, 1);
     return pl.a.prec == 1 ? (pl.dma ? 2 : 1) : 0;
@@ -1605,7 +1722,7 @@ static int conv_x3(int op, const void* a3, long a_plane, const void* b3, long b_
     int rc = check_geom(who, N, H, W, C, K, stride, pad, &g);
     if (rc) return rc;
     DG_CHECK_ARG(a3 && b3 && out, "%s: null pointer", who);
-    DG_CHECK_ARG(dg_get_option(DG_OPT_BF16) == 2, "%s: plane operands need option bf16 = 2", who);
+    DgPrecScope scope(DG_PREC_F32X3);       // plane operands ARE the f32x3 arithmetic: no process-wide switch involved
     DG_CHECK_ARG(K > 1, "%s: the K == 1 head has no plane form", who);
     Plan pl;
     // forward with plain (not transposed) weight planes where the window forward kernel would apply: the register-staged tiles read
@@ -1648,7 +1765,7 @@ extern "C" int dg_conv_dgrad_x3(const void* dy3, long dy_plane, int dy_layout, c
 extern "C" int dg_conv_x3_bnstats_rows(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (op == 2 || check_geom("dg_conv_x3_bnstats_rows", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
-    if (dg_get_option(DG_OPT_BF16) != 2) return 0;
+    DgPrecScope scope(DG_PREC_F32X3);
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
     return (pl.dma == 2 || pl.dma == 3) ? pl.stat_rows : 0;
@@ -1664,7 +1781,7 @@ extern "C" int dg_conv_wgrad_x3(const void* dy3, long dy_plane, int dy_layout, c
 extern "C" int dg_conv_x3_planes_ok(int op, int N, int H, int W, int C, int K, int stride, int pad) {
     ConvGeom g;
     if (check_geom("dg_conv_x3_planes_ok", N, H, W, C, K, stride, pad, &g) != DG_OK || K == 1) return 0;
-    if (dg_get_option(DG_OPT_BF16) != 2) return 0;
+    DgPrecScope scope(DG_PREC_F32X3);
     Plan pl;
     make_plan(op, g, &pl, 3, 3);
     if (pl.dma == 0 && x3_register_staged_planes_ok(op, g, pl)) return 4;
@@ -1796,15 +1913,40 @@ extern "C" int dg_convT4x4_1to4_wgrad(const float* dy, const float* x, float* dw
 
 extern "C" int dg_c3_fwd_mfma_launch(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int act,
                                      float slope, hipStream_t st);   // edge.hip
+extern "C" int dg_c3_fwd_mfma_launch_g(int groups, const float* const* x_tab, const float* const* w_tab, void* const* y_tab, int y_bf16, int N, int H, int W,
+                                       int act, float slope, hipStream_t st);   // edge.hip
 static int c3_fwd_run(const float* x_nchw, const float* w, float* y_nhwc, int y_bf16, int N, int H, int W, int K,
                       int act, float slope, dg_stream_t stream);
 // ---- 3-channel image side, forward direction (conv1 forward / last-convT input-grad) ----------------
+// grouped form: the K == 64 streaming kernels only (the network's first conv / last transposed conv), arithmetic as an argument
+extern "C" int dg_conv4x4s2_c3_fwd_g(int groups, const float* const* x_nchw, const float* const* w, float* const* y_nhwc, int N, int H, int W, int K,
+                                     int act, float slope, int prec, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && x_nchw && w && y_nhwc, "dg_conv4x4s2_c3_fwd_g: bad group / null table");
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(x_nchw[i] && w[i] && y_nhwc[i], "dg_conv4x4s2_c3_fwd_g: null pointer");
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_fwd_g: prec=%d", prec);
+    DG_CHECK_ARG(N >= 1 && K == 64, "dg_conv4x4s2_c3_fwd_g: the grouped form is the K == 64 streaming kernel (K=%d)", K);
+    DG_CHECK_ARG(dg_is_pow2(H) && dg_is_pow2(W) && H >= 2 && W >= 2, "dg_conv4x4s2_c3_fwd_g: H,W must be powers of two");
+    DG_CHECK_ARG((long)N * 3 * H * W * 4 < (1L << 30) && (long)N * (H / 2) * (W / 2) < (1L << 30) && dg_get_option(DG_OPT_KT) != 16,
+                 "dg_conv4x4s2_c3_fwd_g: tensors must be below 1 GiB");
+    DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_conv4x4s2_c3_fwd_g: bad act %d", act);
+    DgPrecScope scope(prec);
+    int rc = dg_c3_fwd_mfma_launch_g(groups, x_nchw, w, (void* const*)y_nhwc, 0, N, H, W, act, slope, (hipStream_t)stream);
+    if (rc != DG_OK) return rc;
+    DG_CHECK_LAUNCH("dg_conv4x4s2_c3_fwd_g");
+    return DG_OK;
+}
 extern "C" int dg_conv4x4s2_c3_fwd(const float* x_nchw, const float* w, float* y_nhwc, int N, int H, int W, int K,
                                    int act, float slope, dg_stream_t stream) {
     return c3_fwd_run(x_nchw, w, y_nhwc, 0, N, H, W, K, act, slope, stream);
 }
 extern "C" int dg_conv4x4s2_c3_fwd_t(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int K,
                                      int act, float slope, dg_stream_t stream) {
+    return c3_fwd_run(x_nchw, w, (float*)y_nhwc, y_bf16, N, H, W, K, act, slope, stream);
+}
+extern "C" int dg_conv4x4s2_c3_fwd_p(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                                     int act, float slope, int prec, dg_stream_t stream) {
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_fwd_p: prec=%d", prec);
+    DgPrecScope scope(prec);
     return c3_fwd_run(x_nchw, w, (float*)y_nhwc, y_bf16, N, H, W, K, act, slope, stream);
 }
 static int c3_fwd_run(const float* x_nchw, const float* w, float* y_nhwc, int y_bf16, int N, int H, int W, int K,

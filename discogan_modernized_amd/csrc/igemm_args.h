@@ -39,7 +39,22 @@ struct IgemmArgs {
     unsigned abytes, bbytes;   // operand sizes for the buffer descriptors (BUF kernels: both < 2 GiB)
     int prec;                  // 1: bf16 MFMA operands (option "bf16"; BUF kernels only)
     int xcd_group;             // workgroups sharing operand-A rows are placed on one XCD (needs tilesM * splits % 8 == 0)
+    // Grouped launch (round 4; dg_conv_*_g): `groups` problems of IDENTICAL geometry and plan go out as one launch, blockIdx.z =
+    // problem index g.  A / B / C / part / stat above are problem 0's tensors; gd*[g - 1] is the BYTE distance of problem g's tensor
+    // from problem 0's (any two allocations have one).  The reference issues such problems as independent passes
+    // (image_translation.py:342-361: G_B(A) | G_A(B), G_A(AB) | G_B(BA), D_A(A) | D_A(BA) | D_B(B) | D_B(AB)).
+    // share (weight gradient, split-K reduction kernels only): `share` consecutive problems ACCUMULATE into the same output tensor
+    // (a discriminator's real and fake pass, image_translation.py:353-361): the reduction kernel of output problem z adds the slab
+    // sums of problems z * share .. z * share + share - 1 one after the other, in that order -- bitwise what `share` launches do.
+    int groups, share;
+    long gdA[DG_MAX_GROUPS - 1], gdB[DG_MAX_GROUPS - 1], gdC[DG_MAX_GROUPS - 1], gdPart[DG_MAX_GROUPS - 1], gdStat[DG_MAX_GROUPS - 1];
 };
+
+// problem g's pointer (g = blockIdx.z; wave-uniform: scalar loads and adds)
+template <typename T>
+__device__ __forceinline__ T* dg_group_ptr(T* base, const long* gd, int g) {
+    return g == 0 ? base : (T*)((const char*)base + gd[g - 1]);
+}
 
 
 typedef __bf16 dg_bf16x4 __attribute__((ext_vector_type(4)));

@@ -10,8 +10,10 @@
 
 extern "C" size_t dg_loss_workspace_bytes(void) { return LOSS_MAX_BLOCKS * sizeof(double); }
 
-__global__ __launch_bounds__(256) void final_sum_kernel(const double* __restrict__ part, int nparts, double scale,
-                                                        float* __restrict__ out) {
+// grouped launches (dg_*_g; round 4): blockIdx.y (blockIdx.x in the one-block kernels) = problem, one tensor per problem (DgPtrs)
+__global__ __launch_bounds__(256) void final_sum_kernel(const DgPtrs parts, int nparts, double scale, const DgPtrs outs) {
+    const double* __restrict__ part = dg_pick<const double>(parts, blockIdx.x);
+    float* __restrict__ out = dg_pick<float>(outs, blockIdx.x);
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -29,8 +31,10 @@ __device__ __forceinline__ void block_partial_store(float v, double* part) {
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ x, const float* __restrict__ t, long n,
-                                                          double* __restrict__ part) {
+__global__ __launch_bounds__(256) void mse_partial_kernel(const DgPtrs xs, const DgPtrs ts, long n, const DgPtrs parts) {
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
+    const float* __restrict__ t = dg_pick<const float>(ts, blockIdx.y);
+    double* __restrict__ part = dg_pick<double>(parts, blockIdx.y);
     float s = 0.f;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -42,8 +46,11 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
         for (long e = n4 * 4; e < n; ++e) s += (x[e] - t[e]) * (x[e] - t[e]);
     block_partial_store(s, part);
 }
-__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, long n,
-                                                      const float* __restrict__ gout, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const DgPtrs xs, const DgPtrs ts, long n, const DgPtrs gouts, const DgPtrs dxs) {
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
+    const float* __restrict__ t = dg_pick<const float>(ts, blockIdx.y);
+    const float* __restrict__ gout = dg_pick<const float>(gouts, blockIdx.y);
+    float* __restrict__ dx = dg_pick<float>(dxs, blockIdx.y);
     const float sc = 2.f * gout[0] / (float)n;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -54,7 +61,13 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ 
         for (long e = n4 * 4; e < n; ++e) dx[e] = (x[e] - t[e]) * sc;
 }
 
-__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, int n, float label, float* __restrict__ loss) {
+struct DgLabels {
+    float v[DG_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const DgPtrs ps, int n, const DgLabels labels, const DgPtrs losses) {
+    const float* __restrict__ p = dg_pick<const float>(ps, blockIdx.x);
+    float* __restrict__ loss = dg_pick<float>(losses, blockIdx.x);
+    const float label = labels.v[blockIdx.x];
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -67,8 +80,11 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / n);
 }
-__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ p, int n, float label,
-                                                      const float* __restrict__ gout, float* __restrict__ dp) {
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const DgPtrs ps, int n, const DgLabels labels, const DgPtrs gouts, const DgPtrs dps) {
+    const float* __restrict__ p = dg_pick<const float>(ps, blockIdx.y);
+    const float* __restrict__ gout = dg_pick<const float>(gouts, blockIdx.y);
+    float* __restrict__ dp = dg_pick<float>(dps, blockIdx.y);
+    const float label = labels.v[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float v = p[i];
@@ -129,8 +145,10 @@ __device__ __forceinline__ f32x4 fm_ld4(const __bf16* p) { return __builtin_conv
 __device__ __forceinline__ void fm_st4(float* p, const f32x4& v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void fm_st4(__bf16* p, const f32x4& v) { *(fm_bf16x4*)p = __builtin_convertvector(v, fm_bf16x4); }
 template <typename T>
-__global__ __launch_bounds__(256) void fm_partial_kernel(const T* __restrict__ real, const T* __restrict__ fake, int N,
-                                                         long J, int nchunks, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void fm_partial_kernel(const DgPtrs reals, const DgPtrs fakes, int N, long J, int nchunks, const DgPtrs parts) {
+    const T* __restrict__ real = dg_pick<const T>(reals, blockIdx.z);
+    const T* __restrict__ fake = dg_pick<const T>(fakes, blockIdx.z);
+    float* __restrict__ part = dg_pick<float>(parts, blockIdx.z);
     const long j4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (j4 * 4 >= J) return;
     const int per = (N + nchunks - 1) / nchunks;
@@ -144,8 +162,10 @@ __global__ __launch_bounds__(256) void fm_partial_kernel(const T* __restrict__ r
     *(f32x4*)(part + ((long)nchunks + blockIdx.y) * J + j4 * 4) = sf;
 }
 // stage 2: diff[j] = mean_n real - mean_n fake (fixed chunk order), block partials of diff^2
-__global__ __launch_bounds__(256) void fm_diff_kernel(const float* __restrict__ part, int N, long J, int nchunks,
-                                                      float* __restrict__ diff, double* __restrict__ dpart) {
+__global__ __launch_bounds__(256) void fm_diff_kernel(const DgPtrs parts, int N, long J, int nchunks, const DgPtrs diffs, const DgPtrs dparts) {
+    const float* __restrict__ part = dg_pick<const float>(parts, blockIdx.y);
+    float* __restrict__ diff = dg_pick<float>(diffs, blockIdx.y);
+    double* __restrict__ dpart = dg_pick<double>(dparts, blockIdx.y);
     float s = 0.f;
     const long j4n = J >> 2;
     const float inv = 1.f / (float)N;
@@ -162,8 +182,11 @@ __global__ __launch_bounds__(256) void fm_diff_kernel(const float* __restrict__ 
     block_partial_store(s, dpart);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ diff, int N, long J, const float* __restrict__ gout,
-                                                     T* __restrict__ dreal, T* __restrict__ dfake) {
+__global__ __launch_bounds__(256) void fm_bwd_kernel(const DgPtrs diffs, int N, long J, const DgPtrs gouts, const DgPtrs dreals, const DgPtrs dfakes) {
+    const float* __restrict__ diff = dg_pick<const float>(diffs, blockIdx.y);
+    const float* __restrict__ gout = dg_pick<const float>(gouts, blockIdx.y);
+    T* __restrict__ dreal = dg_pick<T>(dreals, blockIdx.y);
+    T* __restrict__ dfake = dg_pick<T>(dfakes, blockIdx.y);
     // d loss / d real[n][j] = 2*diff[j] / (N*J);  d/d fake = -that
     const float sc = 2.f * gout[0] / ((float)N * (float)J);
     const long j4n = J >> 2;
@@ -238,35 +261,79 @@ static int loss_grid(long work) {
     return (int)g;
 }
 
+#define DG_GROUP_TABLES_OK(who, ...)                                                                                     \
+    do {                                                                                                                \
+        DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS, who ": groups=%d (1..%d)", groups, DG_MAX_GROUPS);            \
+        const void* const* tabs__[] = {__VA_ARGS__};                                                                    \
+        for (size_t t__ = 0; t__ < sizeof(tabs__) / sizeof(tabs__[0]); ++t__) {                                         \
+            DG_CHECK_ARG(tabs__[t__] != nullptr, who ": null pointer table");                                           \
+            for (int i__ = 0; i__ < groups; ++i__) DG_CHECK_ARG(tabs__[t__][i__] != nullptr, who ": null pointer (problem %d)", i__); \
+        }                                                                                                               \
+    } while (0)
+#define DG_TAB(x) ((const void* const*)(x))
+
+extern "C" int dg_mse_fwd_g(int groups, const float* const* x, const float* const* t, size_t n, float* const* loss, void* const* ws, size_t ws_bytes,
+                            dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_mse_fwd", DG_TAB(x), DG_TAB(t), DG_TAB(loss), DG_TAB(ws));
+    DG_CHECK_ARG(n > 0, "dg_mse_fwd: bad argument");
+    if (ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_mse_fwd: workspace too small");
+    const int g = loss_grid((long)(n / 4) + 1);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(g, groups), dim3(256), 0, st, dg_ptrs(DG_TAB(x), groups), dg_ptrs(DG_TAB(t), groups), (long)n,
+                       dg_ptrs(DG_TAB(ws), groups));
+    DG_CHECK_LAUNCH("mse_partial");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(groups), dim3(256), 0, st, dg_ptrs(DG_TAB(ws), groups), g, 1.0 / (double)n, dg_ptrs(DG_TAB(loss), groups));
+    DG_CHECK_LAUNCH("mse_final");
+    return DG_OK;
+}
 extern "C" int dg_mse_fwd(const float* x, const float* t, size_t n, float* loss, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(x && t && loss && n > 0, "dg_mse_fwd: bad argument");
     if (!ws || ws_bytes < dg_loss_workspace_bytes()) return dg_fail(DG_ERR_WORKSPACE, "dg_mse_fwd: workspace too small");
-    const int g = loss_grid((long)(n / 4) + 1);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mse_partial_kernel, dim3(g), dim3(256), 0, st, x, t, (long)n, (double*)ws);
-    DG_CHECK_LAUNCH("mse_partial");
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)n, loss);
-    DG_CHECK_LAUNCH("mse_final");
+    return dg_mse_fwd_g(1, &x, &t, n, &loss, &ws, ws_bytes, stream);
+}
+extern "C" int dg_mse_bwd_g(int groups, const float* const* x, const float* const* t, size_t n, const float* const* gout, float* const* dx,
+                            dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_mse_bwd", DG_TAB(x), DG_TAB(t), DG_TAB(gout), DG_TAB(dx));
+    DG_CHECK_ARG(n > 0, "dg_mse_bwd: bad argument");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(loss_grid((long)(n / 4) + 1) * 2, groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs(DG_TAB(x), groups),
+                       dg_ptrs(DG_TAB(t), groups), (long)n, dg_ptrs(DG_TAB(gout), groups), dg_ptrs(DG_TAB(dx), groups));
+    DG_CHECK_LAUNCH("mse_bwd");
     return DG_OK;
 }
 extern "C" int dg_mse_bwd(const float* x, const float* t, size_t n, const float* gout, float* dx, dg_stream_t stream) {
     DG_CHECK_ARG(x && t && gout && dx && n > 0, "dg_mse_bwd: bad argument");
-    hipLaunchKernelGGL(mse_bwd_kernel, dim3(loss_grid((long)(n / 4) + 1) * 2), dim3(256), 0, (hipStream_t)stream, x, t, (long)n, gout, dx);
-    DG_CHECK_LAUNCH("mse_bwd");
+    return dg_mse_bwd_g(1, &x, &t, n, &gout, &dx, stream);
+}
+static DgLabels bce_labels(int groups, const float* label) {
+    DgLabels l;
+    for (int i = 0; i < DG_MAX_GROUPS; ++i) l.v[i] = i < groups ? label[i] : 0.f;
+    return l;
+}
+extern "C" int dg_bce_fwd_g(int groups, const float* const* p, int n, const float* label, float* const* loss, dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_bce_fwd", DG_TAB(p), DG_TAB(loss));
+    DG_CHECK_ARG(label && n > 0, "dg_bce_fwd: bad argument");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs(DG_TAB(p), groups), n, bce_labels(groups, label),
+                       dg_ptrs(DG_TAB(loss), groups));
+    DG_CHECK_LAUNCH("bce_fwd");
     return DG_OK;
 }
 extern "C" int dg_bce_fwd(const float* p, int n, float label, float* loss, void* ws, size_t ws_bytes, dg_stream_t stream) {
     (void)ws; (void)ws_bytes;
     DG_CHECK_ARG(p && loss && n > 0, "dg_bce_fwd: bad argument");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, label, loss);
-    DG_CHECK_LAUNCH("bce_fwd");
+    return dg_bce_fwd_g(1, &p, n, &label, &loss, stream);
+}
+extern "C" int dg_bce_bwd_g(int groups, const float* const* p, int n, const float* label, const float* const* gout, float* const* dp,
+                            dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_bce_bwd", DG_TAB(p), DG_TAB(gout), DG_TAB(dp));
+    DG_CHECK_ARG(label && n > 0, "dg_bce_bwd: bad argument");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256, groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs(DG_TAB(p), groups), n,
+                       bce_labels(groups, label), dg_ptrs(DG_TAB(gout), groups), dg_ptrs(DG_TAB(dp), groups));
+    DG_CHECK_LAUNCH("bce_bwd");
     return DG_OK;
 }
 extern "C" int dg_bce_bwd(const float* p, int n, float label, const float* gout, float* dp, dg_stream_t stream) {
     DG_CHECK_ARG(p && gout && dp && n > 0, "dg_bce_bwd: bad argument");
-    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, n, label, gout, dp);
-    DG_CHECK_LAUNCH("bce_bwd");
-    return DG_OK;
+    return dg_bce_bwd_g(1, &p, n, &label, &gout, &dp, stream);
 }
 extern "C" int dg_bce_target_fwd(const float* p, const float* target, int n, float* loss, dg_stream_t stream) {
     DG_CHECK_ARG(p && target && loss && n > 0, "dg_bce_target_fwd: bad argument");
@@ -288,7 +355,7 @@ extern "C" int dg_hinge_fwd(const float* x, const float* y, size_t n, float marg
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hinge_partial_kernel, dim3(g), dim3(256), 0, st, x, y, (long)n, margin, (double*)ws);
     DG_CHECK_LAUNCH("hinge_partial");
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, g, 1.0 / (double)n, loss);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, dg_ptrs1(ws), g, 1.0 / (double)n, dg_ptrs1(loss));
     DG_CHECK_LAUNCH("hinge_final");
     return DG_OK;
 }
@@ -310,48 +377,70 @@ static int fm_chunks(int N, size_t J) {
 extern "C" size_t dg_fm_workspace_bytes(int N, size_t J) {
     return dg_loss_workspace_bytes() + (size_t)2 * fm_chunks(N, J) * J * sizeof(float);
 }
-extern "C" int dg_fm_fwd_t(const void* real, const void* fake, int io_bf16, int N, size_t J, float* diff, float* loss, void* ws,
-                           size_t ws_bytes, dg_stream_t stream);
-extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss, void* ws,
-                         size_t ws_bytes, dg_stream_t stream) {
-    return dg_fm_fwd_t(real, fake, 0, N, J, diff, loss, ws, ws_bytes, stream);
+static int fm_fwd_run(int groups, const void* const* real, const void* const* fake, int io_bf16, int N, size_t J, float* const* diff,
+                      float* const* loss, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_fm_fwd", real, fake, DG_TAB(diff), DG_TAB(loss), DG_TAB(ws));
+    DG_CHECK_ARG(N > 0 && J > 0 && J % 4 == 0, "dg_fm_fwd: bad argument");
+    if (ws_bytes < dg_fm_workspace_bytes(N, J)) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
+    const int nch = fm_chunks(N, J);
+    const void* parts[DG_MAX_GROUPS];
+    for (int i = 0; i < groups; ++i) parts[i] = (const char*)ws[i] + dg_loss_workspace_bytes();
+    const DgPtrs pparts = dg_ptrs(parts, groups), pdpart = dg_ptrs(DG_TAB(ws), groups);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid1((unsigned)((J / 4 + 255) / 256), nch, groups);
+    if (io_bf16)
+        hipLaunchKernelGGL(fm_partial_kernel<__bf16>, grid1, dim3(256), 0, st, dg_ptrs(real, groups), dg_ptrs(fake, groups), N, (long)J, nch, pparts);
+    else
+        hipLaunchKernelGGL(fm_partial_kernel<float>, grid1, dim3(256), 0, st, dg_ptrs(real, groups), dg_ptrs(fake, groups), N, (long)J, nch, pparts);
+    DG_CHECK_LAUNCH("fm_partial");
+    const int g = loss_grid((long)(J / 4));
+    hipLaunchKernelGGL(fm_diff_kernel, dim3(g, groups), dim3(256), 0, st, pparts, N, (long)J, nch, dg_ptrs(DG_TAB(diff), groups), pdpart);
+    DG_CHECK_LAUNCH("fm_diff");
+    hipLaunchKernelGGL(final_sum_kernel, dim3(groups), dim3(256), 0, st, pdpart, g, 1.0 / (double)J, dg_ptrs(DG_TAB(loss), groups));
+    DG_CHECK_LAUNCH("fm_final");
+    return DG_OK;
 }
 extern "C" int dg_fm_fwd_t(const void* real, const void* fake, int io_bf16, int N, size_t J, float* diff, float* loss, void* ws,
                            size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(real && fake && diff && loss && N > 0 && J > 0 && J % 4 == 0, "dg_fm_fwd: bad argument");
     if (!ws || ws_bytes < dg_fm_workspace_bytes(N, J)) return dg_fail(DG_ERR_WORKSPACE, "dg_fm_fwd: workspace too small");
-    const int nch = fm_chunks(N, J);
-    double* dpart = (double*)ws;
-    float* part = (float*)((char*)ws + dg_loss_workspace_bytes());
-    hipStream_t st = (hipStream_t)stream;
+    return fm_fwd_run(1, &real, &fake, io_bf16, N, J, &diff, &loss, &ws, ws_bytes, stream);
+}
+extern "C" int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss, void* ws,
+                         size_t ws_bytes, dg_stream_t stream) {
+    return dg_fm_fwd_t(real, fake, 0, N, J, diff, loss, ws, ws_bytes, stream);
+}
+extern "C" int dg_fm_fwd_g(int groups, const float* const* real, const float* const* fake, int N, size_t J, float* const* diff, float* const* loss,
+                           void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    return fm_fwd_run(groups, DG_TAB(real), DG_TAB(fake), 0, N, J, diff, loss, ws, ws_bytes, stream);
+}
+static int fm_bwd_run(int groups, const float* const* diff, int N, size_t J, const float* const* gout, void* const* dreal, void* const* dfake,
+                      int io_bf16, dg_stream_t stream) {
+    DG_GROUP_TABLES_OK("dg_fm_bwd", DG_TAB(diff), DG_TAB(gout));
+    DG_CHECK_ARG(N > 0 && J > 0 && J % 4 == 0, "dg_fm_bwd: bad argument");
+    const long total = (long)(J / 4) * N;
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    const dim3 grid((unsigned)g, groups);
+    const DgPtrs pr = dg_ptrs(DG_TAB(dreal), groups), pf = dg_ptrs(DG_TAB(dfake), groups);
     if (io_bf16)
-        hipLaunchKernelGGL(fm_partial_kernel<__bf16>, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, (const __bf16*)real,
-                           (const __bf16*)fake, N, (long)J, nch, part);
+        hipLaunchKernelGGL(fm_bwd_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, dg_ptrs(DG_TAB(diff), groups), N, (long)J, dg_ptrs(DG_TAB(gout), groups), pr, pf);
     else
-        hipLaunchKernelGGL(fm_partial_kernel<float>, dim3((unsigned)((J / 4 + 255) / 256), nch), dim3(256), 0, st, (const float*)real,
-                           (const float*)fake, N, (long)J, nch, part);
-    DG_CHECK_LAUNCH("fm_partial");
-    const int g = loss_grid((long)(J / 4));
-    hipLaunchKernelGGL(fm_diff_kernel, dim3(g), dim3(256), 0, st, (const float*)part, N, (long)J, nch, diff, dpart);
-    DG_CHECK_LAUNCH("fm_diff");
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)dpart, g, 1.0 / (double)J, loss);
-    DG_CHECK_LAUNCH("fm_final");
+        hipLaunchKernelGGL(fm_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dg_ptrs(DG_TAB(diff), groups), N, (long)J, dg_ptrs(DG_TAB(gout), groups), pr, pf);
+    DG_CHECK_LAUNCH("fm_bwd");
     return DG_OK;
 }
 extern "C" int dg_fm_bwd_t(const float* diff, int N, size_t J, const float* gout, void* dreal, void* dfake, int io_bf16, dg_stream_t stream) {
     DG_CHECK_ARG(diff && gout && N > 0 && J > 0 && J % 4 == 0, "dg_fm_bwd: bad argument");
-    const long total = (long)(J / 4) * N;
-    long g = (total + 255) / 256;
-    if (g > 2048) g = 2048;
-    if (io_bf16)
-        hipLaunchKernelGGL(fm_bwd_kernel<__bf16>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, (__bf16*)dreal, (__bf16*)dfake);
-    else
-        hipLaunchKernelGGL(fm_bwd_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, diff, N, (long)J, gout, (float*)dreal, (float*)dfake);
-    DG_CHECK_LAUNCH("fm_bwd");
-    return DG_OK;
+    return fm_bwd_run(1, &diff, N, J, &gout, &dreal, &dfake, io_bf16, stream);
 }
 extern "C" int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t stream) {
     return dg_fm_bwd_t(diff, N, J, gout, dreal, dfake, 0, stream);
+}
+/* dreal / dfake tables may be NULL (that side needs no gradient); within a table every problem's entry is set or none is */
+extern "C" int dg_fm_bwd_g(int groups, const float* const* diff, int N, size_t J, const float* const* gout, float* const* dreal, float* const* dfake,
+                           dg_stream_t stream) {
+    return fm_bwd_run(groups, diff, N, J, gout, (void* const*)dreal, (void* const*)dfake, 0, stream);
 }
 
 extern "C" int dg_loss_mix_fwd(const float* lossvec, float* out8, int nfm, float rate, int arch, dg_stream_t stream) {

@@ -14,6 +14,10 @@ int dg_fail(int code, const char* fmt, ...) {
     return code;
 }
 int dg_get_option(int idx) { return (idx >= 0 && idx < DG_OPT_COUNT) ? g_options[idx] : 0; }
+static thread_local int tl_call_prec = -1;
+int dg_cur_prec() { return tl_call_prec >= 0 ? tl_call_prec : g_options[DG_OPT_BF16]; }
+DgPrecScope::DgPrecScope(int prec) : old(tl_call_prec) { if (prec >= 0) tl_call_prec = prec; }     // DG_PREC_DEFAULT (-1): keep what is in force
+DgPrecScope::~DgPrecScope() { tl_call_prec = old; }
 
 extern "C" int dg_version(void) { return 100; }
 extern "C" const char* dg_last_error(void) { return dg_err_buf; }
@@ -25,7 +29,11 @@ extern "C" int dg_set_option(const char* name, int value) {
     else if (!strcmp(name, "split_below")) g_options[DG_OPT_SPLIT_BELOW] = value;
     else if (!strcmp(name, "no_xcd_group")) g_options[DG_OPT_RESERVED] = value;   // 1: plain blockIdx -> tile order; 3: only the per-XCD row-tile blocks of single-column forward convs off
     else if (!strcmp(name, "bf16")) g_options[DG_OPT_BF16] = value;   // 1: interior conv GEMMs on bf16 MFMA, fp32 accumulate; 2: fp32 operands as three bf16 planes
-    else if (!strcmp(name, "dbg_zero")) g_options[DG_OPT_DBG_ZERO] = value;   // timing experiments only: drop operand loads (wrong results)
+#ifdef DG_TIMING_KNOBS
+    // timing builds only (make TIMING=1 -> libdiscogan_hip_timing.so, tools/bench_ops.py --dbg_zero): 1|2|3 drop operand loads (WRONG
+    // results), 4 / 8 select older reduction walks (correct results, another summation order).  The product library has no such switch.
+    else if (!strcmp(name, "dbg_zero")) g_options[DG_OPT_DBG_ZERO] = value;
+#endif
     else if (!strcmp(name, "no_dma")) g_options[DG_OPT_NO_DMA] = value;   // 1: bf16-operand convs stay on the register-staged tiles (igemm.hip) instead of the LDS-DMA kernel
     else if (!strcmp(name, "dma_mfma")) g_options[DG_OPT_DMA_MFMA] = value;   // 32: the LDS-DMA kernel's 32x32x16 body instead of 16x16x32; 1: no window kernels (A/B)
     else if (!strcmp(name, "x3_mfma")) g_options[DG_OPT_X3_MFMA] = value;   // 16: the f32x3 plane kernel's 16x16x32 body (planes paired along k) instead of 32x32x16

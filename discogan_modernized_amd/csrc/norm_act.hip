@@ -9,6 +9,7 @@
 //   backward: g = dz * act'(u) with u recomputed bit-identically from y;
 //             dbeta = sum g, dgamma = sum g*xhat, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
 #include "dg_common.h"
+#include <string.h>
 
 #define BN_U 8     // independent row loads in flight per thread (same-box A/B of the whole iteration: U=2 13.46 ms, 4 13.17, 8 13.13)
 
@@ -48,6 +49,29 @@ __device__ __forceinline__ void bn_st(__bf16* p, const float (&v)[8]) {
 
 __device__ __forceinline__ float bn_norm(float y, float mean, float gs, float beta) { return fmaf(y - mean, gs, beta); }
 
+// Grouped launches (dg_bn_*_g; round 4): the problems of one launch -- the same BatchNorm layer of the A-side and the B-side network, a
+// discriminator layer's real and fake pass (image_translation.py:342-361) -- share M, C and every launch parameter; each has its own
+// tensors.  A block index picks the problem (wave-uniform: scalar loads from the kernel arguments); the kernel bodies are the
+// one-problem bodies, so a problem's result is bitwise what its own launch computes.
+struct BnProb {
+    const void* y;        // conv output (statistics, apply, backward)
+    const void* dz;       // backward: gradient of the layer's output
+    void* out;            // apply: z; backward apply: dy
+    void* out16;          // bf16 shadow / plane triple of `out` (one-problem forms only)
+    void* ws;             // this problem's workspace: partials [+ backward coefficients]
+    float* saved;         // [2][C] mean, invstd
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    int64_t* nbt;
+    float* dgamma;
+    float* dbeta;
+};
+struct BnGroup {
+    BnProb p[DG_MAX_GROUPS];
+};
+
 // Reduction-pass geometry: a 256-thread block is TX float4 lanes along channels x TY = 256/TX row lanes, with
 // TX = the power of two covering C/4 (capped at 64), so every thread is busy for C = 64 as for C = 512.
 // grid = (cchunks, rchunks); each block walks rows r0 + ty + k*TY of its row chunk.
@@ -70,9 +94,10 @@ static BnGrid bn_grid(int M, int C, int V = 4) {
 
 // part layout: [2][rchunks][C]  (0: sum of (y - shift), 1: sum of (y - shift)^2; shift = y[row 0])
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ y, float* __restrict__ part,
-                                                               int M, int C, int rchunks, int TX) {
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const BnGroup G, int M, int C, int rchunks, int TX) {
     constexpr int V = BnV<T>::V;
+    const T* __restrict__ y = (const T*)G.p[blockIdx.z].y;
+    float* __restrict__ part = (float*)G.p[blockIdx.z].ws;
     __shared__ float red[2][256][V];
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -180,26 +205,36 @@ __device__ __forceinline__ int bn_reduce_partials(const float* __restrict__ part
     return c;
 }
 
+// blockIdx.y = output set; share > 1: `share` consecutive problems are passes through the SAME BatchNorm module (a discriminator's real
+// and fake pass): their running-statistics updates are applied one after the other in problem order by the thread that owns the
+// channel -- what `share` consecutive launches leave.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const T* __restrict__ y, const float* __restrict__ part, int M, int C, int rchunks,
-                                                                float eps, float momentum, float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                                float* __restrict__ saved) {
-    double s, q;
-    const int c = bn_reduce_partials(part, C, rchunks, &s, &q);
-    if (c < 0) return;
-    if (c == 0 && nbt) nbt[0] += 1;
-    const double dm = s / M;
-    const double mean = (double)y[c] + dm;
-    double var = q / M - dm * dm;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    saved[c] = (float)mean;
-    saved[C + c] = invstd;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) {
-        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const BnGroup G, int share, int M, int C, int rchunks, float eps, float momentum) {
+    for (int j = 0; j < share; ++j) {
+        const BnProb& P = G.p[blockIdx.y * share + j];
+        const T* __restrict__ y = (const T*)P.y;
+        float* __restrict__ running_mean = P.rmean;
+        float* __restrict__ running_var = P.rvar;
+        int64_t* __restrict__ nbt = P.nbt;
+        float* __restrict__ saved = P.saved;
+        double s, q;
+        const int c = bn_reduce_partials((const float*)P.ws, C, rchunks, &s, &q);
+        if (c >= 0) {
+            if (c == 0 && nbt) nbt[0] += 1;
+            const double dm = s / M;
+            const double mean = (double)y[c] + dm;
+            double var = q / M - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            saved[c] = (float)mean;
+            saved[C + c] = invstd;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            if (running_var) {
+                const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+        if (j + 1 < share) __syncthreads();       // the LDS rows of bn_reduce_partials are reused by the next problem
     }
 }
 
@@ -357,11 +392,15 @@ __device__ __forceinline__ BnItem bn_item(long i, int cvn, int cm) {
     return it;
 }
 template <typename TI, typename TO, int Z16>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ y, TO* __restrict__ z, long totalv,
-                                                         int C, const float* __restrict__ saved,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope, __bf16* __restrict__ z16, long pstride, int cm) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnGroup G, long totalv, int C, int act, float slope, long pstride, int cm) {
     constexpr int V = BnV<TI>::V;
+    const BnProb& P = G.p[blockIdx.y];
+    const TI* __restrict__ y = (const TI*)P.y;
+    TO* __restrict__ z = (TO*)P.out;
+    const float* __restrict__ saved = P.saved;
+    const float* __restrict__ gamma = P.gamma;
+    const float* __restrict__ beta = P.beta;
+    __bf16* __restrict__ z16 = (__bf16*)P.out16;
     static_assert(BnV<TI>::V == BnV<TO>::V, "same storage type on both sides");
     const int cvn = C / V;
     for (long lin = (long)blockIdx.x * 256 + threadIdx.x; lin < totalv; lin += (long)gridDim.x * 256) {
@@ -393,11 +432,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const TI* __restrict__ 
 
 // bf16 storage, forward apply with the reduction passes' geometry: fixed channels per thread (parameters loaded once, no
 // 64-bit modulo per access), U rows in flight
-__global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const __bf16* __restrict__ y, __bf16* __restrict__ z, int M, int C,
-                                                           int rchunks, int TX, const float* __restrict__ saved,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int act, float slope) {
+__global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const BnGroup G, int M, int C, int rchunks, int TX, int act, float slope) {
     constexpr int V = 8, U = 4;
+    const BnProb& P = G.p[blockIdx.z];
+    const __bf16* __restrict__ y = (const __bf16*)P.y;
+    __bf16* __restrict__ z = (__bf16*)P.out;
+    const float* __restrict__ saved = P.saved;
+    const float* __restrict__ gamma = P.gamma;
+    const float* __restrict__ beta = P.beta;
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int c = (blockIdx.x * TX + tx) * V;
@@ -448,11 +490,15 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // part layout (fp64): [2][rchunks][C]  (0: sum g, 1: sum g*xhat)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ y,
-                                                             double* __restrict__ part, int M, int C, int rchunks, int TX,
-                                                             const float* __restrict__ saved, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int act, float slope) {
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnGroup G, int M, int C, int rchunks, int TX, int act, float slope) {
     constexpr int V = BnV<T>::V;
+    const BnProb& P = G.p[blockIdx.z];
+    const T* __restrict__ dz = (const T*)P.dz;
+    const T* __restrict__ y = (const T*)P.y;
+    double* __restrict__ part = (double*)P.ws;
+    const float* __restrict__ saved = P.saved;
+    const float* __restrict__ gamma = P.gamma;
+    const float* __restrict__ beta = P.beta;
     __shared__ double red[2][256][V];
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -544,45 +590,55 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 }
 
 // coef (fp64): [2][C] = dbeta/M, dgamma/M  (kept in the workspace after the partials)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int M, int C, int rchunks,
-                                                              double* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate) {
+// blockIdx.y = output set; share > 1: `share` consecutive problems went through the SAME BatchNorm module (a discriminator's real and
+// fake pass) and accumulate into the same dgamma / dbeta: added one after the other in problem order, as consecutive launches do.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnGroup G, int share, int M, int C, int rchunks, int accumulate) {
     __shared__ double red[2][32][BN_FIN_CH];
     const int cl = threadIdx.x % BN_FIN_CH, pl = threadIdx.x / BN_FIN_CH;
     const int c = blockIdx.x * BN_FIN_CH + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        int r = pl;
-        for (; r + 96 < rchunks; r += 128) {       // 8 loads in flight, summed in row order
-            double vs[4], vq[4];
+    for (int j = 0; j < share; ++j) {
+        const BnProb& P = G.p[blockIdx.y * share + j];
+        const double* __restrict__ part = (const double*)P.ws;
+        double* __restrict__ coef = (double*)P.ws + (size_t)2 * rchunks * C;
+        float* __restrict__ dgamma = P.dgamma;
+        float* __restrict__ dbeta = P.dbeta;
+        double s = 0.0, q = 0.0;
+        if (c < C) {
+            int r = pl;
+            for (; r + 96 < rchunks; r += 128) {       // 8 loads in flight, summed in row order
+                double vs[4], vq[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                vs[u] = part[(long)(r + 32 * u) * C + c];
-                vq[u] = part[((long)rchunks + r + 32 * u) * C + c];
+                for (int u = 0; u < 4; ++u) {
+                    vs[u] = part[(long)(r + 32 * u) * C + c];
+                    vq[u] = part[((long)rchunks + r + 32 * u) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s += vs[u];
+                    q += vq[u];
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s += vs[u];
-                q += vq[u];
+            for (; r < rchunks; r += 32) {
+                s += part[(long)r * C + c];
+                q += part[((long)rchunks + r) * C + c];
             }
         }
-        for (; r < rchunks; r += 32) {
-            s += part[(long)r * C + c];
-            q += part[((long)rchunks + r) * C + c];
+        if (j > 0) __syncthreads();
+        red[0][pl][cl] = s;
+        red[1][pl][cl] = q;
+        __syncthreads();
+        if (pl == 0 && c < C) {
+            for (int k = 1; k < 32; ++k) {
+                s += red[0][k][cl];
+                q += red[1][k][cl];
+            }
+            coef[c] = s / M;
+            coef[C + c] = q / M;
+            const int acc = accumulate || j > 0;
+            if (dbeta) dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)s;
+            if (dgamma) dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)q;
         }
     }
-    red[0][pl][cl] = s;
-    red[1][pl][cl] = q;
-    __syncthreads();
-    if (pl != 0 || c >= C) return;
-    for (int j = 1; j < 32; ++j) {
-        s += red[0][j][cl];
-        q += red[1][j][cl];
-    }
-    coef[c] = s / M;
-    coef[C + c] = q / M;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
 }
 
 // bf16 storage: dz, y in, dy out, all bf16.  The reduction geometry of the partial pass (fixed channels per thread, TY row
@@ -590,12 +646,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 // form  dy = gs * ((g - c1) - (y - mean) * istd * c2)  -- the inputs carry 8 significant bits and dy is rounded to 8, which
 // is what bounds the result, not the fp32 evaluation (the fp32-storage kernel below keeps fp64: there the fp32 chain would be
 // the largest error).  Measured: the fp64 form ran at the SAME element rate as the fp32-storage kernel, i.e. compute-bound.
-__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const __bf16* __restrict__ dz, const __bf16* __restrict__ y,
-                                                             __bf16* __restrict__ dy, int M, int C, int rchunks, int TX,
-                                                             const float* __restrict__ saved, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const double* __restrict__ coef,
-                                                             int act, float slope) {
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const BnGroup G, int M, int C, int rchunks, int TX, int coef_rchunks, int act, float slope) {
     constexpr int V = 8, U = 4;
+    const BnProb& P = G.p[blockIdx.z];
+    const __bf16* __restrict__ dz = (const __bf16*)P.dz;
+    const __bf16* __restrict__ y = (const __bf16*)P.y;
+    __bf16* __restrict__ dy = (__bf16*)P.out;
+    const float* __restrict__ saved = P.saved;
+    const float* __restrict__ gamma = P.gamma;
+    const float* __restrict__ beta = P.beta;
+    const double* __restrict__ coef = (const double*)P.ws + (size_t)2 * coef_rchunks * C;
     const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int c = (blockIdx.x * TX + tx) * V;
@@ -650,12 +710,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const __bf16* __res
 
 // T: element type of dz / y / dy.  D16 (fp32 only) = 1: also write a bf16 shadow of dy; = 3: its three bf16 planes
 template <typename T, int D16>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
-                                                           T* __restrict__ dy, long totalv, int C,
-                                                           const float* __restrict__ saved, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const double* __restrict__ coef,
-                                                           int act, float slope, __bf16* __restrict__ dy16, long pstride, int cm) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnGroup G, long totalv, int C, int coef_rchunks, int act, float slope, long pstride, int cm) {
     constexpr int V = BnV<T>::V;
+    const BnProb& P = G.p[blockIdx.y];
+    const T* __restrict__ dz = (const T*)P.dz;
+    const T* __restrict__ y = (const T*)P.y;
+    T* __restrict__ dy = (T*)P.out;
+    const float* __restrict__ saved = P.saved;
+    const float* __restrict__ gamma = P.gamma;
+    const float* __restrict__ beta = P.beta;
+    const double* __restrict__ coef = (const double*)P.ws + (size_t)2 * coef_rchunks * C;
+    __bf16* __restrict__ dy16 = (__bf16*)P.out16;
     const int cvn = C / V;
     for (long lin = (long)blockIdx.x * 256 + threadIdx.x; lin < totalv; lin += (long)gridDim.x * 256) {
         long idx = lin, pi = lin * 4;
@@ -691,8 +756,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total4,
-                                                      long n, int act, float slope) {
+__global__ __launch_bounds__(256) void act_fwd_kernel(const DgPtrs xs, const DgPtrs ys, long total4, long n, int act, float slope) {
+    const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
+    float* __restrict__ y = dg_pick<float>(ys, blockIdx.y);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         if (idx * 4 + 3 < n) {
             const f32x4 v = *(const f32x4*)(x + idx * 4);
@@ -714,8 +780,10 @@ __device__ __forceinline__ float act_bwd_one(float dy, float out, int act, float
     if (act == DG_ACT_RELU) return out > 0.f ? dy : 0.f;
     return dy;
 }
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
-                                                      float* __restrict__ dx, long total4, long n, int act, float slope) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const DgPtrs dys, const DgPtrs outs, const DgPtrs dxs, long total4, long n, int act, float slope) {
+    const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.y);
+    const float* __restrict__ out = dg_pick<const float>(outs, blockIdx.y);
+    float* __restrict__ dx = dg_pick<float>(dxs, blockIdx.y);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
         if (idx * 4 + 3 < n) {
             const f32x4 d = *(const f32x4*)(dy + idx * 4), o = *(const f32x4*)(out + idx * 4);
@@ -755,35 +823,59 @@ extern "C" size_t dg_bn_workspace_bytes(int M, int C) {
 }
 
 // io_bf16: every activation tensor of the call (y / z / dz / dy) is bf16; statistics, parameters and their gradients stay fp32
+// groups problems per launch (BnGroup), share: consecutive problems through the same module (see bn_stats_finalize_kernel)
 template <typename T>
-static int bn_train_stats_impl(const T* y, int M, int C, float eps, float momentum, float* running_mean, float* running_var,
-                               int64_t* nbt, float* saved, void* ws, size_t ws_bytes, dg_stream_t stream) {
+static int bn_train_stats_impl(int groups, int share, const BnGroup& G, int M, int C, float eps, float momentum, size_t ws_bytes, dg_stream_t stream) {
     constexpr int V = BnV<T>::V;
-    DG_CHECK_ARG(y && saved, "dg_bn_train_stats: null pointer");
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && share >= 1 && groups % share == 0, "dg_bn_train_stats: groups=%d share=%d", groups, share);
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(G.p[i].y && G.p[i].saved, "dg_bn_train_stats: null pointer (problem %d)", i);
     DG_CHECK_ARG(M >= 2, "dg_bn_train_stats: Expected more than 1 value per channel when training (M=%d)", M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_train_stats: C=%d must be a multiple of %d", C, V);
-    if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
-        return dg_fail(DG_ERR_WORKSPACE, "dg_bn_train_stats: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
+    for (int i = 0; i < groups; ++i)
+        if (G.p[i].ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
+            return dg_fail(DG_ERR_WORKSPACE, "dg_bn_train_stats: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
     const BnGrid g = bn_grid(M, C, V);
     const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(cc, rc), dim3(256), 0, st, y, (float*)ws, M, C, rc, g.tx);
+    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(cc, rc, groups), dim3(256), 0, st, G, M, C, rc, g.tx);
     DG_CHECK_LAUNCH("bn_stats_partial");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<T>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, y, (const float*)ws, M, C, rc, eps,
-                       momentum, running_mean, running_var, nbt, saved);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<T>, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH, groups / share), dim3(256), 0, st, G, share, M, C, rc, eps, momentum);
     DG_CHECK_LAUNCH("bn_stats_finalize");
     return DG_OK;
 }
-extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
-                                 float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
-                                 dg_stream_t stream) {
-    return bn_train_stats_impl<float>(y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
+static BnGroup bn_group_zero() {
+    BnGroup G;
+    memset(&G, 0, sizeof(G));
+    return G;
 }
 extern "C" int dg_bn_train_stats_t(const void* y, int io_bf16, int M, int C, float eps, float momentum, float* running_mean,
                                    float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
                                    dg_stream_t stream) {
-    if (io_bf16) return bn_train_stats_impl<__bf16>((const __bf16*)y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
-    return bn_train_stats_impl<float>((const float*)y, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
+    BnGroup G = bn_group_zero();
+    G.p[0].y = y; G.p[0].rmean = running_mean; G.p[0].rvar = running_var; G.p[0].nbt = nbt; G.p[0].saved = saved; G.p[0].ws = ws;
+    if (io_bf16) return bn_train_stats_impl<__bf16>(1, 1, G, M, C, eps, momentum, ws_bytes, stream);
+    return bn_train_stats_impl<float>(1, 1, G, M, C, eps, momentum, ws_bytes, stream);
+}
+extern "C" int dg_bn_train_stats(const float* y, int M, int C, float eps, float momentum, float* running_mean,
+                                 float* running_var, int64_t* nbt, float* saved, void* ws, size_t ws_bytes,
+                                 dg_stream_t stream) {
+    return dg_bn_train_stats_t(y, 0, M, C, eps, momentum, running_mean, running_var, nbt, saved, ws, ws_bytes, stream);
+}
+extern "C" int dg_bn_train_stats_g(int groups, int share, const float* const* y, int M, int C, float eps, float momentum, float* const* running_mean,
+                                   float* const* running_var, int64_t* const* nbt, float* const* saved, void* const* ws, size_t ws_bytes,
+                                   dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && y && saved && ws, "dg_bn_train_stats_g: bad group / null table");
+    BnGroup G = bn_group_zero();
+    for (int i = 0; i < groups; ++i) {
+        G.p[i].y = y[i]; G.p[i].saved = saved[i]; G.p[i].ws = ws[i];
+        G.p[i].rmean = running_mean ? running_mean[i] : nullptr;
+        G.p[i].rvar = running_var ? running_var[i] : nullptr;
+        G.p[i].nbt = nbt ? nbt[i] : nullptr;
+    }
+    if (share > 1)
+        for (int i = 0; i < groups; ++i)
+            DG_CHECK_ARG(G.p[i].rmean == G.p[i / share * share].rmean, "dg_bn_train_stats_g: problems of one share set must name the same module buffers");
+    return bn_train_stats_impl<float>(groups, share < 1 ? 1 : share, G, M, C, eps, momentum, ws_bytes, stream);
 }
 
 static int bn_partials_row_blocks(int P) {
@@ -820,48 +912,62 @@ extern "C" int dg_bn_stats_from_partials(const float* stat, int P, int M, int C,
 }
 
 template <typename T>
-static int bn_act_fwd_impl(const T* y, T* z, void* z16, int M, int C, const float* saved, const float* gamma,
-                           const float* beta, int act, float slope, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
+static int bn_act_fwd_impl(int groups, const BnGroup& G, int M, int C, int act, float slope, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
-    DG_CHECK_ARG(y && (z || (z16 && pstride > 0)) && saved && gamma && beta, "dg_bn_act_fwd: null pointer");
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS, "dg_bn_act_fwd: groups=%d", groups);
+    const void* z16 = G.p[0].out16;
+    DG_CHECK_ARG(groups == 1 || z16 == nullptr, "dg_bn_act_fwd: shadow / plane outputs exist in the one-problem forms only");
+    for (int i = 0; i < groups; ++i)
+        DG_CHECK_ARG(G.p[i].y && (G.p[i].out || (G.p[i].out16 && pstride > 0)) && G.p[i].saved && G.p[i].gamma && G.p[i].beta, "dg_bn_act_fwd: null pointer");
     DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_fwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_fwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_fwd: bad act %d", act);
     const long totalv = (long)M * C / V;
     if constexpr (V == 8) {
         const BnGrid g = bn_grid(M, C, V);
-        hipLaunchKernelGGL(bn_act_fwd16_kernel, dim3(g.cchunks, g.rchunks), dim3(256), 0, (hipStream_t)stream, y, z, M, C, g.rchunks, g.tx,
-                           saved, gamma, beta, act, slope);
+        hipLaunchKernelGGL(bn_act_fwd16_kernel, dim3(g.cchunks, g.rchunks, groups), dim3(256), 0, (hipStream_t)stream, G, M, C, g.rchunks, g.tx, act, slope);
         DG_CHECK_LAUNCH("bn_act_fwd16");
         return DG_OK;
     }
+    const dim3 grid(stream_grid(totalv), groups);
     if constexpr (V == 4) {
         if (z16 && pstride > 0) {
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, pstride, plane_cm);
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 3>), grid, dim3(256), 0, (hipStream_t)stream, G, totalv, C, act, slope, pstride, plane_cm);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
         if (z16) {
-            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                               saved, gamma, beta, act, slope, (__bf16*)z16, 0L, 0);
+            hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 1>), grid, dim3(256), 0, (hipStream_t)stream, G, totalv, C, act, slope, 0L, 0);
             DG_CHECK_LAUNCH("bn_act_fwd");
             return DG_OK;
         }
     }
-    hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, (hipStream_t)stream, y, z, totalv, C,
-                       saved, gamma, beta, act, slope, (__bf16*)nullptr, 0L, 0);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<T, T, 0>), grid, dim3(256), 0, (hipStream_t)stream, G, totalv, C, act, slope, 0L, 0);
     DG_CHECK_LAUNCH("bn_act_fwd");
     return DG_OK;
 }
+static BnGroup bn_fwd_one(const void* y, void* z, void* z16, const float* saved, const float* gamma, const float* beta) {
+    BnGroup G = bn_group_zero();
+    G.p[0].y = y; G.p[0].out = z; G.p[0].out16 = z16; G.p[0].saved = (float*)saved; G.p[0].gamma = gamma; G.p[0].beta = beta;
+    return G;
+}
 extern "C" int dg_bn_act_fwd(const float* y, float* z, int M, int C, const float* saved, const float* gamma,
                              const float* beta, int act, float slope, dg_stream_t stream) {
-    return bn_act_fwd_impl<float>(y, z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
+    return bn_act_fwd_impl<float>(1, bn_fwd_one(y, z, nullptr, saved, gamma, beta), M, C, act, slope, stream);
+}
+extern "C" int dg_bn_act_fwd_g(int groups, const float* const* y, float* const* z, int M, int C, const float* const* saved, const float* const* gamma,
+                               const float* const* beta, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && y && z && saved && gamma && beta, "dg_bn_act_fwd_g: bad group / null table");
+    BnGroup G = bn_group_zero();
+    for (int i = 0; i < groups; ++i) {
+        G.p[i].y = y[i]; G.p[i].out = z[i]; G.p[i].saved = (float*)saved[i]; G.p[i].gamma = gamma[i]; G.p[i].beta = beta[i];
+    }
+    return bn_act_fwd_impl<float>(groups, G, M, C, act, slope, stream);
 }
 extern "C" int dg_bn_act_fwd_bf16(const float* y, float* z, void* z_bf16, int M, int C, const float* saved, const float* gamma,
                                   const float* beta, int act, float slope, dg_stream_t stream) {
     DG_CHECK_ARG(z_bf16, "dg_bn_act_fwd_bf16: null shadow pointer");
-    return bn_act_fwd_impl<float>(y, z, z_bf16, M, C, saved, gamma, beta, act, slope, stream);
+    return bn_act_fwd_impl<float>(1, bn_fwd_one(y, z, z_bf16, saved, gamma, beta), M, C, act, slope, stream);
 }
 // the same pass, also writing the three bf16 planes of z (plane_elems elements apart, >= M * C, % 8 == 0) for the f32x3 matrix path
 extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t plane_elems, int plane_layout, int M, int C, const float* saved,
@@ -869,70 +975,92 @@ extern "C" int dg_bn_act_fwd_x3(const float* y, float* z, void* z_planes, size_t
     DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_fwd_x3: plane_layout 0 (pixel-major) or 1 (quad-chunk)");
     DG_CHECK_ARG(z_planes, "dg_bn_act_fwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_fwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
-    return bn_act_fwd_impl<float>(y, z, z_planes, M, C, saved, gamma, beta, act, slope, stream, (long)plane_elems, plane_layout);
+    return bn_act_fwd_impl<float>(1, bn_fwd_one(y, z, z_planes, saved, gamma, beta), M, C, act, slope, stream, (long)plane_elems, plane_layout);
 }
 extern "C" int dg_bn_act_fwd_t(const void* y, void* z, int io_bf16, int M, int C, const float* saved, const float* gamma,
                                const float* beta, int act, float slope, dg_stream_t stream) {
-    if (io_bf16) return bn_act_fwd_impl<__bf16>((const __bf16*)y, (__bf16*)z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
-    return bn_act_fwd_impl<float>((const float*)y, (float*)z, nullptr, M, C, saved, gamma, beta, act, slope, stream);
+    if (io_bf16) return bn_act_fwd_impl<__bf16>(1, bn_fwd_one(y, z, nullptr, saved, gamma, beta), M, C, act, slope, stream);
+    return bn_act_fwd_impl<float>(1, bn_fwd_one(y, z, nullptr, saved, gamma, beta), M, C, act, slope, stream);
 }
 
 template <typename T>
-static int bn_act_bwd_impl(const T* dz, const T* y, T* dy, void* dy16, int M, int C, const float* saved,
-                           const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
-                           int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
+static int bn_act_bwd_impl(int groups, int share, const BnGroup& G, int M, int C, int act, float slope, int accumulate, size_t ws_bytes,
+                           dg_stream_t stream, long pstride = 0, int plane_cm = 0) {
     constexpr int V = BnV<T>::V;
-    DG_CHECK_ARG(dz && y && (dy || (dy16 && pstride > 0)) && saved && gamma && beta, "dg_bn_act_bwd: null pointer");
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && share >= 1 && groups % share == 0, "dg_bn_act_bwd: groups=%d share=%d", groups, share);
+    const void* dy16 = G.p[0].out16;
+    DG_CHECK_ARG(groups == 1 || dy16 == nullptr, "dg_bn_act_bwd: shadow / plane outputs exist in the one-problem forms only");
+    for (int i = 0; i < groups; ++i)
+        DG_CHECK_ARG(G.p[i].dz && G.p[i].y && (G.p[i].out || (G.p[i].out16 && pstride > 0)) && G.p[i].saved && G.p[i].gamma && G.p[i].beta, "dg_bn_act_bwd: null pointer");
     DG_CHECK_ARG(!plane_cm || (pstride > 0 && C % 64 == 0 && M % 4 == 0), "dg_bn_act_bwd: quad-chunk planes need plane operands, C %% 64 == 0 and M %% 4 == 0 (C=%d, M=%d)", C, M);
     DG_CHECK_ARG(C >= V && C % V == 0, "dg_bn_act_bwd: C=%d must be a multiple of %d", C, V);
     DG_CHECK_ARG(act == DG_ACT_NONE || act == DG_ACT_LEAKY || act == DG_ACT_RELU, "dg_bn_act_bwd: bad act %d", act);
-    if (ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
-        return dg_fail(DG_ERR_WORKSPACE, "dg_bn_act_bwd: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
+    for (int i = 0; i < groups; ++i)
+        if (G.p[i].ws == nullptr || ws_bytes < dg_bn_workspace_bytes(M, C))
+            return dg_fail(DG_ERR_WORKSPACE, "dg_bn_act_bwd: workspace %zu < %zu", ws_bytes, dg_bn_workspace_bytes(M, C));
     const BnGrid g = bn_grid(M, C, V);
     const int cc = g.cchunks, rc = g.rchunks;
     hipStream_t st = (hipStream_t)stream;
-    double* part = (double*)ws;
-    double* coef = part + (size_t)2 * rc * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(cc, rc), dim3(256), 0, st, dz, y, part, M, C, rc, g.tx, saved, gamma, beta, act, slope);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(cc, rc, groups), dim3(256), 0, st, G, M, C, rc, g.tx, act, slope);
     DG_CHECK_LAUNCH("bn_bwd_partial");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH), dim3(256), 0, st, (const double*)part, M, C, rc, coef,
-                       dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH, groups / share), dim3(256), 0, st, G, share, M, C, rc, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long totalv = (long)M * C / V;
+    const dim3 grid(stream_grid(totalv), groups);
     if constexpr (V == 4) {
         if (dy16 && pstride > 0) {
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 3>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, pstride, plane_cm);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 3>), grid, dim3(256), 0, st, G, totalv, C, rc, act, slope, pstride, plane_cm);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
         if (dy16) {
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                               beta, (const double*)coef, act, slope, (__bf16*)dy16, 0L, 0);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, st, G, totalv, C, rc, act, slope, 0L, 0);
             DG_CHECK_LAUNCH("bn_bwd_apply");
             return DG_OK;
         }
     } else {
-        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(cc, rc), dim3(256), 0, st, dz, y, dy, M, C, rc, g.tx, saved, gamma, beta,
-                           (const double*)coef, act, slope);
+        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(cc, rc, groups), dim3(256), 0, st, G, M, C, rc, g.tx, rc, act, slope);
         DG_CHECK_LAUNCH("bn_bwd_apply16");
         return DG_OK;
     }
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), dim3(stream_grid(totalv)), dim3(256), 0, st, dz, y, dy, totalv, C, saved, gamma,
-                       beta, (const double*)coef, act, slope, (__bf16*)nullptr, 0L, 0);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 0>), grid, dim3(256), 0, st, G, totalv, C, rc, act, slope, 0L, 0);
     DG_CHECK_LAUNCH("bn_bwd_apply");
     return DG_OK;
+}
+static BnGroup bn_bwd_one(const void* dz, const void* y, void* dy, void* dy16, const float* saved, const float* gamma, const float* beta,
+                          float* dgamma, float* dbeta, void* ws) {
+    BnGroup G = bn_group_zero();
+    BnProb& P = G.p[0];
+    P.dz = dz; P.y = y; P.out = dy; P.out16 = dy16; P.saved = (float*)saved; P.gamma = gamma; P.beta = beta; P.dgamma = dgamma; P.dbeta = dbeta; P.ws = ws;
+    return G;
 }
 extern "C" int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, const float* saved,
                              const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                              int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return bn_act_bwd_impl<float>(dz, y, dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+    return bn_act_bwd_impl<float>(1, 1, bn_bwd_one(dz, y, dy, nullptr, saved, gamma, beta, dgamma, dbeta, ws), M, C, act, slope, accumulate, ws_bytes, stream);
+}
+extern "C" int dg_bn_act_bwd_g(int groups, int share, const float* const* dz, const float* const* y, float* const* dy, int M, int C,
+                               const float* const* saved, const float* const* gamma, const float* const* beta, int act, float slope,
+                               float* const* dgamma, float* const* dbeta, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && dz && y && dy && saved && gamma && beta && ws, "dg_bn_act_bwd_g: bad group / null table");
+    BnGroup G = bn_group_zero();
+    for (int i = 0; i < groups; ++i) {
+        BnProb& P = G.p[i];
+        P.dz = dz[i]; P.y = y[i]; P.out = dy[i]; P.saved = (float*)saved[i]; P.gamma = gamma[i]; P.beta = beta[i]; P.ws = ws[i];
+        P.dgamma = dgamma ? dgamma[i] : nullptr;
+        P.dbeta = dbeta ? dbeta[i] : nullptr;
+    }
+    if (share > 1)
+        for (int i = 0; i < groups; ++i)
+            DG_CHECK_ARG(G.p[i].dgamma == G.p[i / share * share].dgamma && G.p[i].dbeta == G.p[i / share * share].dbeta,
+                         "dg_bn_act_bwd_g: problems of one share set must name the same dgamma / dbeta");
+    return bn_act_bwd_impl<float>(groups, share < 1 ? 1 : share, G, M, C, act, slope, accumulate, ws_bytes, stream);
 }
 extern "C" int dg_bn_act_bwd_bf16(const float* dz, const float* y, float* dy, void* dy_bf16, int M, int C, const float* saved,
                                   const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                                   int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
     DG_CHECK_ARG(dy_bf16, "dg_bn_act_bwd_bf16: null shadow pointer");
-    return bn_act_bwd_impl<float>(dz, y, dy, dy_bf16, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream);
+    return bn_act_bwd_impl<float>(1, 1, bn_bwd_one(dz, y, dy, dy_bf16, saved, gamma, beta, dgamma, dbeta, ws), M, C, act, slope, accumulate, ws_bytes, stream);
 }
 extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void* dy_planes, size_t plane_elems, int plane_layout, int M, int C,
                                 const float* saved, const float* gamma, const float* beta, int act, float slope, float* dgamma,
@@ -940,36 +1068,45 @@ extern "C" int dg_bn_act_bwd_x3(const float* dz, const float* y, float* dy, void
     DG_CHECK_ARG(plane_layout == 0 || plane_layout == 1, "dg_bn_act_bwd_x3: plane_layout 0 (pixel-major) or 1 (quad-chunk)");
     DG_CHECK_ARG(dy_planes, "dg_bn_act_bwd_x3: null plane pointer");
     DG_CHECK_ARG(plane_elems >= (size_t)M * C && plane_elems % 8 == 0, "dg_bn_act_bwd_x3: plane distance %zu for %ld elements", plane_elems, (long)M * C);
-    return bn_act_bwd_impl<float>(dz, y, dy, dy_planes, M, C, saved, gamma, beta, act, slope, dgamma, dbeta, accumulate, ws, ws_bytes, stream,
-                                  (long)plane_elems, plane_layout);
+    return bn_act_bwd_impl<float>(1, 1, bn_bwd_one(dz, y, dy, dy_planes, saved, gamma, beta, dgamma, dbeta, ws), M, C, act, slope, accumulate, ws_bytes,
+                                  stream, (long)plane_elems, plane_layout);
 }
 extern "C" int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_bf16, int M, int C, const float* saved,
                                const float* gamma, const float* beta, int act, float slope, float* dgamma, float* dbeta,
                                int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    if (io_bf16)
-        return bn_act_bwd_impl<__bf16>((const __bf16*)dz, (const __bf16*)y, (__bf16*)dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma,
-                                       dbeta, accumulate, ws, ws_bytes, stream);
-    return bn_act_bwd_impl<float>((const float*)dz, (const float*)y, (float*)dy, nullptr, M, C, saved, gamma, beta, act, slope, dgamma, dbeta,
-                                  accumulate, ws, ws_bytes, stream);
+    const BnGroup G = bn_bwd_one(dz, y, dy, nullptr, saved, gamma, beta, dgamma, dbeta, ws);
+    if (io_bf16) return bn_act_bwd_impl<__bf16>(1, 1, G, M, C, act, slope, accumulate, ws_bytes, stream);
+    return bn_act_bwd_impl<float>(1, 1, G, M, C, act, slope, accumulate, ws_bytes, stream);
 }
 
-extern "C" int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t stream) {
-    DG_CHECK_ARG(x && y, "dg_act_fwd: null pointer");
+extern "C" int dg_act_fwd_g(int groups, const float* const* x, float* const* y, size_t n, int act, float slope, dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && x && y, "dg_act_fwd: bad group / null table");
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(x[i] && y[i], "dg_act_fwd: null pointer");
     DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_fwd: bad act %d", act);
     if (n == 0) return DG_OK;
     const long total4 = (long)((n + 3) / 4);
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, (long)n, act, slope);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(total4), groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs((const void* const*)x, groups),
+                       dg_ptrs((const void* const*)y, groups), total4, (long)n, act, slope);
     DG_CHECK_LAUNCH("act_fwd");
     return DG_OK;
 }
-extern "C" int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, dg_stream_t stream) {
-    DG_CHECK_ARG(dy && out && dx, "dg_act_bwd: null pointer");
+extern "C" int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t stream) {
+    return dg_act_fwd_g(1, &x, &y, n, act, slope, stream);
+}
+extern "C" int dg_act_bwd_g(int groups, const float* const* dy, const float* const* out, float* const* dx, size_t n, int act, float slope,
+                            dg_stream_t stream) {
+    DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && dy && out && dx, "dg_act_bwd: bad group / null table");
+    for (int i = 0; i < groups; ++i) DG_CHECK_ARG(dy[i] && out[i] && dx[i], "dg_act_bwd: null pointer");
     DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_bwd: bad act %d", act);
     if (n == 0) return DG_OK;
     const long total4 = (long)((n + 3) / 4);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, total4, (long)n, act, slope);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(total4), groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs((const void* const*)dy, groups),
+                       dg_ptrs((const void* const*)out, groups), dg_ptrs((const void* const*)dx, groups), total4, (long)n, act, slope);
     DG_CHECK_LAUNCH("act_bwd");
     return DG_OK;
+}
+extern "C" int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, dg_stream_t stream) {
+    return dg_act_bwd_g(1, &dy, &out, &dx, n, act, slope, stream);
 }
 extern "C" int dg_act_bwd_t(const void* dy, const void* out, void* dx, int io_bf16, size_t n, int act, float slope, dg_stream_t stream) {
     if (!io_bf16) return dg_act_bwd((const float*)dy, (const float*)out, (float*)dx, n, act, slope, stream);

@@ -13,6 +13,62 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+PREC_DEFAULT, PREC_F32, PREC_BF16, PREC_F32X3 = -1, 0, 1, 2      # include/discogan_hip.h DG_PREC_*
+
+
+class Context:
+    """The arithmetic and operand-form settings ONE caller (a trainer, a test) runs its ops under -- a per-caller object instead
+    of process-wide switches ("dtype enum" per call, "no global mutable state").
+
+      prec    arithmetic of the conv products, passed to the C ABI with EVERY call (DG_PREC_F32 | _BF16 | _F32X3); None = the
+              library's process default (dg_set_option("bf16"): tools and op tests that flip it around single calls)
+      shadow  bf16 path: conv kernels read bf16 shadows written by the producers (see "bf16 shadow operands" below)
+      act16   bf16 path: feature maps and their gradients exist only as bf16
+      x3      f32x3 path: conv kernels read plane triples written once per tensor
+      shadow_tab / plane_tab: the derived copies of this caller's live activations
+
+    ``with ops.use(ctx):`` makes it the ambient context of the forward calls issued inside; every autograd Function remembers the
+    context of its forward and runs its backward under it (functional._fwd / _bwd), so two trainers with different arithmetic can be
+    interleaved call by call in one process."""
+
+    def __init__(self, prec=None, shadow=False, act16=False, x3=False):
+        self.prec = prec
+        self.shadow, self.act16, self.x3 = bool(shadow), bool(act16), bool(x3)
+        self.shadow_tab, self.plane_tab = {}, {}
+
+    @property
+    def cprec(self):
+        return PREC_DEFAULT if self.prec is None else int(self.prec)
+
+    def clear(self):
+        self.shadow_tab.clear()
+        self.plane_tab.clear()
+
+
+_AMBIENT = Context()          # what module-level ops.SHADOW / ops.ACT16 / ops.X3 read and write outside any ``use`` block
+_CUR = _AMBIENT
+
+
+def current():
+    return _CUR
+
+
+class use:
+    """Context manager: run the ops issued inside under ``ctx``."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        global _CUR
+        self.prev = _CUR
+        _CUR = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global _CUR
+        _CUR = self.prev
+        return False
 
 # bench.py's roofline leg sets this to a list: every launch of the MFMA implicit-GEMM family then
 # appends (op, algorithmic FLOPs, start event, end event), recorded on the launch stream.
@@ -102,6 +158,14 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _tab(ts):
+    """Pointer table of a grouped C-ABI call: one device pointer per problem (None entries allowed)."""
+    import ctypes as C
+    if ts is None:
+        return None
+    return (C.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
 def _check_dev(*ts, allow16=False, planes_ok=False):
     """fp32 HIP tensors only.  allow16: the wrapper dispatches on the storage type itself (bf16 activation storage: the
     ``*_t`` / ``*_mixed`` entry points); every other wrapper calls an fp32-only kernel with numel() elements, where a bf16
@@ -128,15 +192,12 @@ def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
 # bf16 ACTIVATION STORAGE (DiscoGANTrainer(mfma_dtype="bf16", act_dtype="bf16")): with ACT16 on, every feature map and
 # feature-map gradient an op produces is a bf16 tensor (channel counts that are multiples of 8; the [N,100] bottleneck and
 # everything image-shaped stay fp32), and the ops take bf16 tensors as they come -- there is no fp32 copy to shadow.
-ACT16 = False
-
-
 def _is16(t):
     return t is not None and t.dtype == torch.bfloat16
 
 
 def _act_dtype(channels):
-    return torch.bfloat16 if (ACT16 and channels % 8 == 0) else torch.float32
+    return torch.bfloat16 if (_CUR.act16 and channels % 8 == 0) else torch.float32
 
 
 def is_nhwc(x):
@@ -211,16 +272,12 @@ def _ws(nbytes, device):
 #   weights    : ``param._dg_bf16`` (a view of optim.Adam's flat bf16 buffer), valid while ``param._version`` is unchanged
 #   activations: side table keyed by the fp32 tensor's storage address; the entry holds the fp32 tensor, so the address
 #                cannot be recycled while the entry lives; the trainer clears the table every iteration.
-SHADOW = False
-_SHADOW_TAB = {}
-
-
 def shadow_clear():
-    _SHADOW_TAB.clear()
+    _CUR.shadow_tab.clear()
 
 
 def shadow_put(t, t16):
-    _SHADOW_TAB[t.data_ptr()] = (t, t16)
+    _CUR.shadow_tab[t.data_ptr()] = (t, t16)
 
 
 def derived_release(*tensors):
@@ -231,16 +288,16 @@ def derived_release(*tensors):
         if t is None:
             continue
         key = t.data_ptr()
-        for tab in (_SHADOW_TAB, _PLANE_TAB):
+        for tab in (_CUR.shadow_tab, _CUR.plane_tab):
             e = tab.get(key)
             if e is not None and e[0].shape == t.shape:
                 del tab[key]
 
 
 def shadow_get(t):
-    if not SHADOW:
+    if not _CUR.shadow:
         return None
-    e = _SHADOW_TAB.get(t.data_ptr())
+    e = _CUR.shadow_tab.get(t.data_ptr())
     if e is None or e[0].shape != t.shape or e[0].stride() != t.stride():
         return None
     return e[1]
@@ -248,7 +305,7 @@ def shadow_get(t):
 
 def weight_shadow(w):
     """bf16 shadow of a conv weight Parameter (None when shadows are off or the parameter is not in a flat Adam group)."""
-    if not SHADOW:
+    if not _CUR.shadow:
         return None
     w16 = getattr(w, "_dg_bf16", None)
     if w16 is None:
@@ -271,7 +328,7 @@ def empty_nhwc_bf16(n, c, h, w, device):
 
 
 def _bf16_ok(op, n, h, wd, c, k, stride, pad):
-    return SHADOW and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) >= 1
+    return _CUR.shadow and _lib.load().dg_conv_bf16_operands_ok(op, n, h, wd, c, k, stride, pad) >= 1
 
 
 # ---- f32x3 plane operands (mfma_dtype="f32x3") -----------------------------------------------------------------
@@ -282,7 +339,6 @@ def _bf16_ok(op, n, h, wd, c, k, stride, pad):
 #                valid while ``param._version`` is unchanged (a foreign write re-splits the one weight)
 #   activations: side table like the bf16 shadows; filled by the producers (BatchNorm kernels) or, for a tensor nobody has
 #                split yet, by dg_f32_to_bf16x3 at its first use (the triple then serves the forward AND the weight gradient)
-X3 = False
 # X3_CM: the BatchNorm kernels write the plane triples that a WINDOW input-grad kernel will read (dy of the conv layers with
 # <= 128 input channels, the input of the transposed convs with <= 128 output channels) in the QUAD-CHUNK layout
 # ([pixels/4][C/16][4][16], include/discogan_hip.h "plane_layout"): the window kernel then uses every byte of the 128-byte lines
@@ -327,15 +383,14 @@ X3_RSP = __import__("os").environ.get("DG_X3_RSP", "0") == "1"
 
 def _plane_code_ok(code):
     return code in (1, 2) or (code == 3 and (X3_FWW or X3_RSP)) or (code == 4 and X3_RSP)
-_PLANE_TAB = {}
 
 
 def planes_clear():
-    _PLANE_TAB.clear()
+    _CUR.plane_tab.clear()
 
 
 def planes_put(t, t3, cm=False):
-    _PLANE_TAB[t.data_ptr()] = (t, t3, bool(cm))
+    _CUR.plane_tab[t.data_ptr()] = (t, t3, bool(cm))
 
 
 def f32_to_bf16x3(x, out3):
@@ -349,7 +404,7 @@ def planes_of(t, allow_cm=False):
     """(plane-0 address, plane distance in bytes, chunk-major?) of an fp32 activation / gradient tensor; splits it on first
     use.  A chunk-major triple (written by a BatchNorm kernel for a window input-grad kernel) is only handed to callers that
     can read it (allow_cm); anybody else gets a pixel-major split of the fp32 tensor."""
-    e = _PLANE_TAB.get(t.data_ptr())
+    e = _CUR.plane_tab.get(t.data_ptr())
     if e is None or e[0].shape != t.shape or e[0].stride() != t.stride() or (e[2] and not allow_cm):
         if getattr(t, "_dg_planes_only", False):
             raise _lib.DiscoganHipError("plane-only tensor without a usable plane triple (released, or in a layout this reader cannot take)")
@@ -366,7 +421,7 @@ def x3_all_plane_readers(n, h, wd, c, k, forward_is_dgrad=False, need_wgrad=True
     """Are the conv kernels that will READ a tensor all plane kernels?  For a layer input x of Conv2d(c, k, 4, 2, 1) on [n, c, h, wd]:
     its forward (op 0) and weight-grad (op 2); with forward_is_dgrad (ConvTranspose2d: the same geometry read as an input-grad): op 1
     and op 2.  For a gradient dy: the layer's input-grad (op 1) and weight-grad -- the same question with forward_is_dgrad."""
-    if not (X3 and X3_PLANES_ONLY):
+    if not (_CUR.x3 and X3_PLANES_ONLY):
         return False
     L = _lib.load()
     first = 1 if forward_is_dgrad else 0
@@ -377,7 +432,7 @@ def x3_window_dgrad(n, h, wd, c, k):
     """Will the input-grad of Conv2d(c, k, 4, 2, 1) on an [n, c, h, wd] input (= the forward of the transposed conv with the same
     weight) run on the window kernel AND its weight gradient on the plane kernel?  Then the producer of the gradient operand
     writes chunk-major planes (X3_CM)."""
-    if not (X3 and X3_CM) or k % 64 != 0:
+    if not (_CUR.x3 and X3_CM) or k % 64 != 0:
         return False
     L = _lib.load()
     return L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, 2, 1) == 2 and L.dg_conv_x3_planes_ok(2, n, h, wd, c, k, 2, 1) == 1
@@ -421,7 +476,7 @@ def weight_planes(w, transposed=False):
 
 
 def _x3_ok(op, n, h, wd, c, k, stride, pad):
-    return X3 and k > 1 and _plane_code_ok(_lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad))
+    return _CUR.x3 and k > 1 and _plane_code_ok(_lib.load().dg_conv_x3_planes_ok(op, n, h, wd, c, k, stride, pad))
 
 
 # ---- interior convolutions ------------------------------------------------------------------------------
@@ -448,11 +503,12 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     k = w.shape[0]
     ho, wo = _out_hw(h, wd, stride, pad)
     L = _lib.load()
-    ws, wsb = _ws(L.dg_conv_workspace_bytes(0, n, h, wd, c, k, stride, pad), x.device)
-    rows = L.dg_conv_bnstats_rows(0, n, h, wd, c, k, stride, pad) if want_stats else 0
-    if want_stats == "split" and L.dg_conv_plan_splits(0, n, h, wd, c, k, stride, pad) <= 1:
+    prec = _CUR.cprec
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec), x.device)
+    rows = L.dg_conv_bnstats_rows_p(0, n, h, wd, c, k, stride, pad, prec) if want_stats else 0
+    if want_stats == "split" and L.dg_conv_plan_splits_p(0, n, h, wd, c, k, stride, pad, prec) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
-    code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (X3 and k > 1) else 0
+    code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (_CUR.x3 and k > 1) else 0
     if _plane_code_ok(code):
         wp, wdist, wt = weight_planes(w, transposed=True)
         if code == 4 or (code == 3 and not (wt and X3_FWW)):
@@ -490,14 +546,10 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
             _lib.check(L.dg_conv_fwd_mixed(_ptr(xa), x16, _ptr(wa), w16, _ptr(y), o16, n, h, wd, c, k,
                                            stride, pad, _ptr(stat), stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()),
                        "dg_conv_fwd_mixed")
-        elif rows > 0:
-            stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32)
-            _lib.check(L.dg_conv_fwd_bnstats(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, _ptr(stat), stat.numel(),
-                                             _ptr(ws), wsb, _stream()), "dg_conv_fwd_bnstats")
-        else:
-            stat = None
-            _lib.check(L.dg_conv_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, k, stride, pad, _ptr(ws), wsb, _stream()),
-                       "dg_conv_fwd")
+        else:       # the fp32-tensor form: arithmetic = this context's, passed with the call
+            stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32) if rows > 0 else None
+            _lib.check(L.dg_conv_fwd_g(1, _tab([x]), _tab([w]), _tab([y]), n, h, wd, c, k, stride, pad, prec, _tab([stat]) if rows > 0 else None,
+                                       stat.numel() if rows > 0 else 0, _tab([ws]), wsb, _stream()), "dg_conv_fwd_g")
     return (y, stat) if want_stats else y
 
 
@@ -512,9 +564,10 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     c = w.shape[1]
     h, wd = x_hw
     L = _lib.load()
-    ws, wsb = _ws(L.dg_conv_workspace_bytes(1, n, h, wd, c, k, stride, pad), dy.device)
-    rows = L.dg_conv_bnstats_rows(1, n, h, wd, c, k, stride, pad) if want_stats else 0
-    if want_stats == "split" and L.dg_conv_plan_splits(1, n, h, wd, c, k, stride, pad) <= 1:
+    prec = _CUR.cprec
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec), dy.device)
+    rows = L.dg_conv_bnstats_rows_p(1, n, h, wd, c, k, stride, pad, prec) if want_stats else 0
+    if want_stats == "split" and L.dg_conv_plan_splits_p(1, n, h, wd, c, k, stride, pad, prec) <= 1:
         rows = 0
     if _x3_ok(1, n, h, wd, c, k, stride, pad):
         dp, dd, dcm = planes_of(dy, allow_cm=L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, stride, pad) == 2)
@@ -550,14 +603,10 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
             _lib.check(L.dg_conv_dgrad_mixed(_ptr(da), d16, _ptr(wa), w16, _ptr(dx), o16, n, h, wd, c, k,
                                              stride, pad, _ptr(stat), stat.numel() if stat is not None else 0, _ptr(ws), wsb, _stream()),
                        "dg_conv_dgrad_mixed")
-        elif rows > 0:
-            stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32)
-            _lib.check(L.dg_conv_dgrad_bnstats(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, _ptr(stat), stat.numel(),
-                                               _ptr(ws), wsb, _stream()), "dg_conv_dgrad_bnstats")
         else:
-            stat = None
-            _lib.check(L.dg_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, k, stride, pad, _ptr(ws), wsb,
-                                       _stream()), "dg_conv_dgrad")
+            stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32) if rows > 0 else None
+            _lib.check(L.dg_conv_dgrad_g(1, _tab([dy]), _tab([w]), _tab([dx]), n, h, wd, c, k, stride, pad, prec, _tab([stat]) if rows > 0 else None,
+                                         stat.numel() if rows > 0 else 0, _tab([ws]), wsb, _stream()), "dg_conv_dgrad_g")
     return (dx, stat) if want_stats else dx
 
 
@@ -600,7 +649,8 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     k = dy.shape[1]
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
-    ws, wsb = _ws(L.dg_conv_workspace_bytes(2, n, h, wd, c, k, stride, pad), x.device)
+    prec = _CUR.cprec
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec), x.device)
     if _x3_ok(2, n, h, wd, c, k, stride, pad):
         dp, dd, dcm = planes_of(dy, allow_cm=True)
         xp, xd, _ = planes_of(x)
@@ -624,8 +674,8 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
             _lib.check(L.dg_conv_wgrad_mixed(_ptr(da), d16, _ptr(xa), x16, _ptr(dw), n, h, wd, c, k,
                                              stride, pad, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv_wgrad_mixed")
         else:
-            _lib.check(L.dg_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, c, k, stride, pad, int(accumulate),
-                                       _ptr(ws), wsb, _stream()), "dg_conv_wgrad")
+            _lib.check(L.dg_conv_wgrad_g(1, 1, _tab([dy]), _tab([x]), _tab([dw]), n, h, wd, c, k, stride, pad, prec, int(accumulate),
+                                         _tab([ws]), wsb, _stream()), "dg_conv_wgrad_g")
     return dw
 
 
@@ -638,7 +688,7 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2, want_planes=False):
     w = w.contiguous()
     n, _, h, wd = x.shape
     k = w.shape[0]
-    if want_planes and X3 and k == 64 and x.numel() * 4 < (1 << 30) and n * (h // 2) * (wd // 2) < (1 << 30):
+    if want_planes and _CUR.x3 and k == 64 and x.numel() * 4 < (1 << 30) and n * (h // 2) * (wd // 2) < (1 << 30):
         y = empty_nhwc(n, k, h // 2, wd // 2, x.device)
         y3 = torch.empty((3, y.numel()), device=x.device, dtype=torch.bfloat16)
         with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), _hbm("edge_c3_fwd", 4.0 * x.numel() + 10.0 * y.numel()):
@@ -646,17 +696,13 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2, want_planes=False):
                        "dg_conv4x4s2_c3_fwd_x3")
         planes_put(y, y3)
         return y
-    o16 = ACT16 and k == 64 and x.numel() * 4 < (1 << 30)
+    o16 = _CUR.act16 and k == 64 and x.numel() * 4 < (1 << 30)
     y = empty_nhwc(n, k, h // 2, wd // 2, x.device, torch.bfloat16 if o16 else torch.float32)
     with _prof("c3_fwd", 2.0 * n * (h // 2) * (wd // 2) * k * 48), \
             _hbm("edge_c3_fwd", 4.0 * x.numel() + y.numel() * y.element_size()):
-        if o16:
-            _lib.check(_lib.load().dg_conv4x4s2_c3_fwd_t(_ptr(x), _ptr(w), _ptr(y), 1, n, h, wd, k, act, slope, _stream()),
-                       "dg_conv4x4s2_c3_fwd_t")
-        else:
-            _lib.check(_lib.load().dg_conv4x4s2_c3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, k, act, slope, _stream()),
-                       "dg_conv4x4s2_c3_fwd")
-    if SHADOW and not o16 and k % 8 == 0:
+        _lib.check(_lib.load().dg_conv4x4s2_c3_fwd_p(_ptr(x), _ptr(w), _ptr(y), int(o16), n, h, wd, k, act, slope, _CUR.cprec, _stream()),
+                   "dg_conv4x4s2_c3_fwd_p")
+    if _CUR.shadow and not o16 and k % 8 == 0:
         shadow_put(y, f32_to_bf16(y, empty_nhwc_bf16(n, k, h // 2, wd // 2, x.device)))
     return y
 
@@ -672,12 +718,8 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_dgrad_workspace_bytes(k), dy.device)
     with _hbm("edge_c3_dgrad", dy.numel() * dy.element_size() + 4.0 * dx.numel()):
-        if _is16(dy):
-            _lib.check(L.dg_conv4x4s2_c3_dgrad_t(_ptr(dy), 1, _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
-                                                 _stream()), "dg_conv4x4s2_c3_dgrad_t")
-        else:
-            _lib.check(L.dg_conv4x4s2_c3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _ptr(ws), wsb,
-                                               _stream()), "dg_conv4x4s2_c3_dgrad")
+        _lib.check(L.dg_conv4x4s2_c3_dgrad_p(_ptr(dy), int(_is16(dy)), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _CUR.cprec, _ptr(ws), wsb,
+                                             _stream()), "dg_conv4x4s2_c3_dgrad_p")
     return dx
 
 
@@ -700,17 +742,17 @@ def c3_wgrad(dy, x_nchw, out=None, accumulate=False, act_out=None, act=ACT_NONE,
         assert ao.shape == dy.shape and ao.dtype == dy.dtype
     if _is16(dy):
         with _hbm("edge_c3_wgrad", 2.0 * ((2 if fuse else 1) * dy.numel()) + 4.0 * x.numel()):
-            _lib.check(L.dg_conv4x4s2_c3_wgrad_t(_ptr(dy), _ptr(ao), 1, act if fuse else ACT_NONE, float(slope), _ptr(x), _ptr(dw),
-                                                 n, h, wd, k, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_t")
+            _lib.check(L.dg_conv4x4s2_c3_wgrad_p(_ptr(dy), _ptr(ao), 1, act if fuse else ACT_NONE, float(slope), _ptr(x), _ptr(dw),
+                                                 n, h, wd, k, _CUR.cprec, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_p")
         return dw
     if fuse:
         with _hbm("edge_c3_wgrad", 4.0 * (2 * dy.numel() + x.numel())):
-            _lib.check(L.dg_conv4x4s2_c3_wgrad_act(_ptr(dy), _ptr(ao), act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k,
-                                                   int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_act")
+            _lib.check(L.dg_conv4x4s2_c3_wgrad_p(_ptr(dy), _ptr(ao), 0, act, float(slope), _ptr(x), _ptr(dw), n, h, wd, k, _CUR.cprec,
+                                                 int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_p")
         return dw
     with _hbm("edge_c3_wgrad", 4.0 * (dy.numel() + x.numel())):
-        _lib.check(L.dg_conv4x4s2_c3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, h, wd, k, int(accumulate), _ptr(ws), wsb,
-                                           _stream()), "dg_conv4x4s2_c3_wgrad")
+        _lib.check(L.dg_conv4x4s2_c3_wgrad_p(_ptr(dy), None, 0, ACT_NONE, 0.0, _ptr(x), _ptr(dw), n, h, wd, k, _CUR.cprec, int(accumulate), _ptr(ws), wsb,
+                                             _stream()), "dg_conv4x4s2_c3_wgrad_p")
     return dw
 
 
@@ -758,7 +800,7 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False, planes_on
                                                    act, slope, _stream()), "dg_bn_act_fwd_t")
         return z
     z = empty_nhwc(n, c, h, w, y.device)
-    if X3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
+    if _CUR.x3 and c % 8 == 0:             # f32x3 path: the next conv (forward and weight gradient) reads z as a plane triple
         z3 = torch.empty((3, z.numel()), device=y.device, dtype=torch.bfloat16)
         with _hbm("bn_apply", (10.0 if (planes_only and X3_PLANES_ONLY) else 14.0) * n * h * w * c):
             cm = int(bool(planes_cm) and c % 64 == 0 and (n * h * w) % 4 == 0)
@@ -769,7 +811,7 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False, planes_on
         if po:
             z._dg_planes_only = True
         return z
-    if SHADOW and c % 8 == 0:
+    if _CUR.shadow and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
         with _hbm("bn_apply", 10.0 * n * h * w * c):
             _lib.check(_lib.load().dg_bn_act_fwd_bf16(_ptr(y), _ptr(z), _ptr(z16), n * h * w, c, _ptr(saved), _ptr(gamma), _ptr(beta),
@@ -808,7 +850,7 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
                                          slope, _ptr(dgamma), _ptr(dbeta), acc, _ptr(ws), wsb, _stream()), "dg_bn_act_bwd_t")
         return dy, dgamma, dbeta
     dy = empty_nhwc(n, c, h, w, y.device)
-    if X3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
+    if _CUR.x3 and c % 8 == 0:             # f32x3 path: dy goes to the layer's input-gradient and weight-gradient convs as a plane triple
         dy3 = torch.empty((3, dy.numel()), device=y.device, dtype=torch.bfloat16)
         po = bool(planes_only) and X3_PLANES_ONLY
         with _hbm("bn_backward", (22.0 if po else 26.0) * m * c):
@@ -819,7 +861,7 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
         if po:
             dy._dg_planes_only = True
         return dy, dgamma, dbeta
-    if SHADOW and c % 8 == 0:
+    if _CUR.shadow and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)
         with _hbm("bn_backward", 22.0 * m * c):
             _lib.check(L.dg_bn_act_bwd_bf16(_ptr(dz), _ptr(y), _ptr(dy), _ptr(dy16), m, c, _ptr(saved), _ptr(gamma), _ptr(beta), act,
@@ -1003,3 +1045,309 @@ def adam_step_flat(p, g, m, v, state, beta1, beta2, eps, weight_decay, grad_scal
         _lib.check(_lib.load().dg_adam_step_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1,
                                                  beta2,
                                                  eps, weight_decay, grad_scale, _stream()), "dg_adam_step_flat")
+
+
+# ---- grouped launches (round 4) -------------------------------------------------------------------------------------------
+# The reference issues the passes of an iteration in independent pairs of identical shape -- G_B(A) | G_A(B), G_A(AB) | G_B(BA),
+# D_A(A) | D_B(B), D_A(BA) | D_B(AB) (image_translation.py:342-361) -- and each discriminator sees real and fake images with the same
+# weights (:353-354,360-361).  The *_g wrappers take one tensor per problem (lists) and issue ONE launch per kernel for all of them
+# (dg_*_g: a block index picks the problem); every problem's result is bitwise what the one-problem wrapper computes.  fp32 tensors on
+# the exact-fp32 and the register-staged f32x3 arithmetic only: no shadows, no plane triples, no bf16 storage, no fused statistics.
+def group_ok():
+    """May the current context run grouped launches?"""
+    return not (_CUR.shadow or _CUR.act16 or _CUR.x3)
+
+
+def _same_shape(ts, who):
+    for t in ts[1:]:
+        if t.shape != ts[0].shape:
+            raise _lib.DiscoganHipError(f"{who}: the problems of a grouped launch must have identical shapes")
+
+
+def _ws_g(nbytes, g, device):
+    """One workspace per problem (slices of ONE allocation): (list of tensors or Nones, bytes each)."""
+    if nbytes == 0:
+        return [None] * g, 0
+    per = (nbytes + 255) // 256 * 64                    # floats per problem, 256-byte aligned
+    t = torch.empty(g * per, device=device, dtype=torch.float32)
+    return [t[i * per:(i + 1) * per] for i in range(g)], per * 4
+
+
+def _share_of(params):
+    """Consecutive problems that name the SAME parameter (a discriminator's real and fake pass) accumulate into one gradient tensor:
+    returns the run length when every run has the same length, else raises."""
+    g = len(params)
+    run = 1
+    while run < g and params[run] is params[0]:
+        run += 1
+    if g % run != 0 or any(params[i] is not params[i // run * run] for i in range(g)) or \
+            any(params[i] is params[i - run] for i in range(run, g, run)):
+        raise _lib.DiscoganHipError("grouped launch: problems sharing a parameter must form runs of equal length")
+    return run
+
+
+def conv_fwd_g(xs, ws_, stride, pad):
+    """Conv2d forward of ``len(xs)`` problems in one launch (plus one split-K reduction launch)."""
+    g = len(xs)
+    _check_dev(*xs, *ws_)
+    xs = [as_nhwc(x) for x in xs]
+    ws_ = [_krsc(w) for w in ws_]
+    _same_shape(xs, "conv_fwd_g")
+    _same_shape(ws_, "conv_fwd_g")
+    n, c, h, wd = xs[0].shape
+    k = ws_[0].shape[0]
+    ho, wo = _out_hw(h, wd, stride, pad)
+    L = _lib.load()
+    prec = _CUR.cprec
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec), g, xs[0].device)
+    ys = [empty_nhwc(n, k, ho, wo, xs[0].device) for _ in range(g)]
+    with _prof("conv_fwd" if k > 1 else "head1", 2.0 * g * n * ho * wo * k * c * 16):
+        _lib.check(L.dg_conv_fwd_g(g, _tab(xs), _tab(ws_), _tab(ys), n, h, wd, c, k, stride, pad, prec, None, 0, _tab(wsl), wsb, _stream()),
+                   "dg_conv_fwd_g")
+    return ys
+
+
+def conv_dgrad_g(dys, ws_, x_hw, stride, pad):
+    g = len(dys)
+    _check_dev(*dys, *ws_)
+    dys = [as_nhwc(d) for d in dys]
+    ws_ = [_krsc(w) for w in ws_]
+    _same_shape(dys, "conv_dgrad_g")
+    _same_shape(ws_, "conv_dgrad_g")
+    n, k = dys[0].shape[0], dys[0].shape[1]
+    c = ws_[0].shape[1]
+    h, wd = x_hw
+    L = _lib.load()
+    prec = _CUR.cprec
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec), g, dys[0].device)
+    dxs = [empty_nhwc(n, c, h, wd, dys[0].device) for _ in range(g)]
+    with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * g * n * dys[0].shape[2] * dys[0].shape[3] * k * c * 16):
+        _lib.check(L.dg_conv_dgrad_g(g, _tab(dys), _tab(ws_), _tab(dxs), n, h, wd, c, k, stride, pad, prec, None, 0, _tab(wsl), wsb, _stream()),
+                   "dg_conv_dgrad_g")
+    return dxs
+
+
+def conv_wgrad_g(dys, xs, stride, pad, outs, accumulate, share=1):
+    """Weight gradients of ``len(dys)`` problems into ``outs`` (accumulating views of the flat gradient buffer).  share > 1: every
+    ``share`` consecutive problems name the same ``outs`` tensor and are summed into it in problem order."""
+    g = len(dys)
+    _check_dev(*dys, *xs)
+    dys = [as_nhwc(d) for d in dys]
+    xs = [as_nhwc(x) for x in xs]
+    _same_shape(dys, "conv_wgrad_g")
+    _same_shape(xs, "conv_wgrad_g")
+    n, c, h, wd = xs[0].shape
+    k = dys[0].shape[1]
+    L = _lib.load()
+    prec = _CUR.cprec
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec), g, xs[0].device)
+    with _prof("conv_wgrad" if k > 1 else "head1", 2.0 * g * n * dys[0].shape[2] * dys[0].shape[3] * k * c * 16):
+        _lib.check(L.dg_conv_wgrad_g(g, int(share), _tab(dys), _tab(xs), _tab(outs), n, h, wd, c, k, stride, pad, prec, int(accumulate),
+                                     _tab(wsl), wsb, _stream()), "dg_conv_wgrad_g")
+
+
+def c3_fwd_g(xs, ws_, act=ACT_NONE, slope=0.2):
+    g = len(xs)
+    _check_dev(*xs, *ws_)
+    xs = [x.contiguous() for x in xs]
+    ws_ = [w.contiguous() for w in ws_]
+    _same_shape(xs, "c3_fwd_g")
+    n, _, h, wd = xs[0].shape
+    k = ws_[0].shape[0]
+    ys = [empty_nhwc(n, k, h // 2, wd // 2, xs[0].device) for _ in range(g)]
+    with _prof("c3_fwd", 2.0 * g * n * (h // 2) * (wd // 2) * k * 48), _hbm("edge_c3_fwd", g * (4.0 * xs[0].numel() + 4.0 * ys[0].numel())):
+        _lib.check(_lib.load().dg_conv4x4s2_c3_fwd_g(g, _tab(xs), _tab(ws_), _tab(ys), n, h, wd, k, act, slope, _CUR.cprec, _stream()),
+                   "dg_conv4x4s2_c3_fwd_g")
+    return ys
+
+
+def c3_dgrad_g(dys, ws_, act=ACT_NONE):
+    g = len(dys)
+    _check_dev(*dys, *ws_)
+    dys = [as_nhwc(d) for d in dys]
+    ws_ = [w.contiguous() for w in ws_]
+    _same_shape(dys, "c3_dgrad_g")
+    n, k, ho, wo = dys[0].shape
+    dxs = [torch.empty((n, 3, 2 * ho, 2 * wo), device=dys[0].device, dtype=torch.float32) for _ in range(g)]
+    with _hbm("edge_c3_dgrad", g * (4.0 * dys[0].numel() + 4.0 * dxs[0].numel())):
+        _lib.check(_lib.load().dg_conv4x4s2_c3_dgrad_g(g, _tab(dys), _tab(ws_), _tab(dxs), n, 2 * ho, 2 * wo, k, act, _CUR.cprec, _stream()),
+                   "dg_conv4x4s2_c3_dgrad_g")
+    return dxs
+
+
+def c3_wgrad_g(dys, xs, outs, accumulate, act_outs=None, act=ACT_NONE, slope=0.0, share=1):
+    g = len(dys)
+    _check_dev(*dys, *xs)
+    dys = [as_nhwc(d) for d in dys]
+    xs = [x.contiguous() for x in xs]
+    _same_shape(dys, "c3_wgrad_g")
+    n, k, ho, wo = dys[0].shape
+    h, wd = xs[0].shape[2], xs[0].shape[3]
+    fuse = act_outs is not None and act != ACT_NONE
+    aos = [as_nhwc(a) for a in act_outs] if fuse else None
+    L = _lib.load()
+    wsl, wsb = _ws_g(L.dg_c3_wgrad_workspace_bytes(n, h, wd, k), g, dys[0].device)
+    with _hbm("edge_c3_wgrad", g * 4.0 * ((2 if fuse else 1) * dys[0].numel() + xs[0].numel())):
+        _lib.check(L.dg_conv4x4s2_c3_wgrad_g(g, int(share), _tab(dys), _tab(aos), act if fuse else ACT_NONE, float(slope), _tab(xs), _tab(outs),
+                                             n, h, wd, k, _CUR.cprec, int(accumulate), _tab(wsl), wsb, _stream()), "dg_conv4x4s2_c3_wgrad_g")
+
+
+def bn_train_stats_g(ys, running_means, running_vars, nbts, eps, momentum, share=1):
+    g = len(ys)
+    _check_dev(*ys)
+    ys = [as_nhwc(y) for y in ys]
+    _same_shape(ys, "bn_train_stats_g")
+    n, c, h, w = ys[0].shape
+    m = n * h * w
+    saved = [torch.empty((2, c), device=ys[0].device, dtype=torch.float32) for _ in range(g)]
+    L = _lib.load()
+    wsl, wsb = _ws_g(L.dg_bn_workspace_bytes(m, c), g, ys[0].device)
+    with _hbm("bn_stats", 4.0 * g * m * c):
+        _lib.check(L.dg_bn_train_stats_g(g, int(share), _tab(ys), m, c, eps, momentum, _tab(running_means), _tab(running_vars), _tab(nbts),
+                                         _tab(saved), _tab(wsl), wsb, _stream()), "dg_bn_train_stats_g")
+    return saved
+
+
+def bn_act_fwd_g(ys, saveds, gammas, betas, act, slope=0.2):
+    g = len(ys)
+    _check_dev(*ys)
+    ys = [as_nhwc(y) for y in ys]
+    n, c, h, w = ys[0].shape
+    zs = [empty_nhwc(n, c, h, w, ys[0].device) for _ in range(g)]
+    with _hbm("bn_apply", 8.0 * g * n * h * w * c):
+        _lib.check(_lib.load().dg_bn_act_fwd_g(g, _tab(ys), _tab(zs), n * h * w, c, _tab(saveds), _tab(gammas), _tab(betas), act, slope, _stream()),
+                   "dg_bn_act_fwd_g")
+    return zs
+
+
+def bn_act_bwd_g(dzs, ys, saveds, gammas, betas, act, slope, dgammas, dbetas, accumulate, share=1):
+    """dgammas / dbetas: accumulating views of the flat gradient buffer, or None (parameters frozen)."""
+    g = len(dzs)
+    _check_dev(*dzs, *ys)
+    dzs = [as_nhwc(d) for d in dzs]
+    ys = [as_nhwc(y) for y in ys]
+    _same_shape(dzs, "bn_act_bwd_g")
+    n, c, h, w = ys[0].shape
+    m = n * h * w
+    dys = [empty_nhwc(n, c, h, w, ys[0].device) for _ in range(g)]
+    L = _lib.load()
+    wsl, wsb = _ws_g(L.dg_bn_workspace_bytes(m, c), g, ys[0].device)
+    with _hbm("bn_backward", 20.0 * g * m * c):
+        _lib.check(L.dg_bn_act_bwd_g(g, int(share), _tab(dzs), _tab(ys), _tab(dys), m, c, _tab(saveds), _tab(gammas), _tab(betas), act, slope,
+                                     _tab(dgammas), _tab(dbetas), int(accumulate), _tab(wsl), wsb, _stream()), "dg_bn_act_bwd_g")
+    return dys
+
+
+def act_fwd_g(xs, act, slope=0.2):
+    _check_dev(*xs)
+    xs = [_dense(x) for x in xs]
+    ys = [_dense_like(x) for x in xs]
+    _lib.check(_lib.load().dg_act_fwd_g(len(xs), _tab(xs), _tab(ys), xs[0].numel(), act, slope, _stream()), "dg_act_fwd_g")
+    return ys
+
+
+def act_bwd_g(dys, outs, act, slope=0.2):
+    _check_dev(*dys, *outs)
+    outs = [_dense(o) for o in outs]
+    dys = list(dys)
+    for i, (d, o) in enumerate(zip(dys, outs)):
+        if d.stride() != o.stride():
+            dl = _dense_like(o)
+            dl.copy_(d)
+            dys[i] = dl
+    dxs = [_dense_like(o) for o in outs]
+    _lib.check(_lib.load().dg_act_bwd_g(len(outs), _tab(dys), _tab(outs), _tab(dxs), outs[0].numel(), act, slope, _stream()), "dg_act_bwd_g")
+    return dxs
+
+
+def mse_fwd_g(xs, ts, outs):
+    g = len(xs)
+    _check_dev(*xs, *ts)
+    pairs = [same_layout_pair(x, t) for x, t in zip(xs, ts)]
+    xs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    L = _lib.load()
+    wsl, wsb = _ws_g(L.dg_loss_workspace_bytes(), g, xs[0].device)
+    _lib.check(L.dg_mse_fwd_g(g, _tab(xs), _tab(ts), xs[0].numel(), _tab(outs), _tab(wsl), wsb, _stream()), "dg_mse_fwd_g")
+    return xs, ts
+
+
+def mse_bwd_g(xs, ts, gouts):
+    dxs = [_dense_like(x) for x in xs]
+    _lib.check(_lib.load().dg_mse_bwd_g(len(xs), _tab(xs), _tab(ts), xs[0].numel(), _tab(gouts), _tab(dxs), _stream()), "dg_mse_bwd_g")
+    return dxs
+
+
+def _labels(labels):
+    import ctypes as C
+    return (C.c_float * len(labels))(*[float(l) for l in labels])
+
+
+def bce_fwd_g(ps, labels, outs):
+    _check_dev(*ps)
+    ps = [p.contiguous() for p in ps]
+    _lib.check(_lib.load().dg_bce_fwd_g(len(ps), _tab(ps), ps[0].numel(), _labels(labels), _tab(outs), _stream()), "dg_bce_fwd_g")
+    return ps
+
+
+def bce_bwd_g(ps, labels, gouts):
+    dps = [torch.empty_like(p) for p in ps]
+    _lib.check(_lib.load().dg_bce_bwd_g(len(ps), _tab(ps), ps[0].numel(), _labels(labels), _tab(gouts), _tab(dps), _stream()), "dg_bce_bwd_g")
+    return dps
+
+
+def fm_fwd_g(reals, fakes, outs):
+    g = len(reals)
+    _check_dev(*reals, *fakes)
+    pairs = [same_layout_pair(r, f) for r, f in zip(reals, fakes)]
+    reals, fakes = [p[0] for p in pairs], [p[1] for p in pairs]
+    n = reals[0].shape[0]
+    j = reals[0].numel() // n
+    diffs = [torch.empty(j, device=reals[0].device, dtype=torch.float32) for _ in range(g)]
+    L = _lib.load()
+    wsl, wsb = _ws_g(L.dg_fm_workspace_bytes(n, j), g, reals[0].device)
+    _lib.check(L.dg_fm_fwd_g(g, _tab(reals), _tab(fakes), n, j, _tab(diffs), _tab(outs), _tab(wsl), wsb, _stream()), "dg_fm_fwd_g")
+    return diffs, reals, fakes
+
+
+def fm_bwd_g(diffs, like_reals, like_fakes, gouts, need_real, need_fake):
+    n = like_fakes[0].shape[0]
+    j = diffs[0].numel()
+    dreals = [_dense_like(t) for t in like_reals] if need_real else None
+    dfakes = [_dense_like(t) for t in like_fakes] if need_fake else None
+    _lib.check(_lib.load().dg_fm_bwd_g(len(diffs), _tab(diffs), n, j, _tab(gouts), _tab(dreals), _tab(dfakes), _stream()), "dg_fm_bwd_g")
+    return dreals, dfakes
+
+
+# ---- module attributes ops.SHADOW / ops.ACT16 / ops.X3: views of the CURRENT context (kept for op-level tests and tools, which set
+# them around single calls; a trainer carries its own Context and never touches them) -----------------------------------------------
+import sys as _sys
+import types as _types
+
+
+class _OpsModule(_types.ModuleType):
+    @property
+    def SHADOW(self):
+        return _CUR.shadow
+
+    @SHADOW.setter
+    def SHADOW(self, v):
+        _CUR.shadow = bool(v)
+
+    @property
+    def ACT16(self):
+        return _CUR.act16
+
+    @ACT16.setter
+    def ACT16(self, v):
+        _CUR.act16 = bool(v)
+
+    @property
+    def X3(self):
+        return _CUR.x3
+
+    @X3.setter
+    def X3(self, v):
+        _CUR.x3 = bool(v)
+
+
+_sys.modules[__name__].__class__ = _OpsModule

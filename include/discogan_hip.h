@@ -45,6 +45,26 @@ extern "C" {
 
 typedef void* dg_stream_t;
 
+/* Arithmetic of the conv products, a PER-CALL argument of the *_g / *_p entry points ("dtype enum"):
+ *   DG_PREC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   DG_PREC_BF16  operands rounded to bf16 (RNE), bf16 MFMA, fp32 accumulation (BASELINE configs[4]);
+ *   DG_PREC_F32X3 fp32-accurate products on the bf16 MFMA: every operand value as three bf16 pieces (24 significand bits), six MFMAs
+ *                 per product block, fp32 accumulation.
+ * Entry points WITHOUT the argument use the process default (dg_set_option("bf16", n); 0 unless set), kept for tools and tests. */
+#define DG_PREC_DEFAULT (-1)  /* "whatever the process default is" (tools / tests that flip dg_set_option("bf16")) */
+#define DG_PREC_F32 0
+#define DG_PREC_BF16 1
+#define DG_PREC_F32X3 2
+
+/* Grouped launches (round 4).  The reference issues the passes of an iteration in independent pairs of identical shape --
+ * G_B(A) | G_A(B), G_A(AB) | G_B(BA), D_A(A) | D_B(B), D_A(BA) | D_B(AB) (image_translation.py:342-361) -- and each discriminator
+ * sees real and fake images with the SAME weights (:353-354,360-361).  A *_g entry point takes `groups` (1..DG_MAX_GROUPS) such
+ * problems -- identical geometry, one pointer per problem in every pointer table -- and issues ONE launch per kernel of the op
+ * (a block index selects the problem); each problem's result is bitwise what the one-problem call computes.  Where several problems
+ * accumulate into the same tensor (`share`: a discriminator's real and fake pass into one weight / BatchNorm-parameter gradient) the
+ * final reduction adds them in problem order, bitwise what consecutive accumulating calls leave. */
+#define DG_MAX_GROUPS 4
+
 int dg_version(void);
 const char* dg_last_error(void);
 
@@ -66,9 +86,8 @@ const char* dg_last_error(void);
  *   default 32x32x16 body (same products; measured not faster in the whole step);
  * "dgw_persist" 1: the f32x3 window input-grad kernel as one persistent workgroup per CU when there are more tiles than CUs (the
  *   next tile's first DMA is issued in front of the finished tile's epilogue; bit-identical, measured not faster);
- * "dbg_zero" 1|2|3: timing experiments only (operand loads dropped: wrong results); bit 2 (4): the window forward kernel walks its
- *   super-chunks chunk-major, bit 3 (8): the register-staged f32x3 forward walks 16-channel chunks with the taps inside (the order
- *   before round 3) -- both correct results in another summation order (same-box A/B switches). */
+ * (The operand-dropping timing switch of earlier rounds exists only in the separate timing build, csrc/Makefile TIMING=1; the product
+ *   library has no option that changes results.) */
 int dg_set_option(const char* name, int value);
 
 /* ---- interior convolutions: implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------
@@ -88,6 +107,19 @@ int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int 
 /* dw (+)= sum_pixels dy (x) im2col(x); accumulate!=0 adds into dw */
 int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
                   int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream);
+
+/* Grouped forms with the arithmetic as an argument.  stat (may be NULL): fused BatchNorm partial statistics, one buffer of
+ * dg_conv_bnstats_rows_p(...) x (3 * columns + 4) floats per problem; ws: one workspace of ws_bytes >= dg_conv_workspace_bytes_p(...)
+ * per problem (NULL entries allowed when that is 0).  dg_conv_wgrad_g: share > 1 = every `share` consecutive problems name the same dw. */
+size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
+int dg_conv_bnstats_rows_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
+int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
+int dg_conv_fwd_g(int groups, const float* const* x, const float* const* w, float* const* y, int N, int H, int W, int C, int K, int stride,
+                  int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_dgrad_g(int groups, const float* const* dy, const float* const* w, float* const* dx, int N, int H, int W, int C, int K, int stride,
+                    int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
+int dg_conv_wgrad_g(int groups, int share, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W, int C, int K,
+                    int stride, int pad, int prec, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream);
 
 /* Inference path (inference.py:149,172-187: generator.eval() forward): [Conv2d | ConvTranspose2d] -> BatchNorm2d(eval)
  * -> LeakyReLU/ReLU as ONE kernel.  The caller folds the BatchNorm scale into the weights (w * gamma*invstd per output
@@ -162,6 +194,25 @@ int dg_conv4x4s2_c3_wgrad_act(const float* dy_nhwc, const float* act_out_nhwc, i
                               const float* x_nchw, float* dw, int N, int H, int W, int K, int accumulate,
                               void* ws, size_t ws_bytes, dg_stream_t s);
 
+/* Grouped forms of the three edge ops (K == 64: the streaming / scatter / per-wave kernels), arithmetic as an argument.
+ * dg_conv4x4s2_c3_wgrad_g: act_out_nhwc NULL with act NONE; share > 1 = every `share` consecutive problems name the same dw;
+ * ws: one workspace of ws_bytes >= dg_c3_wgrad_workspace_bytes(...) per problem. */
+/* one-problem forms with the arithmetic as an argument (y_bf16 / dy_bf16 / io_bf16: the 64-channel NHWC side is bf16, see the *_t forms) */
+int dg_conv4x4s2_c3_fwd_p(const float* x_nchw, const float* w, void* y_nhwc, int y_bf16, int N, int H, int W, int K,
+                          int act, float slope, int prec, dg_stream_t s);
+int dg_conv4x4s2_c3_dgrad_p(const void* dy_nhwc, int dy_bf16, const float* w, float* dx_nchw, int N, int H, int W, int K,
+                            int act, int prec, void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4s2_c3_wgrad_p(const void* dy_nhwc, const void* act_out_nhwc, int io_bf16, int act, float slope,
+                            const float* x_nchw, float* dw, int N, int H, int W, int K, int prec, int accumulate,
+                            void* ws, size_t ws_bytes, dg_stream_t s);
+int dg_conv4x4s2_c3_fwd_g(int groups, const float* const* x_nchw, const float* const* w, float* const* y_nhwc, int N, int H, int W, int K,
+                          int act, float slope, int prec, dg_stream_t s);
+int dg_conv4x4s2_c3_dgrad_g(int groups, const float* const* dy_nhwc, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,
+                            int act, int prec, dg_stream_t s);
+int dg_conv4x4s2_c3_wgrad_g(int groups, int share, const float* const* dy_nhwc, const float* const* act_out_nhwc, int act, float slope,
+                            const float* const* x_nchw, float* const* dw, int N, int H, int W, int K, int prec, int accumulate,
+                            void* const* ws, size_t ws_bytes, dg_stream_t s);
+
 /* ---- BatchNorm2d (training mode) + activation, NHWC [M][C], M = N*H*W ------------------------
  * nn.BatchNorm2d (model.py:12...; eps 1e-5, momentum 0.1, biased batch var for normalisation,
  * unbiased for running_var, num_batches_tracked int64 += 1) fused with the in-place
@@ -186,10 +237,26 @@ int dg_bn_act_bwd(const float* dz, const float* y, float* dy, int M, int C, cons
                   const float* gamma, const float* beta, int act, float slope,
                   float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, dg_stream_t s);
 
+/* Grouped forms (fp32 tensors).  share > 1: every `share` consecutive problems are passes through the SAME BatchNorm module (a
+ * discriminator's real and fake pass, image_translation.py:353-361): they name the same running_mean / running_var /
+ * num_batches_tracked (dg_bn_train_stats_g) or the same dgamma / dbeta (dg_bn_act_bwd_g), and the finalize kernel applies their
+ * updates one after the other in problem order.  ws: one workspace of ws_bytes >= dg_bn_workspace_bytes(M, C) per problem; the
+ * backward keeps its coefficients there between its three kernels. */
+int dg_bn_train_stats_g(int groups, int share, const float* const* y, int M, int C, float eps, float momentum, float* const* running_mean,
+                        float* const* running_var, int64_t* const* num_batches_tracked, float* const* saved, void* const* ws, size_t ws_bytes,
+                        dg_stream_t s);
+int dg_bn_act_fwd_g(int groups, const float* const* y, float* const* z, int M, int C, const float* const* saved, const float* const* gamma,
+                    const float* const* beta, int act, float slope, dg_stream_t s);
+int dg_bn_act_bwd_g(int groups, int share, const float* const* dz, const float* const* y, float* const* dy, int M, int C,
+                    const float* const* saved, const float* const* gamma, const float* const* beta, int act, float slope,
+                    float* const* dgamma, float* const* dbeta, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t s);
+
 /* ---- stand-alone activations ------------------------------------------------------------------ */
 int dg_act_fwd(const float* x, float* y, size_t n, int act, float slope, dg_stream_t s);
 /* out = output of the activation (in-place semantics of the reference, model.py:9,36) */
 int dg_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, dg_stream_t s);
+int dg_act_fwd_g(int groups, const float* const* x, float* const* y, size_t n, int act, float slope, dg_stream_t s);
+int dg_act_bwd_g(int groups, const float* const* dy, const float* const* out, float* const* dx, size_t n, int act, float slope, dg_stream_t s);
 
 /* ---- losses: scalars stay in device memory ----------------------------------------------------
  * gout points to the upstream gradient scalar (device).  ws: >= dg_loss_workspace_bytes().
@@ -207,6 +274,16 @@ size_t dg_fm_workspace_bytes(int N, size_t J);
 int dg_fm_fwd(const float* real, const float* fake, int N, size_t J, float* diff, float* loss,
               void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_fm_bwd(const float* diff, int N, size_t J, const float* gout, float* dreal, float* dfake, dg_stream_t s);
+/* Grouped forms: the A-side and B-side term of each loss in one launch per kernel (image_translation.py:349-350,353-365).  label: one
+ * host float per problem.  dg_fm_bwd_g: dreal / dfake tables may be NULL (that side takes no gradient). */
+int dg_mse_fwd_g(int groups, const float* const* x, const float* const* t, size_t n, float* const* loss, void* const* ws, size_t ws_bytes, dg_stream_t s);
+int dg_mse_bwd_g(int groups, const float* const* x, const float* const* t, size_t n, const float* const* gout, float* const* dx, dg_stream_t s);
+int dg_bce_fwd_g(int groups, const float* const* p, int n, const float* label, float* const* loss, dg_stream_t s);
+int dg_bce_bwd_g(int groups, const float* const* p, int n, const float* label, const float* const* gout, float* const* dp, dg_stream_t s);
+int dg_fm_fwd_g(int groups, const float* const* real, const float* const* fake, int N, size_t J, float* const* diff, float* const* loss,
+                void* const* ws, size_t ws_bytes, dg_stream_t s);
+int dg_fm_bwd_g(int groups, const float* const* diff, int N, size_t J, const float* const* gout, float* const* dreal, float* const* dfake,
+                dg_stream_t s);
 
 /* Profiling hook: the next implicit-GEMM launches write 8 int64 per workgroup into buf ({wall0, cyc0, cyc after
  * prologue, cyc after the K loop, cyc after the epilogue stores are issued, wall1, XCC<<32|HW_ID, cyc end});

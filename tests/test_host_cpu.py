@@ -136,7 +136,8 @@ def test_conv_planner_dispatch_at_512px_batch32():
     ch = stage_channels(512)                 # 64, 128, 256, 512, 1024, 2048, 2048
     layers = [(ch[i - 1], ch[i], 512 >> i) for i in range(1, len(ch))]           # (C, K, H of the layer input)
     try:
-        _lib.set_option("bf16", 2)           # f32x3: plane kernels (igemm_dma_x3.hip; narrow input-grads: igemm_dma_x3_dgw.hip)
+        # the planning queries name their arithmetic themselves (round 4: no process-wide "bf16" option involved)
+        # f32x3: plane kernels (igemm_dma_x3.hip; narrow input-grads: igemm_dma_x3_dgw.hip)
         for C, K, H in layers:
             got = [L.dg_conv_x3_planes_ok(op, 32, H, H, C, K, 2, 1) for op in (0, 1, 2)]
             # every forward has a plane kernel (>= 192 columns: 256 x 256 tile = 1; <= 128: the window forward kernel = 3, which reads the
@@ -144,20 +145,22 @@ def test_conv_planner_dispatch_at_512px_batch32():
             # operand in the quad-chunk layout) and every weight-grad
             want = [1 if K >= 192 else 3, 2 if C <= 128 else 1, 1]
             assert got == want, (C, K, H, got, want)
-        _lib.set_option("bf16", 1)           # bf16: 2 = LDS-DMA kernel (igemm_dma.hip) or the window kernel, 1 = register-staged tiles
+        # bf16: 2 = LDS-DMA kernel (igemm_dma.hip) or the window kernel, 1 = register-staged tiles
         for C, K, H in layers:
             got = [L.dg_conv_bf16_operands_ok(op, 32, H, H, C, K, 2, 1) for op in (0, 1, 2)]
             want = [2 if K >= 192 else 1, 2, 2 if K >= 192 else 1]
             assert got == want, (C, K, H, got, want)
         _lib.set_option("dma_mfma", 1)       # A/B switch: no window kernels
         assert L.dg_conv_bf16_operands_ok(1, 32, 256, 256, 64, 128, 2, 1) == 1
-        _lib.set_option("bf16", 2)
         assert L.dg_conv_x3_planes_ok(1, 32, 256, 256, 64, 128, 2, 1) == 0
-        _lib.set_option("bf16", 0)           # exact fp32: neither operand form applies
-        assert L.dg_conv_x3_planes_ok(0, 32, 64, 64, 256, 512, 2, 1) == 0 and L.dg_conv_bf16_operands_ok(0, 32, 64, 64, 256, 512, 2, 1) == 0
     finally:
         _lib.set_option("dma_mfma", 0)
-        _lib.set_option("bf16", 0)
+    # precision as an argument of the planning queries: the three arithmetics plan different K-tiles / splits for the same shape
+    ws = [L.dg_conv_workspace_bytes_p(0, 64, 8, 8, 256, 512, 2, 1, prec) for prec in (0, 1, 2)]
+    assert all(w > 0 for w in ws)
+    assert L.dg_conv_plan_splits_p(0, 64, 8, 8, 256, 512, 2, 1, 0) >= 2
+    # the timing switch that drops operand loads does not exist in the product library
+    assert L.dg_set_option(b"dbg_zero", 1) != 0
 
 
 def test_graft_entry_build():
