@@ -66,6 +66,11 @@ def parse(argv=None):
     ap.add_argument("--async_wgrad", action="store_true", help="experiment: weight-gradient kernels on a third HIP stream")
     ap.add_argument("--mfma_turns", action="store_true", help="experiment: the two chains take turns on the matrix cores")
     ap.add_argument("--skew_steps", type=int, default=0, help="experiment: hold the B-side chain back by this many layer groups of the A-side chain")
+    ap.add_argument("--group_launch", default="auto", choices=["auto", "on", "off"],
+                    help="grouped launches: the A-side / B-side pass of each pair (and a discriminator's real + fake pass) as ONE launch per "
+                         "kernel; auto = below 256 px on the exact-fp32 / register-staged f32x3 arithmetic")
+    ap.add_argument("--group_plan", default="launch", choices=["launch", "single"],
+                    help="split-K plan of a grouped conv launch: sized for the whole launch (default) or per problem (bitwise the ungrouped step)")
     ap.add_argument("--comm", default="auto", choices=["auto", "capi", "c10d"], help="data-parallel transport (dp.ExchangeGroup)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="data-parallel exchange overlapped with compute (eager dispatch) or behind a replayed hipGraph")
@@ -258,14 +263,17 @@ def cpu_baseline(image_size, batch, budget_s, update_interval=3):
 COMM_NOTE = []
 
 
-def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None, act_dtype=None):
+def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None, act_dtype=None, group=None):
     from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args
     ov = {"auto": None, "on": True, "off": False}[a.overlap] if overlap is None else overlap
     kw = dict(device=dev, image_size=image_size, seed=1234, process_group=pg,
               use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
               mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov,
               act_dtype=act_dtype or (a.act_dtype if (mfma_dtype or a.mfma_dtype) == "bf16" else "f32"), skew_steps=a.skew_steps,
-              async_wgrad=a.async_wgrad, mfma_turns=a.mfma_turns, x3_planes=False if a.no_x3_planes else None)
+              async_wgrad=a.async_wgrad, mfma_turns=a.mfma_turns, x3_planes=False if a.no_x3_planes else None,
+              group_launch={"auto": None, "on": True, "off": False}[a.group_launch] if group is None else group, group_plan=a.group_plan)
+    if kw["group_launch"] is None and (a.async_wgrad or a.mfma_turns or a.skew_steps):
+        kw["group_launch"] = False
     want = comm or a.comm
     # Multi-rank run: "auto" = the library's own RCCL communicator.  dp.ExchangeGroup votes on every rank's readiness BEFORE
     # the collective init (store keys, no collective) and runs the init under a deadline: a failed vote moves ALL ranks to
@@ -289,7 +297,7 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
     warmup = warmup + (phase - warmup) % ui
     dt, it = timed_run(tr, A, B, steps, warmup, world)
     res = dict(images_per_sec=round(batch * world * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
-               warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=bool(tr.overlap_comm))
+               warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=bool(tr.overlap_comm), grouped_launches=bool(tr.group_launch))
     live = LIVE_GFLOP_PER_IMAGE.get(image_size or tr.image_size)
     if live:
         res["whole_step_tflops"] = round(batch * steps / dt * live / 1e3, 2)
@@ -406,7 +414,7 @@ def main():
     if world == 1 and not a.no_extra:
         def side(label, image_size, batch, steps, warmup, **kw):
             t0 = time.time()
-            t = make_trainer(a, dev, None, image_size, **{k: v for k, v in kw.items() if k in ("mfma_dtype", "graph", "overlap", "comm", "act_dtype")})
+            t = make_trainer(a, dev, None, image_size, **{k: v for k, v in kw.items() if k in ("mfma_dtype", "graph", "overlap", "comm", "act_dtype", "group")})
             x, y = synthetic_batch(batch, image_size, 1000, dev)
             r = measure(a, t, x, y, batch, 1, steps, warmup, roofline=kw.get("roofline", False), image_size=image_size)
             r.pop("_next_iter", None)

@@ -29,12 +29,12 @@ SIGNATURES = {
     "dg_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "dg_conv_workspace_bytes_p": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_workspace_bytes_p": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "dg_conv_bnstats_rows_p": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "dg_conv_plan_splits_p": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "dg_conv_fwd_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
-    "dg_conv_dgrad_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
-    "dg_conv_wgrad_g": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_conv_plan_splits_p": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "dg_conv_fwd_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
+    "dg_conv_dgrad_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
+    "dg_conv_wgrad_g": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_fwd_p": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dg_conv4x4s2_c3_dgrad_p": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_wgrad_p": (_i, [_p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -43,6 +43,14 @@ struct DgPrecScope {
     explicit DgPrecScope(int prec);
     ~DgPrecScope();
 };
+// Problems the split-K plan of the CURRENT call is sized for (plan_groups of the *_g conv entry points): 1 = every problem planned as if
+// launched alone (bitwise the one-problem result), g = the whole grouped launch fills the chip, so fewer K-splits per problem.
+int dg_cur_plan_groups();
+struct DgPlanScope {
+    int old;
+    explicit DgPlanScope(int plan_groups);
+    ~DgPlanScope();
+};
 enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_DGW_PERSIST = 11, DG_OPT_COUNT = 12 };
 
 // ---- grouped launches (round 4): one tensor per problem, picked by a block index (wave-uniform: scalar loads) ------------------

@@ -1333,7 +1333,9 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
     const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma >= 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Ng + BN - 1) / BN;
-    const int base = a.tilesM * a.tilesN * (pl->dma >= 3 ? 4 / pl->ncls : zmul);
+    // workgroups of the launch before any K split; a grouped launch planned as a whole (plan_groups of the *_g entry points) counts all
+    // its problems: the chip is filled by the group, each problem needs fewer splits (fewer slabs written and re-read)
+    const int base = a.tilesM * a.tilesN * (pl->dma >= 3 ? 4 / pl->ncls : zmul) * (pl->dma ? 1 : dg_cur_plan_groups());
     a.splits = pl->dma == 5 ? 1 : choose_splits(base, a.nIt, pl->dma == 2 && pl->wm * pl->wn == 4 ? 512 : (pl->dma ? 256 : 0));
     a.itPerSplit = (a.nIt + a.splits - 1) / a.splits;
     a.splits = (a.nIt + a.itPerSplit - 1) / a.itPerSplit;  // no empty split
@@ -1536,8 +1538,8 @@ static void set_group_deltas(IgemmArgs& a, int groups, const void* const* A, con
 }
 
 static int conv_g(int op, int groups, int share, const float* const* a_in, const float* const* b_in, float* const* out, int N, int H, int W, int C,
-                  int K, int stride, int pad, int prec, int accumulate, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes,
-                  hipStream_t st, const char* who) {
+                  int K, int stride, int pad, int prec, int plan_groups, int accumulate, float* const* stat, size_t stat_floats, void* const* ws,
+                  size_t ws_bytes, hipStream_t st, const char* who) {
     DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS, "%s: groups=%d (1..%d)", who, groups, DG_MAX_GROUPS);
     DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "%s: prec=%d (DG_PREC_F32 | DG_PREC_BF16 | DG_PREC_F32X3)", who, prec);
     DG_CHECK_ARG(share <= 1 || (op == 2 && groups % share == 0), "%s: share=%d needs the weight gradient and groups %% share == 0", who, share);
@@ -1548,7 +1550,10 @@ static int conv_g(int op, int groups, int share, const float* const* a_in, const
     for (int i = 0; i < groups; ++i) DG_CHECK_ARG(a_in[i] && b_in[i] && out[i], "%s: null pointer (problem %d)", who, i);
     if (share > 1)
         for (int i = 0; i < groups; ++i) DG_CHECK_ARG(out[i] == out[i / share * share], "%s: problems of one share set must name the same dw", who);
+    if (plan_groups < 0) plan_groups = -plan_groups;          // internal: a member launch of a share set keeps its parent's plan
+    else DG_CHECK_ARG(plan_groups == 1 || plan_groups == groups, "%s: plan_groups=%d (1 or groups=%d)", who, plan_groups, groups);
     DgPrecScope scope(prec);
+    DgPlanScope pscope(plan_groups);
     if (K == 1) {
         DG_CHECK_ARG(stride == 1, "%s: K==1 only for the 4x4 head", who);
         return head1_g(op, groups, share, (const void* const*)a_in, 0, (const void* const*)b_in, 0, (void* const*)out, 0, N, C, accumulate, st, who);
@@ -1565,7 +1570,10 @@ static int conv_g(int op, int groups, int share, const float* const* a_in, const
             const float *aa[DG_MAX_GROUPS], *bb[DG_MAX_GROUPS];
             float* oo[DG_MAX_GROUPS];
             for (int z = 0; z < nout; ++z) { aa[z] = a_in[z * share + j]; bb[z] = b_in[z * share + j]; oo[z] = out[z * share + j]; }
-            rc = conv_g(op, nout, 1, aa, bb, oo, N, H, W, C, K, stride, pad, prec, (accumulate || j > 0) ? 1 : 0, nullptr, 0, ws, ws_bytes, st, who);
+            void* wj[DG_MAX_GROUPS];
+            for (int z = 0; z < nout; ++z) wj[z] = ws ? ws[z * share + j] : nullptr;
+            // (plan_groups handed on unchanged: the same unsplit plan for every member launch)
+            rc = conv_g(op, nout, 1, aa, bb, oo, N, H, W, C, K, stride, pad, prec, -plan_groups, (accumulate || j > 0) ? 1 : 0, nullptr, 0, wj, ws_bytes, st, who);
             if (rc) return rc;
         }
         return DG_OK;
@@ -1594,43 +1602,47 @@ static int conv_g(int op, int groups, int share, const float* const* a_in, const
 }
 
 extern "C" int dg_conv_fwd_g(int groups, const float* const* x, const float* const* w, float* const* y, int N, int H, int W, int C, int K, int stride,
-                             int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(0, groups, 1, x, w, y, N, H, W, C, K, stride, pad, prec, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd_g");
+                             int pad, int prec, int plan_groups, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes,
+                             dg_stream_t stream) {
+    return conv_g(0, groups, 1, x, w, y, N, H, W, C, K, stride, pad, prec, plan_groups, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd_g");
 }
 extern "C" int dg_conv_dgrad_g(int groups, const float* const* dy, const float* const* w, float* const* dx, int N, int H, int W, int C, int K, int stride,
-                               int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(1, groups, 1, dy, w, dx, N, H, W, C, K, stride, pad, prec, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad_g");
+                               int pad, int prec, int plan_groups, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes,
+                               dg_stream_t stream) {
+    return conv_g(1, groups, 1, dy, w, dx, N, H, W, C, K, stride, pad, prec, plan_groups, 0, stat, stat_floats, ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad_g");
 }
 extern "C" int dg_conv_wgrad_g(int groups, int share, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W, int C, int K,
-                               int stride, int pad, int prec, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(2, groups, share, dy, x, dw, N, H, W, C, K, stride, pad, prec, accumulate, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad_g");
+                               int stride, int pad, int prec, int plan_groups, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream) {
+    return conv_g(2, groups, share, dy, x, dw, N, H, W, C, K, stride, pad, prec, plan_groups, accumulate, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad_g");
 }
 // planning queries with the arithmetic as an argument (the forms without it read the process default)
-extern "C" size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
+extern "C" size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec, int plan_groups) {
     DgPrecScope scope(prec);
+    DgPlanScope pscope(plan_groups);
     return dg_conv_workspace_bytes(op, N, H, W, C, K, stride, pad);
 }
 extern "C" int dg_conv_bnstats_rows_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
     DgPrecScope scope(prec);
     return dg_conv_bnstats_rows(op, N, H, W, C, K, stride, pad);
 }
-extern "C" int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec) {
+extern "C" int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec, int plan_groups) {
     DgPrecScope scope(prec);
+    DgPlanScope pscope(plan_groups);
     return dg_conv_plan_splits(op, N, H, W, C, K, stride, pad);
 }
 
 // the one-problem forms without a precision argument: the process default arithmetic (dg_set_option("bf16"))
 extern "C" int dg_conv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int K,
                            int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(0, 1, 1, &x, &w, &y, N, H, W, C, K, stride, pad, dg_cur_prec(), 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd");
+    return conv_g(0, 1, 1, &x, &w, &y, N, H, W, C, K, stride, pad, dg_cur_prec(), 1, 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_fwd");
 }
 extern "C" int dg_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K,
                              int stride, int pad, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(1, 1, 1, &dy, &w, &dx, N, H, W, C, K, stride, pad, dg_cur_prec(), 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad");
+    return conv_g(1, 1, 1, &dy, &w, &dx, N, H, W, C, K, stride, pad, dg_cur_prec(), 1, 0, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_dgrad");
 }
 extern "C" int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int W, int C, int K,
                              int stride, int pad, int accumulate, void* ws, size_t ws_bytes, dg_stream_t stream) {
-    return conv_g(2, 1, 1, &dy, &x, &dw, N, H, W, C, K, stride, pad, dg_cur_prec(), accumulate, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad");
+    return conv_g(2, 1, 1, &dy, &x, &dw, N, H, W, C, K, stride, pad, dg_cur_prec(), 1, accumulate, nullptr, 0, &ws, ws_bytes, (hipStream_t)stream, "dg_conv_wgrad");
 }
 
 // ---- bf16 shadow operands (option "bf16" = 1 only) -------------------------------------------------------------------

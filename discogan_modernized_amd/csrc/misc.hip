@@ -18,6 +18,10 @@ static thread_local int tl_call_prec = -1;
 int dg_cur_prec() { return tl_call_prec >= 0 ? tl_call_prec : g_options[DG_OPT_BF16]; }
 DgPrecScope::DgPrecScope(int prec) : old(tl_call_prec) { if (prec >= 0) tl_call_prec = prec; }     // DG_PREC_DEFAULT (-1): keep what is in force
 DgPrecScope::~DgPrecScope() { tl_call_prec = old; }
+static thread_local int tl_plan_groups = 1;
+int dg_cur_plan_groups() { return tl_plan_groups; }
+DgPlanScope::DgPlanScope(int plan_groups) : old(tl_plan_groups) { tl_plan_groups = plan_groups >= 1 ? plan_groups : 1; }
+DgPlanScope::~DgPlanScope() { tl_plan_groups = old; }
 
 extern "C" int dg_version(void) { return 100; }
 extern "C" const char* dg_last_error(void) { return dg_err_buf; }

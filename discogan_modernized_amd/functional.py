@@ -8,10 +8,31 @@ side that is not stepped.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 from torch.autograd import Function
 
 from . import ops
+
+
+def _fwd(f):
+    """forward(): remember the ops.Context (arithmetic, operand forms, derived-copy tables) the call runs under."""
+    @functools.wraps(f)
+    def w(ctx, *a, **k):
+        ctx.dgc = ops.current()
+        return f(ctx, *a, **k)
+    return staticmethod(w)
+
+
+def _bwd(f):
+    """backward(): run under the forward's context, whatever is ambient when autograd gets here -- two trainers with different
+    arithmetic may be interleaved call by call."""
+    @functools.wraps(f)
+    def w(ctx, *g):
+        with ops.use(ctx.dgc):
+            return f(ctx, *g)
+    return staticmethod(w)
 
 
 def _flat_grad_of(param):
@@ -78,7 +99,7 @@ def _release_after_backward(dy, x):
 class ConvFn(Function):
     """nn.Conv2d(C,K,4,stride,pad,bias=False), interior (C % 32 == 0)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, stride, pad, want_stats=False):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
@@ -99,7 +120,7 @@ class ConvFn(Function):
         ctx.set_materialize_grads(False)
         return y, stat
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dy, dstat=None):
         if dy is None:                                 # (set_materialize_grads(False): an unused output arrives as None)
             return None, None, None, None, None
@@ -124,7 +145,7 @@ class ConvTransposeFn(Function):
     """nn.ConvTranspose2d(Cin,Cout,4,stride,pad,bias=False), interior: forward = conv dgrad with the
     same weight tensor."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, stride, pad, want_stats=False):
         x = ops.as_nhwc(x)
         ctx.save_for_backward(x, w)
@@ -148,7 +169,7 @@ class ConvTransposeFn(Function):
         ctx.set_materialize_grads(False)
         return y, stat
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dy, dstat=None):
         if dy is None:
             return None, None, None, None, None
@@ -174,7 +195,7 @@ class ConvC3Fn(Function):
     """First layer nn.Conv2d(3,K,4,2,1) on the NCHW image, with the following in-place
     LeakyReLU fused (model.py:8-9, 80-81)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, act, slope, want_planes=False):
         y = ops.c3_fwd(x, w, act, slope, want_planes=want_planes)
         ctx.save_for_backward(x, w, y)
@@ -183,7 +204,7 @@ class ConvC3Fn(Function):
         ctx.final = FINAL_PASS
         return y
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         act, slope = ctx.act
@@ -209,7 +230,7 @@ class ConvC3Fn(Function):
 class ConvTransposeC3Fn(Function):
     """Last layer nn.ConvTranspose2d(K,3,4,2,1) + Sigmoid producing the NCHW image (model.py:142-143)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, act):
         x = ops.as_nhwc(x)
         out = ops.c3_dgrad(x, w, act)
@@ -219,7 +240,7 @@ class ConvTransposeC3Fn(Function):
         ctx.final = FINAL_PASS
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dout):
         x, w, out = ctx.saved_tensors
         g = ops.act_bwd(dout, out, ctx.act) if ctx.act != ops.ACT_NONE else dout.contiguous()
@@ -239,7 +260,7 @@ class BatchNormActFn(Function):
     """nn.BatchNorm2d (+ in-place LeakyReLU / ReLU).  Training mode updates the running buffers in
     the kernel exactly like PyTorch (momentum 0.1, unbiased running_var, num_batches_tracked += 1)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, slope,
                 partials=None, z_cm=False, dy_cm=False, z_po=False, dy_po=False):
         """z_cm / dy_cm (f32x3 plane path, ops.X3_CM): the plane triple of z / of this layer's dy will be read by a window
@@ -262,7 +283,7 @@ class BatchNormActFn(Function):
         ctx.final = FINAL_PASS
         return z
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dz):
         y, saved, gamma, beta = ctx.saved_tensors
         act, slope, training = ctx.cfg
@@ -283,14 +304,14 @@ class BatchNormActFn(Function):
 class ActFn(Function):
     """Stand-alone LeakyReLU / ReLU / Sigmoid (backward from the OUTPUT, in-place semantics)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, act, slope):
         out = ops.act_fwd(x, act, slope)
         ctx.save_for_backward(out)
         ctx.cfg = (act, slope)
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, dy):
         (out,) = ctx.saved_tensors
         act, slope = ctx.cfg
@@ -298,14 +319,14 @@ class ActFn(Function):
 
 
 class MSELossFn(Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, x, t, out=None):
         loss, xd, td = ops.mse_fwd(x, t, out)
         ctx.save_for_backward(xd, td)
         ctx.in_strides = x.stride()
         return loss
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         xd, td = ctx.saved_tensors
         gout = gout.contiguous()
@@ -319,7 +340,7 @@ class MSELossFn(Function):
 class BCELossFn(Function):
     """nn.BCELoss against a constant label tensor (image_translation.py:157-166)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, p, label, out=None):
         shape = p.shape
         loss, pc = ops.bce_fwd(p.reshape(-1), label, out)
@@ -327,7 +348,7 @@ class BCELossFn(Function):
         ctx.cfg = (label, shape)
         return loss
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         (pc,) = ctx.saved_tensors
         label, shape = ctx.cfg
@@ -337,7 +358,7 @@ class BCELossFn(Function):
 class BCETargetLossFn(Function):
     """nn.BCELoss against a target TENSOR (no gradient w.r.t. the target), image_translation.py:157-166."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, p, target):
         shape = p.shape
         loss, pc, tc = ops.bce_target_fwd(p.reshape(-1), target.detach().reshape(-1))
@@ -345,7 +366,7 @@ class BCETargetLossFn(Function):
         ctx.shape = shape
         return loss
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         pc, tc = ctx.saved_tensors
         return ops.bce_target_bwd(pc, tc, gout.contiguous()).reshape(ctx.shape), None
@@ -354,7 +375,7 @@ class BCETargetLossFn(Function):
 class HingeEmbeddingLossFn(Function):
     """nn.HingeEmbeddingLoss(margin, mean) for targets in {+1, -1} (image_translation.py:141-142,269)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, y, margin):
         loss, xd, yd = ops.hinge_fwd(x, y.detach(), margin)
         ctx.save_for_backward(xd, yd)
@@ -362,7 +383,7 @@ class HingeEmbeddingLossFn(Function):
         ctx.in_shape = x.shape
         return loss
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         xd, yd = ctx.saved_tensors
         return ops.hinge_bwd(xd, yd, ctx.margin, gout.contiguous()), None, None
@@ -371,13 +392,13 @@ class HingeEmbeddingLossFn(Function):
 class FeatureMatchFn(Function):
     """One layer of get_fm_loss: mean((real.mean(0) - fake.mean(0))**2)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, real, fake, out=None):
         loss, diff, rd, fd = ops.fm_fwd(real, fake, out)
         ctx.save_for_backward(diff, rd, fd)
         return loss
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         diff, rd, fd = ctx.saved_tensors
         dreal, dfake = ops.fm_bwd(diff, rd, fd, gout.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
@@ -391,14 +412,14 @@ class LossMixFn(Function):
     depends on, ``idx`` their slot numbers: autograd routes each seed to the loss op that wrote the slot and
     never visits the others.  Returns the 8 outputs of dg_loss_mix_fwd as 0-dim tensors."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, lossvec, nfm, rate, arch, which, idx, *slots):
         out = ops.loss_mix_fwd(lossvec, nfm, rate, arch)
         ctx.cfg = (lossvec.numel(), nfm, rate, arch, which, idx)
         ctx.set_materialize_grads(False)
         return tuple(out.unbind(0))
 
-    @staticmethod
+    @_bwd
     def backward(ctx, *gouts):
         nslots, nfm, rate, arch, which, idx = ctx.cfg
         gout = gouts[which]
@@ -406,3 +427,283 @@ class LossMixFn(Function):
             return (None,) * (6 + len(idx))
         gv = ops.loss_mix_bwd(gout.contiguous(), nslots, nfm, rate, arch, which)
         return (None, None, None, None, None, None) + tuple(gv[i] for i in idx)
+
+
+# ---- grouped launches (round 4): one autograd node for the same layer of several passes -------------------------------------------
+# ``g`` problems = the A-side and the B-side pass of a pair (image_translation.py:342-346: G_B(A) | G_A(B), G_A(AB) | G_B(BA);
+# :353-361: D_A(.) | D_B(.)), or a discriminator layer's real and fake pass of both sides (g = 4, problems ordered
+# D_A real, D_A fake, D_B real, D_B fake: the two passes through one module are consecutive, which is what lets the kernels add
+# their parameter gradients / running-statistics updates in the order separate launches would).  Inputs and outputs are flat tuples,
+# problem-major.  Each problem's numbers are bitwise those of the one-problem Function (tests/test_group_gpu.py).
+def _all_or_none(grads, who):
+    """Gradients of a grouped node arrive for all problems or for none (the trainer groups passes with the same liveness)."""
+    live = [g_ is not None for g_ in grads]
+    if any(live) and not all(live):
+        raise RuntimeError(f"{who}: gradients arrived for some problems of a grouped node only")
+    return all(live)
+
+
+def _flat_grads_of(params):
+    fgs = [_flat_grad_of(p) for p in params]
+    if any(f is None for f in fgs):
+        raise RuntimeError("grouped launches need parameters whose .grad is the optimiser's flat gradient view (optim.Adam)")
+    return fgs
+
+
+class ConvGroupFn(Function):
+    """Interior Conv2d (transposed=False) or ConvTranspose2d (True) of ``g`` problems.  args: x_0..x_{g-1}, w_0..w_{g-1}."""
+
+    @_fwd
+    def forward(ctx, g, stride, pad, transposed, *xw):
+        xs = [ops.as_nhwc(x) for x in xw[:g]]
+        ws = list(xw[g:])
+        ctx.g, ctx.sp, ctx.tr = g, (stride, pad), transposed
+        ctx.wrefs = ws
+        ctx.final = FINAL_PASS
+        ctx.save_for_backward(*xs, *ws)
+        if transposed:
+            hin, win = xs[0].shape[2], xs[0].shape[3]
+            hw = ((hin - 1) * stride - 2 * pad + 4, (win - 1) * stride - 2 * pad + 4)
+            ys = ops.conv_dgrad_g(xs, ws, hw, stride, pad)
+        else:
+            ys = ops.conv_fwd_g(xs, ws, stride, pad)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @_bwd
+    def backward(ctx, *dys):
+        g = ctx.g
+        if not _all_or_none(dys, "ConvGroupFn"):
+            return (None,) * (4 + 2 * g)
+        saved = ctx.saved_tensors
+        xs, ws = list(saved[:g]), ctx.wrefs
+        stride, pad = ctx.sp
+        dys = [ops.as_nhwc(d) for d in dys]
+        need_x = [ctx.needs_input_grad[4 + i] for i in range(g)]
+        need_w = [ctx.needs_input_grad[4 + g + i] for i in range(g)]
+        if any(need_x) != all(need_x) or any(need_w) != all(need_w):
+            raise RuntimeError("ConvGroupFn: the problems of a grouped node must need the same gradients")
+        dxs = [None] * g
+        if need_x[0]:
+            dxs = ops.conv_fwd_g(dys, ws, stride, pad) if ctx.tr else ops.conv_dgrad_g(dys, ws, (xs[0].shape[2], xs[0].shape[3]), stride, pad)
+        if need_w[0]:
+            fgs = _flat_grads_of(ws)
+            share = ops._share_of(ws)
+            if ctx.tr:      # dw[cin][r][s][cout] = sum x[..cin] * dy[..cout]: conv wgrad with roles (dy := x, x := dy)
+                ops.conv_wgrad_g(xs, dys, stride, pad, fgs, True, share)
+            else:
+                ops.conv_wgrad_g(dys, xs, stride, pad, fgs, True, share)
+            _final(ctx.final, *ws)
+        return (None, None, None, None) + tuple(dxs) + (None,) * g
+
+
+class ConvC3GroupFn(Function):
+    """First layer Conv2d(3, K, 4, 2, 1) + fused LeakyReLU of ``g`` problems.  args: x_0.., w_0.."""
+
+    @_fwd
+    def forward(ctx, g, act, slope, *xw):
+        xs, ws = list(xw[:g]), list(xw[g:])
+        ys = ops.c3_fwd_g(xs, ws, act, slope)
+        ctx.g, ctx.act = g, (act, slope)
+        ctx.wrefs = ws
+        ctx.final = FINAL_PASS
+        ctx.save_for_backward(*xs, *ws, *ys)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @_bwd
+    def backward(ctx, *dys):
+        g = ctx.g
+        if not _all_or_none(dys, "ConvC3GroupFn"):
+            return (None,) * (3 + 2 * g)
+        saved = ctx.saved_tensors
+        xs, ws, ys = list(saved[:g]), ctx.wrefs, list(saved[2 * g:])
+        act, slope = ctx.act
+        need_x = [ctx.needs_input_grad[3 + i] for i in range(g)]
+        need_w = [ctx.needs_input_grad[3 + g + i] for i in range(g)]
+        if any(need_x) != all(need_x) or any(need_w) != all(need_w):
+            raise RuntimeError("ConvC3GroupFn: the problems of a grouped node must need the same gradients")
+        dxs = [None] * g
+        if need_x[0] or act == ops.ACT_NONE:
+            gs = ops.act_bwd_g(dys, ys, act, slope) if act != ops.ACT_NONE else [ops.as_nhwc(d) for d in dys]
+            fuse = {}
+        else:       # weight gradient only (image input): the activation backward rides in the wgrad kernel's dy loads
+            gs = [ops.as_nhwc(d) for d in dys]
+            fuse = dict(act_outs=ys, act=act, slope=slope)
+        if need_x[0]:
+            dxs = ops.c3_dgrad_g(gs, ws, ops.ACT_NONE)
+        if need_w[0]:
+            fgs = _flat_grads_of(ws)
+            ops.c3_wgrad_g(gs, xs, fgs, True, share=ops._share_of(ws), **fuse)
+            _final(ctx.final, *ws)
+        return (None, None, None) + tuple(dxs) + (None,) * g
+
+
+class ConvTransposeC3GroupFn(Function):
+    """Last layer ConvTranspose2d(K, 3, 4, 2, 1) + Sigmoid of ``g`` problems.  args: x_0.., w_0.."""
+
+    @_fwd
+    def forward(ctx, g, act, *xw):
+        xs = [ops.as_nhwc(x) for x in xw[:g]]
+        ws = list(xw[g:])
+        outs = ops.c3_dgrad_g(xs, ws, act)
+        ctx.g, ctx.act = g, act
+        ctx.wrefs = ws
+        ctx.final = FINAL_PASS
+        ctx.save_for_backward(*xs, *ws, *outs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @_bwd
+    def backward(ctx, *douts):
+        g = ctx.g
+        if not _all_or_none(douts, "ConvTransposeC3GroupFn"):
+            return (None,) * (2 + 2 * g)
+        saved = ctx.saved_tensors
+        xs, ws, outs = list(saved[:g]), ctx.wrefs, list(saved[2 * g:])
+        gs = ops.act_bwd_g(douts, outs, ctx.act) if ctx.act != ops.ACT_NONE else [d.contiguous() for d in douts]
+        need_x = [ctx.needs_input_grad[2 + i] for i in range(g)]
+        need_w = [ctx.needs_input_grad[2 + g + i] for i in range(g)]
+        if any(need_x) != all(need_x) or any(need_w) != all(need_w):
+            raise RuntimeError("ConvTransposeC3GroupFn: the problems of a grouped node must need the same gradients")
+        dxs = [None] * g
+        if need_x[0]:
+            dxs = ops.c3_fwd_g(gs, ws, ops.ACT_NONE)
+        if need_w[0]:
+            fgs = _flat_grads_of(ws)
+            ops.c3_wgrad_g(xs, gs, fgs, True, share=ops._share_of(ws))
+            _final(ctx.final, *ws)
+        return (None, None) + tuple(dxs) + (None,) * g
+
+
+class BatchNormActGroupFn(Function):
+    """Training-mode BatchNorm2d + LeakyReLU / ReLU of ``g`` problems.  args: y_0.., gamma_0.., beta_0.., running_mean_0..,
+    running_var_0.., num_batches_tracked_0..  Problems through the SAME module (consecutive) update its running statistics one after
+    the other and add their parameter gradients in problem order (share)."""
+
+    @_fwd
+    def forward(ctx, g, eps, momentum, act, slope, *t):
+        ys = [ops.as_nhwc(y) for y in t[:g]]
+        gammas, betas = list(t[g:2 * g]), list(t[2 * g:3 * g])
+        rms, rvs, nbts = list(t[3 * g:4 * g]), list(t[4 * g:5 * g]), list(t[5 * g:6 * g])
+        share = ops._share_of(gammas)
+        saved = ops.bn_train_stats_g(ys, rms, rvs, nbts, eps, momentum, share)
+        zs = ops.bn_act_fwd_g(ys, saved, gammas, betas, act, slope)
+        ctx.g, ctx.cfg, ctx.share = g, (act, slope), share
+        ctx.prefs = (gammas, betas)
+        ctx.final = FINAL_PASS
+        ctx.save_for_backward(*ys, *saved, *gammas, *betas)
+        ctx.set_materialize_grads(False)
+        return tuple(zs)
+
+    @_bwd
+    def backward(ctx, *dzs):
+        g = ctx.g
+        if not _all_or_none(dzs, "BatchNormActGroupFn"):
+            return (None,) * (5 + 6 * g)
+        sv = ctx.saved_tensors
+        ys, saved = list(sv[:g]), list(sv[g:2 * g])
+        gammas, betas = ctx.prefs
+        act, slope = ctx.cfg
+        need_p = [ctx.needs_input_grad[5 + g + i] or ctx.needs_input_grad[5 + 2 * g + i] for i in range(g)]
+        if any(need_p) != all(need_p):
+            raise RuntimeError("BatchNormActGroupFn: the problems of a grouped node must need the same gradients")
+        dg = db = None
+        if need_p[0]:
+            dg, db = _flat_grads_of(gammas), _flat_grads_of(betas)
+        dys = ops.bn_act_bwd_g(dzs, ys, saved, gammas, betas, act, slope, dg, db, True, ctx.share if need_p[0] else 1)
+        if need_p[0]:
+            _final(ctx.final, *gammas, *betas)
+        return (None,) * 5 + tuple(dys) + (None,) * (5 * g)
+
+
+class ActGroupFn(Function):
+    """Stand-alone activation (the discriminators' Sigmoid) of ``g`` problems."""
+
+    @_fwd
+    def forward(ctx, g, act, slope, *xs):
+        outs = ops.act_fwd_g(list(xs), act, slope)
+        ctx.g, ctx.cfg = g, (act, slope)
+        ctx.save_for_backward(*outs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @_bwd
+    def backward(ctx, *dys):
+        if not _all_or_none(dys, "ActGroupFn"):
+            return (None,) * (3 + ctx.g)
+        act, slope = ctx.cfg
+        return (None, None, None) + tuple(ops.act_bwd_g(dys, list(ctx.saved_tensors), act, slope))
+
+
+class MSELossGroupFn(Function):
+    """nn.MSELoss of ``g`` (x, target) pairs; the losses land in ``outs`` (slots of the trainer's loss vector).  args: x_0.., t_0.., out_0.."""
+
+    @_fwd
+    def forward(ctx, g, *t):
+        xs, ts, outs = list(t[:g]), list(t[g:2 * g]), list(t[2 * g:3 * g])
+        xd, td = ops.mse_fwd_g(xs, ts, outs)
+        ctx.g = g
+        ctx.save_for_backward(*xd, *td)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @_bwd
+    def backward(ctx, *gouts):
+        g = ctx.g
+        if not _all_or_none(gouts, "MSELossGroupFn"):
+            return (None,) * (1 + 3 * g)
+        sv = ctx.saved_tensors
+        dxs = ops.mse_bwd_g(list(sv[:g]), list(sv[g:]), [go.contiguous() for go in gouts])
+        return (None,) + tuple(dxs) + (None,) * (2 * g)
+
+
+class BCELossGroupFn(Function):
+    """nn.BCELoss of ``g`` probability vectors against constant labels (image_translation.py:157-166).  args: p_0.., out_0.."""
+
+    @_fwd
+    def forward(ctx, g, labels, *t):
+        ps, outs = list(t[:g]), list(t[g:2 * g])
+        ctx.shapes = [p.shape for p in ps]
+        pcs = ops.bce_fwd_g([p.reshape(-1) for p in ps], labels, outs)
+        ctx.g, ctx.labels = g, tuple(labels)
+        ctx.save_for_backward(*pcs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @_bwd
+    def backward(ctx, *gouts):
+        g = ctx.g
+        live = [i for i in range(g) if gouts[i] is not None]
+        if not live:
+            return (None,) * (2 + 2 * g)
+        pcs = ctx.saved_tensors
+        dps = ops.bce_bwd_g([pcs[i] for i in live], [ctx.labels[i] for i in live], [gouts[i].contiguous() for i in live])
+        out = [None] * g
+        for i, d in zip(live, dps):
+            out[i] = d.reshape(ctx.shapes[i])
+        return (None, None) + tuple(out) + (None,) * g
+
+
+class FeatureMatchGroupFn(Function):
+    """One layer of get_fm_loss for ``g`` discriminators.  args: real_0.., fake_0.., out_0.."""
+
+    @_fwd
+    def forward(ctx, g, *t):
+        reals, fakes, outs = list(t[:g]), list(t[g:2 * g]), list(t[2 * g:3 * g])
+        diffs, rd, fd = ops.fm_fwd_g(reals, fakes, outs)
+        ctx.g = g
+        ctx.save_for_backward(*diffs, *rd, *fd)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @_bwd
+    def backward(ctx, *gouts):
+        g = ctx.g
+        if not _all_or_none(gouts, "FeatureMatchGroupFn"):
+            return (None,) * (1 + 3 * g)
+        sv = ctx.saved_tensors
+        need_r = any(ctx.needs_input_grad[1 + i] for i in range(g))
+        need_f = any(ctx.needs_input_grad[1 + g + i] for i in range(g))
+        dr, df = ops.fm_bwd_g(list(sv[:g]), list(sv[g:2 * g]), list(sv[2 * g:]), [go.contiguous() for go in gouts], need_r, need_f)
+        return (None,) + tuple(dr or [None] * g) + tuple(df or [None] * g) + (None,) * g

@@ -303,6 +303,76 @@ def _run_fused_steps(layers, x):
     return x
 
 
+# ---- grouped passes (round 4) --------------------------------------------------------------------------------------------
+# The reference runs the passes of an iteration in pairs of identical shape (image_translation.py:342-361).  group_generators /
+# group_discriminators run ``g`` such passes -- different networks of the same architecture, or the same network on different inputs
+# -- layer by layer with ONE launch per kernel for all of them (functional.*GroupFn -> ops.*_g -> dg_*_g).  Training mode, fp32
+# tensors, exact-fp32 or register-staged f32x3 arithmetic (ops.group_ok()); results per pass are bitwise those of net(x).
+def _group_layers(layer_lists, xs):
+    g, n = len(xs), len(layer_lists[0])
+    i = 0
+    while i < n:
+        convs = [L[i] for L in layer_lists]
+        conv = convs[0]
+        has_bn = i + 1 < n and isinstance(layer_lists[0][i + 1], BatchNorm2d)
+        j = i + (2 if has_bn else 1)
+        act_mod = layer_lists[0][j] if j < n and isinstance(layer_lists[0][j], _Act) else None
+        act = act_mod.act if act_mod is not None else ops.ACT_NONE
+        slope = act_mod.negative_slope if act_mod is not None else 0.0
+        ws = [c.weight for c in convs]
+        if has_bn:
+            bns = [L[i + 1] for L in layer_lists]
+            if not all(b.training for b in bns):
+                raise RuntimeError("grouped passes run BatchNorm in training mode only")
+            ys = F.ConvGroupFn.apply(g, conv.stride, conv.padding, isinstance(conv, ConvTranspose2d), *xs, *ws)
+            if ys[0].shape[0] * ys[0].shape[2] * ys[0].shape[3] <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(ys[0].shape)}")
+            xs = F.BatchNormActGroupFn.apply(g, bns[0].eps, bns[0].momentum, act, slope, *ys, *[b.weight for b in bns], *[b.bias for b in bns],
+                                             *[b.running_mean for b in bns], *[b.running_var for b in bns], *[b.num_batches_tracked for b in bns])
+        elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
+            xs = F.ConvC3GroupFn.apply(g, act, slope, *xs, *ws)                 # conv1 + LeakyReLU in one kernel
+        elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
+            xs = F.ConvTransposeC3GroupFn.apply(g, act, *xs, *ws)               # last convT + Sigmoid in one kernel
+        else:
+            xs = F.ConvGroupFn.apply(g, conv.stride, conv.padding, isinstance(conv, ConvTranspose2d), *xs, *ws)
+            if act_mod is not None:
+                xs = F.ActGroupFn.apply(g, act, slope, *xs)
+        xs = list(xs)
+        i = j + (1 if act_mod is not None else 0)
+    return xs
+
+
+def group_generators(nets, xs):
+    """[net(x) for net, x in zip(nets, xs)] for generators of one architecture, every layer as one grouped launch per kernel."""
+    if any(n_.main is not None for n_ in nets):
+        raise RuntimeError("grouped passes need the encoder / decoder form of the generators")
+    return _group_layers([list(n_.encoder) + list(n_.decoder) for n_ in nets], list(xs))
+
+
+def group_discriminators(nets, xs):
+    """[net(x) for ...] for discriminators of one architecture: list of (sigmoid output, feature maps).  A network may appear several
+    times (its real and its fake pass): those problems must be consecutive."""
+    g = len(xs)
+    d0 = nets[0]
+    hs = list(F.ConvC3GroupFn.apply(g, ops.ACT_LEAKY, d0.relu1.negative_slope, *xs, *[d.conv1.weight for d in nets]))
+    feats = [[] for _ in range(g)]
+    for i in range(2, d0.n_stages + 1):
+        convs = [getattr(d, f"conv{i}") for d in nets]
+        bns = [getattr(d, f"bn{i}") for d in nets]
+        if not all(b.training for b in bns):
+            raise RuntimeError("grouped passes run BatchNorm in training mode only")
+        ys = F.ConvGroupFn.apply(g, convs[0].stride, convs[0].padding, False, *hs, *[c.weight for c in convs])
+        hs = list(F.BatchNormActGroupFn.apply(g, bns[0].eps, bns[0].momentum, ops.ACT_LEAKY, getattr(d0, f"relu{i}").negative_slope, *ys,
+                                              *[b.weight for b in bns], *[b.bias for b in bns], *[b.running_mean for b in bns],
+                                              *[b.running_var for b in bns], *[b.num_batches_tracked for b in bns]))
+        for k in range(g):
+            feats[k].append(hs[k])
+    heads = [getattr(d, f"conv{d0.n_stages + 1}") for d in nets]
+    ys = F.ConvGroupFn.apply(g, heads[0].stride, heads[0].padding, False, *hs, *[c.weight for c in heads])
+    outs = F.ActGroupFn.apply(g, ops.ACT_SIGMOID, 0.0, *ys)
+    return [(outs[k], feats[k]) for k in range(g)]
+
+
 class Discriminator(_FlatGradMixin, nn.Module):
     """Reference model.py:5-69.  Returns ``(sigmoid [N,1,1,1], [relu2, ..., relu_n])``."""
 

@@ -31,8 +31,9 @@ class Context:
     context of its forward and runs its backward under it (functional._fwd / _bwd), so two trainers with different arithmetic can be
     interleaved call by call in one process."""
 
-    def __init__(self, prec=None, shadow=False, act16=False, x3=False):
+    def __init__(self, prec=None, shadow=False, act16=False, x3=False, group_plan="launch"):
         self.prec = prec
+        self.group_plan = group_plan           # grouped conv launches: split-K planned for the whole "launch" or per "single" problem
         self.shadow, self.act16, self.x3 = bool(shadow), bool(act16), bool(x3)
         self.shadow_tab, self.plane_tab = {}, {}
 
@@ -504,9 +505,9 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
     ho, wo = _out_hw(h, wd, stride, pad)
     L = _lib.load()
     prec = _CUR.cprec
-    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec), x.device)
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec, 1), x.device)
     rows = L.dg_conv_bnstats_rows_p(0, n, h, wd, c, k, stride, pad, prec) if want_stats else 0
-    if want_stats == "split" and L.dg_conv_plan_splits_p(0, n, h, wd, c, k, stride, pad, prec) <= 1:
+    if want_stats == "split" and L.dg_conv_plan_splits_p(0, n, h, wd, c, k, stride, pad, prec, 1) <= 1:
         rows = 0                      # statistics only where the split-K reduction kernel can emit them
     code = L.dg_conv_x3_planes_ok(0, n, h, wd, c, k, stride, pad) if (_CUR.x3 and k > 1) else 0
     if _plane_code_ok(code):
@@ -548,7 +549,7 @@ def conv_fwd(x, w, stride, pad, want_stats=False):
                        "dg_conv_fwd_mixed")
         else:       # the fp32-tensor form: arithmetic = this context's, passed with the call
             stat = torch.empty((rows, 3 * k + 4), device=x.device, dtype=torch.float32) if rows > 0 else None
-            _lib.check(L.dg_conv_fwd_g(1, _tab([x]), _tab([w]), _tab([y]), n, h, wd, c, k, stride, pad, prec, _tab([stat]) if rows > 0 else None,
+            _lib.check(L.dg_conv_fwd_g(1, _tab([x]), _tab([w]), _tab([y]), n, h, wd, c, k, stride, pad, prec, 1, _tab([stat]) if rows > 0 else None,
                                        stat.numel() if rows > 0 else 0, _tab([ws]), wsb, _stream()), "dg_conv_fwd_g")
     return (y, stat) if want_stats else y
 
@@ -565,9 +566,9 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
     h, wd = x_hw
     L = _lib.load()
     prec = _CUR.cprec
-    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec), dy.device)
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec, 1), dy.device)
     rows = L.dg_conv_bnstats_rows_p(1, n, h, wd, c, k, stride, pad, prec) if want_stats else 0
-    if want_stats == "split" and L.dg_conv_plan_splits_p(1, n, h, wd, c, k, stride, pad, prec) <= 1:
+    if want_stats == "split" and L.dg_conv_plan_splits_p(1, n, h, wd, c, k, stride, pad, prec, 1) <= 1:
         rows = 0
     if _x3_ok(1, n, h, wd, c, k, stride, pad):
         dp, dd, dcm = planes_of(dy, allow_cm=L.dg_conv_x3_planes_ok(1, n, h, wd, c, k, stride, pad) == 2)
@@ -605,7 +606,7 @@ def conv_dgrad(dy, w, x_hw, stride, pad, want_stats=False):
                        "dg_conv_dgrad_mixed")
         else:
             stat = torch.empty((rows, 3 * c + 4), device=dy.device, dtype=torch.float32) if rows > 0 else None
-            _lib.check(L.dg_conv_dgrad_g(1, _tab([dy]), _tab([w]), _tab([dx]), n, h, wd, c, k, stride, pad, prec, _tab([stat]) if rows > 0 else None,
+            _lib.check(L.dg_conv_dgrad_g(1, _tab([dy]), _tab([w]), _tab([dx]), n, h, wd, c, k, stride, pad, prec, 1, _tab([stat]) if rows > 0 else None,
                                          stat.numel() if rows > 0 else 0, _tab([ws]), wsb, _stream()), "dg_conv_dgrad_g")
     return (dx, stat) if want_stats else dx
 
@@ -650,7 +651,7 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
     dw = out if out is not None else empty_krsc(k, c, x.device)
     L = _lib.load()
     prec = _CUR.cprec
-    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec), x.device)
+    ws, wsb = _ws(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec, 1), x.device)
     if _x3_ok(2, n, h, wd, c, k, stride, pad):
         dp, dd, dcm = planes_of(dy, allow_cm=True)
         xp, xd, _ = planes_of(x)
@@ -674,7 +675,7 @@ def conv_wgrad(dy, x, stride, pad, out=None, accumulate=False):
             _lib.check(L.dg_conv_wgrad_mixed(_ptr(da), d16, _ptr(xa), x16, _ptr(dw), n, h, wd, c, k,
                                              stride, pad, int(accumulate), _ptr(ws), wsb, _stream()), "dg_conv_wgrad_mixed")
         else:
-            _lib.check(L.dg_conv_wgrad_g(1, 1, _tab([dy]), _tab([x]), _tab([dw]), n, h, wd, c, k, stride, pad, prec, int(accumulate),
+            _lib.check(L.dg_conv_wgrad_g(1, 1, _tab([dy]), _tab([x]), _tab([dw]), n, h, wd, c, k, stride, pad, prec, 1, int(accumulate),
                                          _tab([ws]), wsb, _stream()), "dg_conv_wgrad_g")
     return dw
 
@@ -1058,6 +1059,12 @@ def group_ok():
     return not (_CUR.shadow or _CUR.act16 or _CUR.x3)
 
 
+def _plan_groups(g):
+    """Split-K plan of a grouped conv launch: sized for the whole launch (the group fills the chip: fewer K-slabs per problem), or --
+    Context.group_plan == "single" -- for every problem as if launched alone (bitwise the ungrouped numbers; tests)."""
+    return 1 if getattr(_CUR, "group_plan", "launch") == "single" else g
+
+
 def _same_shape(ts, who):
     for t in ts[1:]:
         if t.shape != ts[0].shape:
@@ -1099,10 +1106,11 @@ def conv_fwd_g(xs, ws_, stride, pad):
     ho, wo = _out_hw(h, wd, stride, pad)
     L = _lib.load()
     prec = _CUR.cprec
-    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec), g, xs[0].device)
+    pg = _plan_groups(g)
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(0, n, h, wd, c, k, stride, pad, prec, pg), g, xs[0].device)
     ys = [empty_nhwc(n, k, ho, wo, xs[0].device) for _ in range(g)]
     with _prof("conv_fwd" if k > 1 else "head1", 2.0 * g * n * ho * wo * k * c * 16):
-        _lib.check(L.dg_conv_fwd_g(g, _tab(xs), _tab(ws_), _tab(ys), n, h, wd, c, k, stride, pad, prec, None, 0, _tab(wsl), wsb, _stream()),
+        _lib.check(L.dg_conv_fwd_g(g, _tab(xs), _tab(ws_), _tab(ys), n, h, wd, c, k, stride, pad, prec, pg, None, 0, _tab(wsl), wsb, _stream()),
                    "dg_conv_fwd_g")
     return ys
 
@@ -1119,10 +1127,11 @@ def conv_dgrad_g(dys, ws_, x_hw, stride, pad):
     h, wd = x_hw
     L = _lib.load()
     prec = _CUR.cprec
-    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec), g, dys[0].device)
+    pg = _plan_groups(g)
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(1, n, h, wd, c, k, stride, pad, prec, pg), g, dys[0].device)
     dxs = [empty_nhwc(n, c, h, wd, dys[0].device) for _ in range(g)]
     with _prof("conv_dgrad" if k > 1 else "head1", 2.0 * g * n * dys[0].shape[2] * dys[0].shape[3] * k * c * 16):
-        _lib.check(L.dg_conv_dgrad_g(g, _tab(dys), _tab(ws_), _tab(dxs), n, h, wd, c, k, stride, pad, prec, None, 0, _tab(wsl), wsb, _stream()),
+        _lib.check(L.dg_conv_dgrad_g(g, _tab(dys), _tab(ws_), _tab(dxs), n, h, wd, c, k, stride, pad, prec, pg, None, 0, _tab(wsl), wsb, _stream()),
                    "dg_conv_dgrad_g")
     return dxs
 
@@ -1140,9 +1149,10 @@ def conv_wgrad_g(dys, xs, stride, pad, outs, accumulate, share=1):
     k = dys[0].shape[1]
     L = _lib.load()
     prec = _CUR.cprec
-    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec), g, xs[0].device)
+    pg = _plan_groups(g)
+    wsl, wsb = _ws_g(L.dg_conv_workspace_bytes_p(2, n, h, wd, c, k, stride, pad, prec, pg), g, xs[0].device)
     with _prof("conv_wgrad" if k > 1 else "head1", 2.0 * g * n * dys[0].shape[2] * dys[0].shape[3] * k * c * 16):
-        _lib.check(L.dg_conv_wgrad_g(g, int(share), _tab(dys), _tab(xs), _tab(outs), n, h, wd, c, k, stride, pad, prec, int(accumulate),
+        _lib.check(L.dg_conv_wgrad_g(g, int(share), _tab(dys), _tab(xs), _tab(outs), n, h, wd, c, k, stride, pad, prec, pg, int(accumulate),
                                      _tab(wsl), wsb, _stream()), "dg_conv_wgrad_g")
 
 

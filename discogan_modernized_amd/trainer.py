@@ -54,7 +54,7 @@ class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
                  use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
                  cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
-                 bucket_mb=128.0, act_dtype="f32", x3_planes=None):
+                 bucket_mb=128.0, act_dtype="f32", x3_planes=None, group_launch=None, group_plan="launch"):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
             if not hasattr(self.args, k):
@@ -138,6 +138,34 @@ class DiscoGANTrainer:
         if self.x3_planes:
             self.optim_gen.enable_x3_planes()
             self.optim_dis.enable_x3_planes()
+        # The arithmetic and operand forms of THIS trainer's calls: an ops.Context handed to every op with the call (the conv
+        # arithmetic is an argument of the C ABI: DG_PREC_*), never a process-wide switch -- two trainers with different arithmetic
+        # can be interleaved call by call (tests/test_group_gpu.py::test_interleaved_trainers_with_different_arithmetic).
+        from . import ops as _ops
+        self.ctx = _ops.Context(prec={"f32": _ops.PREC_F32, "bf16": _ops.PREC_BF16, "f32x3": _ops.PREC_F32X3}[mfma_dtype],
+                                shadow=self.bf16_shadow, act16=self.act_dtype == "bf16", x3=self.x3_planes, group_plan=group_plan)
+        # Grouped launches (round 4): the A-side / B-side pass of every pair of the iteration (image_translation.py:342-346,353-361)
+        # goes out as ONE launch per kernel, and in a D-step each discriminator layer's real and fake pass of both sides as one
+        # launch over four problems (same weights fetched once per launch; BatchNorm statistics / feature maps per pass).  Bitwise
+        # equal to the ungrouped schedule (tests/test_group_gpu.py).  None = where it pays: below 256 px, where the launches are
+        # tens of microseconds (64 px / batch 64: ~500 launches per iteration, a third of them under 6 us), on the arithmetics
+        # whose operands are plain fp32 tensors (exact fp32, register-staged f32x3) and the symmetric `discogan` architecture.
+        # group_plan "launch" (default): the split-K plan of a grouped conv is sized for all its problems together -- fewer slabs per
+        # problem, another (fixed) summation order; "single": every problem keeps the plan of its own launch = bitwise the
+        # ungrouped step (test_grouped_training_step_is_bitwise_the_ungrouped_one).
+        can_group = (mfma_dtype == "f32" or (mfma_dtype == "f32x3" and not self.x3_planes)) and act_dtype == "f32" and \
+            self.args.model_arch == "discogan" and skip_dead_work and not async_wgrad and not mfma_turns and not skew_steps and not cu_partition
+        # Measured, same box, 64 px, images/s ungrouped -> grouped (tools/ab_group_64.sh): batch 64 12.7 k -> 14.6 k (f32), 15.4 k -> 17.4 k
+        # (f32x3); batch 128 16.6 k -> 17.7 k, 21.5 k -> 22.0 k; batch 256 19.3 k -> 19.4 k, 25.7 k -> 24.5 k: with 4x the rows per launch the
+        # two-chain schedule's overlap of one chain's BatchNorm under the other's conv is worth more than the saved launches.  So the
+        # automatic mode groups a batch of up to group_max_pixels = 128 x 64 x 64 image pixels per domain (decided per call).
+        self._group_auto = group_launch is None
+        self.group_max_pixels = 128 * 64 * 64
+        if group_launch is None:
+            group_launch = can_group and image_size < 256
+        if group_launch and not can_group:
+            raise ValueError("group_launch needs mfma_dtype f32 (or f32x3 without planes), act_dtype f32, model_arch discogan, skip_dead_work")
+        self.group_launch = bool(group_launch)
         self.cu_partition = cu_partition if two_streams else None
         self.part_main = None
         if self.cu_partition:
@@ -221,6 +249,8 @@ class DiscoGANTrainer:
     def forward_losses(self, A, B, iters, need_losses=True):
         """image_translation.py:342-382.  need_losses=False (D-steps only): the reconstruction passes ABA / BAB and their
         MSE terms feed nothing but the log line in a D-step, so they are not computed (recon_loss_* read NaN)."""
+        if self.group_launch and (not self._group_auto or A.shape[0] * A.shape[2] * A.shape[3] <= self.group_max_pixels):
+            return self._forward_losses_grouped(A, B, iters, need_losses)
         a = self.args
         dstep = self.is_dis_step(iters)
         skip = self.skip_dead_work
@@ -350,6 +380,74 @@ class DiscoGANTrainer:
             A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
             A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
 
+    def _forward_losses_grouped(self, A, B, iters, need_losses=True):
+        """image_translation.py:342-382 with every pair of passes as grouped launches (model.group_generators /
+        group_discriminators).  Main stream: G_A(B) | G_B(A), then G_A(AB) | G_B(BA) + the two reconstruction terms; side stream
+        (from the hand-over of AB / BA on): the discriminator passes + GAN / feature-matching terms -- D-step: D_A(A) | D_A(BA) |
+        D_B(B) | D_B(AB) as ONE group of four, G-step: the real pair without an autograd graph, then the fake pair."""
+        from .model import group_discriminators, group_generators
+        a = self.args
+        dstep = self.is_dis_step(iters)
+        gen_ctx = torch.no_grad if dstep else torch.enable_grad
+        main = torch.cuda.current_stream(self.device)
+        side = self.side_stream if self.two_streams else main
+        on_side = (lambda: torch.cuda.stream(side)) if self.two_streams else contextlib.nullcontext
+        gA, gB, dA, dB = self.generator_A, self.generator_B, self.discriminator_A, self.discriminator_B
+        nfm = dA.n_stages - 1
+        lv = torch.empty(8 + 2 * nfm, device=self.device, dtype=torch.float32)
+        sl = [lv[i] for i in range(8 + 2 * nfm)]
+        terms = {}
+        F_.FINAL_PASS = True        # the backward of these two passes is the last to touch each generator's parameters
+        try:
+            with gen_ctx():
+                BA, AB = group_generators([gA, gB], [B, A])
+        finally:
+            F_.FINAL_PASS = False
+        if self._ev_dis_ready is not None:                   # D parameters updated on the communication stream
+            main.wait_event(self._ev_dis_ready)
+            self._ev_dis_ready = None
+        if self.two_streams:
+            side.wait_stream(main)
+            for t_ in (A, B, lv, AB, BA):
+                t_.record_stream(side)
+        want_recon = need_losses or not dstep
+        ABA = BAB = None
+        if want_recon:
+            with gen_ctx():
+                ABA, BAB = group_generators([gA, gB], [AB, BA])
+                terms[0], terms[1] = F_.MSELossGroupFn.apply(2, ABA, BAB, A, B, sl[0], sl[1])
+        else:
+            lv[:2].fill_(float("nan"))
+            terms[0], terms[1] = sl[0], sl[1]
+        with on_side():
+            if dstep:
+                (A_dis_real, A_feats_real), (A_dis_fake, A_feats_fake), (B_dis_real, B_feats_real), (B_dis_fake, B_feats_fake) = \
+                    group_discriminators([dA, dA, dB, dB], [A, BA, B, AB])
+            else:
+                with torch.no_grad():
+                    (A_dis_real, A_feats_real), (B_dis_real, B_feats_real) = group_discriminators([dA, dB], [A, B])
+                (A_dis_fake, A_feats_fake), (B_dis_fake, B_feats_fake) = group_discriminators([dA, dB], [BA, AB])
+            # GAN terms (image_translation.py:157-166): slots 2 / 5 bce(real, 1), 4 / 7 bce(fake, 1), 3 / 6 bce(fake, 0)
+            terms[2], terms[4], terms[5], terms[7] = F_.BCELossGroupFn.apply(
+                4, (1.0, 1.0, 1.0, 1.0), A_dis_real, A_dis_fake, B_dis_real, B_dis_fake, sl[2], sl[4], sl[5], sl[7])
+            terms[3], terms[6] = F_.BCELossGroupFn.apply(2, (0.0, 0.0), A_dis_fake, B_dis_fake, sl[3], sl[6])
+            for l in range(nfm):
+                terms[8 + l], terms[8 + nfm + l] = F_.FeatureMatchGroupFn.apply(
+                    2, A_feats_real[l], B_feats_real[l], A_feats_fake[l], B_feats_fake[l], sl[8 + l], sl[8 + nfm + l])
+        if self.two_streams:
+            main.wait_stream(side)
+        rate = self.rate(iters)
+        fmA, fmB = list(range(8, 8 + nfm)), list(range(8 + nfm, 8 + 2 * nfm))
+        which, idx = (7, (2, 3, 5, 6)) if dstep else (6, tuple([0, 1, 4, 7] + fmA + fmB))
+        (gen_loss_A, gen_loss_B, fm_loss_A, fm_loss_B, dis_loss_A, dis_loss_B, gen_loss, dis_loss) = \
+            F_.LossMixFn.apply(lv, nfm, rate, 0, which, idx, *[terms[i] for i in idx])
+        return SimpleNamespace(
+            gen_loss=gen_loss, dis_loss=dis_loss, gen_loss_A=gen_loss_A, gen_loss_B=gen_loss_B,
+            fm_loss_A=fm_loss_A, fm_loss_B=fm_loss_B, recon_loss_A=terms[0], recon_loss_B=terms[1],
+            dis_loss_A=dis_loss_A, dis_loss_B=dis_loss_B, AB=AB, BA=BA, ABA=ABA, BAB=BAB,
+            A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
+            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
+
     def _fwd_bwd(self, A, B, iters, need_losses=True):
         dstep = self.is_dis_step(iters)
         self._set_requires_grad(dstep)
@@ -366,27 +464,18 @@ class DiscoGANTrainer:
         from . import ops as _ops
         _F.WGRAD_STREAM = self.wgrad_stream
         _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
-        from . import _lib as _l
-        if self.mfma_dtype != "f32":
-            _l.set_option("bf16", 1 if self.mfma_dtype == "bf16" else 2)
-        _ops.SHADOW = self.bf16_shadow
-        _ops.ACT16 = self.act_dtype == "bf16"
-        _ops.X3 = self.x3_planes
-        _ops.shadow_clear()
-        _ops.planes_clear()
+        # (the attributes may have been switched between iterations: tests run one trainer in several arithmetics)
+        self.ctx.prec = {"f32": _ops.PREC_F32, "bf16": _ops.PREC_BF16, "f32x3": _ops.PREC_F32X3}[self.mfma_dtype]
+        self.ctx.shadow, self.ctx.act16, self.ctx.x3 = bool(self.bf16_shadow), self.act_dtype == "bf16", bool(self.x3_planes)
+        self.ctx.clear()
         try:
-            out = self.forward_losses(A, B, iters, need_losses)
-            (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
+            with _ops.use(self.ctx):           # this trainer's arithmetic / operand forms ride with every call
+                out = self.forward_losses(A, B, iters, need_losses)
+                (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             _F.WGRAD_STREAM = None
             _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
-            _ops.SHADOW = False
-            _ops.ACT16 = False
-            _ops.X3 = False
-            _ops.shadow_clear()
-            _ops.planes_clear()
-            if self.mfma_dtype != "f32":
-                _l.set_option("bf16", 0)          # the library default stays exact fp32 for everyone else
+            self.ctx.clear()
         if self.skip_dead_work and not dstep:
             for p in self.optim_dis.params:               # a G-step froze the D parameters: give them back
                 p.requires_grad_(True)

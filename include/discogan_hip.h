@@ -110,16 +110,19 @@ int dg_conv_wgrad(const float* dy, const float* x, float* dw, int N, int H, int 
 
 /* Grouped forms with the arithmetic as an argument.  stat (may be NULL): fused BatchNorm partial statistics, one buffer of
  * dg_conv_bnstats_rows_p(...) x (3 * columns + 4) floats per problem; ws: one workspace of ws_bytes >= dg_conv_workspace_bytes_p(...)
- * per problem (NULL entries allowed when that is 0).  dg_conv_wgrad_g: share > 1 = every `share` consecutive problems name the same dw. */
-size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
+ * per problem (NULL entries allowed when that is 0).  dg_conv_wgrad_g: share > 1 = every `share` consecutive problems name the same dw.
+ * plan_groups: 1 = every problem gets the split-K plan of a launch of its own (results bitwise those of the one-problem call);
+ * `groups` = the plan is sized for the whole launch -- the group fills the chip, so each problem is cut into fewer K-slabs (less slab
+ * traffic, shorter reduction): the same products in another, equally fixed, summation order. */
+size_t dg_conv_workspace_bytes_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec, int plan_groups);
 int dg_conv_bnstats_rows_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
-int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec);
+int dg_conv_plan_splits_p(int op, int N, int H, int W, int C, int K, int stride, int pad, int prec, int plan_groups);
 int dg_conv_fwd_g(int groups, const float* const* x, const float* const* w, float* const* y, int N, int H, int W, int C, int K, int stride,
-                  int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
+                  int pad, int prec, int plan_groups, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_dgrad_g(int groups, const float* const* dy, const float* const* w, float* const* dx, int N, int H, int W, int C, int K, int stride,
-                    int pad, int prec, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
+                    int pad, int prec, int plan_groups, float* const* stat, size_t stat_floats, void* const* ws, size_t ws_bytes, dg_stream_t stream);
 int dg_conv_wgrad_g(int groups, int share, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W, int C, int K,
-                    int stride, int pad, int prec, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream);
+                    int stride, int pad, int prec, int plan_groups, int accumulate, void* const* ws, size_t ws_bytes, dg_stream_t stream);
 
 /* Inference path (inference.py:149,172-187: generator.eval() forward): [Conv2d | ConvTranspose2d] -> BatchNorm2d(eval)
  * -> LeakyReLU/ReLU as ONE kernel.  The caller folds the BatchNorm scale into the weights (w * gamma*invstd per output
