@@ -23,6 +23,7 @@ _l = C.c_int64
 # name -> (restype, argtypes); mirrors include/discogan_hip.h one to one
 SIGNATURES = {
     "dg_version": (_i, []),
+    "dg_build_flags": (_i, []),
     "dg_last_error": (C.c_char_p, []),
     "dg_set_option": (_i, [C.c_char_p, _i]),
     "dg_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
@@ -93,8 +94,6 @@ SIGNATURES = {
     "dg_fm_fwd": (_i, [_p, _p, _i, _z, _p, _p, _p, _z, _p]),
     "dg_fm_bwd": (_i, [_p, _i, _z, _p, _p, _p, _p]),
     "dg_debug_igemm_stamps": (_i, [_p, _z]),
-    "dg_stream_create_cu_mask": (_i, [_p, _i, _p]),
-    "dg_stream_destroy": (_i, [_p]),
     "dg_device_cu_count": (_i, []),
     "dg_loss_mix_fwd": (_i, [_p, _p, _i, _f, _i, _p]),
     "dg_loss_mix_bwd": (_i, [_p, _p, _i, _f, _i, _i, _p]),

@@ -1323,11 +1323,13 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         }
         // forward with <= 128 output channels: the input window of one (chunk, parity class) in LDS, re-used by the class's four taps
         // (igemm_dma_x3_fww.hip); whole output rows per 256-pixel tile, transposed weight planes; no split-K
+#ifdef DG_EXPERIMENTS      // the window forward kernel: not faster than the register-staged tiles, experiments library only
         else if (allow_fww && pl->mode == MODE_FWD && g.stride == 2 && g.pad == 1 && g.K <= 128 && g.K % 8 == 0 && g.C % 16 == 0 && g.Wo >= 32 &&
                  g.Wo <= 128 && (g.Ho * g.Wo) % 256 == 0 && dg_get_option(DG_OPT_DMA_MFMA) != 1) {
             pl->dma = 5;
             pl->ncls = 4;
         }
+#endif
     }
     const int BM = pl->dma == 2 ? 128 * pl->wm : (pl->dma ? 256 : 64 * pl->wm);
     const int BN = pl->dma == 2 ? 64 * pl->wn : (pl->dma >= 3 ? a.Ng : (pl->dma ? 256 : 64 * pl->wn));
@@ -1380,10 +1382,12 @@ static void launch_igemm_bf16(const IgemmArgs& a, int zmul, hipStream_t st) {
         if (!a.a16 && a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, false, true>), grid, dim3(256), 0, st, a); return; }
         if (a.a16 && !a.b16) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 1, true, false>), grid, dim3(256), 0, st, a); return; }
     }
+#ifdef DG_EXPERIMENTS      // the register-staged plane reader: measured 45 % slower, experiments library only
     if constexpr (PREC == 2 && MODE == MODE_FWD && WM == 2 && WN == 2) {
         // both operands as plane triples (a16 = b16 = 3): the loader copies the planes, no split in the kernel
         if (a.a16 == 3 && a.b16 == 3) { hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, 2, true, true>), grid, dim3(256), 0, st, a); return; }
     }
+#endif
     hipLaunchKernelGGL((igemm_kernel<MODE, WM, WN, KT, true, PREC>), grid, dim3(256), 0, st, a);
 }
 
@@ -1412,8 +1416,11 @@ static int run_plan(const char* who, Plan& pl, void* ws, size_t ws_bytes, hipStr
     const int nout = ngrp / (a.share > 1 ? a.share : 1);      // outputs of the split-K reduction (share: problems summed into one tensor)
     if (pl.dma && ngrp > 1) return dg_fail(DG_ERR_INVALID, "%s: the LDS-DMA kernels take no grouped launch", who);
     if (pl.dma) {
-        const int ok = pl.dma == 5 ? dg_igemm_x3_fww_launch(a, st)
-                     : pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
+        const int ok =
+#ifdef DG_EXPERIMENTS
+                       pl.dma == 5 ? dg_igemm_x3_fww_launch(a, st) :
+#endif
+                       pl.dma == 4 ? dg_igemm_bf16_dgw_launch(pl.ncls, a, st)
                      : pl.dma == 3 ? dg_igemm_x3_dgw_launch(pl.ncls, a, st)
                      : pl.dma == 2 ? dg_igemm_dma_x3_launch(pl.mode, pl.wm, pl.wn, a, zmul, st) : dg_igemm_dma_launch(pl.mode, a, zmul, st);
         if (!ok) return dg_fail(DG_ERR_INVALID, "%s: no LDS-DMA kernel for mode %d", who, pl.mode);
@@ -1723,6 +1730,9 @@ extern "C" int dg_conv_bf16_operands_ok(int op, int N, int H, int W, int C, int 
 // forward, stride 2, no LDS-DMA plane kernel for the shape (fewer than 192 output channels or rows): the register-staged 128 x 128
 // tiles can read plane triples (16-byte granules of 8 bf16: C % 8 == 0; buffer-descriptor kernels only)
 static bool x3_register_staged_planes_ok(int op, const ConvGeom& g, const Plan& pl) {
+#ifndef DG_EXPERIMENTS
+    return false;           // (the plane-reading register-staged tiles exist in the experiments library only)
+#endif
     return op == 0 && g.stride == 2 && pl.a.prec == 2 && pl.mode == MODE_FWD && pl.wm == 2 && pl.wn == 2 && pl.kt == 16 && g.C % 16 == 0 &&
            pl.a.abytes != 0 && pl.a.bbytes != 0;
 }

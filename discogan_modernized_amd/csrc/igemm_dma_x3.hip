@@ -689,8 +689,11 @@ int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmu
     // weight-grad on 256 -> 512 and 512 -> 1024 channels, +0..1.8 % on 1024 -> 2048 (256 K-tiles per workgroup each), -1..-3 % on
     // 128 -> 256 and -12 % on the forward of 2048 -> 2048 @ 8 (128 K-tiles per workgroup) in isolated launches -- and NOTHING in the
     // whole step (284.2 / 283.4 images/s with 32, 282.6 with 16, 283.1 / 281.9 with 16 on the long K loops only): DESIGN.md 3.1
+    // (built in the experiments library only: make EXPERIMENTS=1 -- the product library has ONE body per tile)
+#ifdef DG_EXPERIMENTS
     const int body = dg_get_option(DG_OPT_X3_MFMA) == 16 ? 16 : 32;
     if (wm == 2 && wn == 4 && body == 16) return x3_launch_tile<2, 4, 3, true>(mode, a, grid, st);
+#endif
     if (wm == 2 && wn == 4) return x3_launch_tile<2, 4, 2, false>(mode, a, grid, st);
     if (wm == 1 && wn == 4 && mode == MODE_WGRAD) {
         hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4, 2>), dim3(grid), dim3(256), 0, st, a);

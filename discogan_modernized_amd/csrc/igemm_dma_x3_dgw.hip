@@ -432,7 +432,13 @@ int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) ncu = -1;
         else ncu = prop.multiProcessorCount;
     }
+    // (built in the experiments library only: make EXPERIMENTS=1)
+#ifdef DG_EXPERIMENTS
     const bool persist = dg_get_option(DG_OPT_DGW_PERSIST) == 1 && ncu > 0 && nblocks > ncu && a.stamps == nullptr;
+#else
+    const bool persist = false;
+#endif
+#ifdef DG_EXPERIMENTS
     if (persist) {
         const int grid = ncu & ~7 ? (ncu & ~7) : ncu;       // a multiple of 8: a workgroup's tiles stay on its XCD's share
         if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4, true>), dim3(grid), dim3(512), 0, st, a, nblocks);
@@ -440,6 +446,8 @@ int dg_igemm_x3_dgw_launch(int ncls, const IgemmArgs& a, hipStream_t st) {
         else return 0;
         return 1;
     }
+#endif
+    (void)persist;
     if (ncls == 4) hipLaunchKernelGGL((igemm_x3_dgw_kernel<4, false>), dim3(nblocks), dim3(512), 0, st, a, nblocks);
     else if (ncls == 2) hipLaunchKernelGGL((igemm_x3_dgw_kernel<2, false>), dim3(nblocks), dim3(512), 0, st, a, nblocks);
     else return 0;

@@ -24,6 +24,18 @@ DgPlanScope::DgPlanScope(int plan_groups) : old(tl_plan_groups) { tl_plan_groups
 DgPlanScope::~DgPlanScope() { tl_plan_groups = old; }
 
 extern "C" int dg_version(void) { return 100; }
+// bit 0: the experiments build (kernels that lost their A/B: window forward kernel, register-staged plane reader, persistent window
+// input-grad, paired-plane 16x16x32 body); bit 1: the timing build (operand-dropping switch).  The product library returns 0.
+extern "C" int dg_build_flags(void) {
+    int f = 0;
+#ifdef DG_EXPERIMENTS
+    f |= 1;
+#endif
+#ifdef DG_TIMING_KNOBS
+    f |= 2;
+#endif
+    return f;
+}
 extern "C" const char* dg_last_error(void) { return dg_err_buf; }
 extern "C" int dg_set_option(const char* name, int value) {
     if (!name) return dg_fail(DG_ERR_INVALID, "dg_set_option: null name");
@@ -40,28 +52,16 @@ extern "C" int dg_set_option(const char* name, int value) {
 #endif
     else if (!strcmp(name, "no_dma")) g_options[DG_OPT_NO_DMA] = value;   // 1: bf16-operand convs stay on the register-staged tiles (igemm.hip) instead of the LDS-DMA kernel
     else if (!strcmp(name, "dma_mfma")) g_options[DG_OPT_DMA_MFMA] = value;   // 32: the LDS-DMA kernel's 32x32x16 body instead of 16x16x32; 1: no window kernels (A/B)
+#ifdef DG_EXPERIMENTS
+    // experiments library only (make EXPERIMENTS=1): kernels that were built, verified and measured not faster
     else if (!strcmp(name, "x3_mfma")) g_options[DG_OPT_X3_MFMA] = value;   // 16: the f32x3 plane kernel's 16x16x32 body (planes paired along k) instead of 32x32x16
-    else if (!strcmp(name, "dgw_persist")) g_options[DG_OPT_DGW_PERSIST] = value;   // 1: the f32x3 window input-grad kernel as one persistent workgroup per CU (measured not faster)
+    else if (!strcmp(name, "dgw_persist")) g_options[DG_OPT_DGW_PERSIST] = value;   // 1: the f32x3 window input-grad kernel as one persistent workgroup per CU
+#endif
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)
     else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);
     return DG_OK;
 }
 
-// HIP streams restricted to a subset of the compute units (one bit per CU, 32 per word).  The trainer gives
-// each of its two independent network chains half of the chip (trainer.py: cu_partition).
-extern "C" int dg_stream_create_cu_mask(const uint32_t* mask, int nwords, dg_stream_t* out) {
-    if (!mask || nwords < 1 || !out) return dg_fail(DG_ERR_INVALID, "dg_stream_create_cu_mask: bad argument");
-    hipStream_t s = nullptr;
-    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
-    if (e != hipSuccess) return dg_fail(DG_ERR_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-    *out = (dg_stream_t)s;
-    return DG_OK;
-}
-extern "C" int dg_stream_destroy(dg_stream_t s) {
-    hipError_t e = hipStreamDestroy((hipStream_t)s);
-    if (e != hipSuccess) return dg_fail(DG_ERR_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
-    return DG_OK;
-}
 extern "C" int dg_device_cu_count(void) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;

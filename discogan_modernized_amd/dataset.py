@@ -263,7 +263,7 @@ def write_shard(filenames, out_path, workers=8):
 
 
 class ShardSource:
-    """Memory-mapped uint8 [n, H, W, 3] shard(s): ``fetch(i, dst)`` copies image i into a (pinned) staging row."""
+    """Memory-mapped uint8 [n, H, W, 3] shard(s): ``load(i)`` returns image i (a view of the mapped file)."""
 
     def __init__(self, paths):
         self.arrays = [np.load(p, mmap_mode="r") for p in ([paths] if isinstance(paths, (str, os.PathLike)) else paths)]
@@ -276,36 +276,45 @@ class ShardSource:
     def __len__(self):
         return int(self.offsets[-1])
 
-    def fetch(self, i, dst):
+    def load(self, i):
         k = int(np.searchsorted(self.offsets, i, side="right") - 1)
-        dst[...] = self.arrays[k][i - self.offsets[k]]
+        return self.arrays[k][i - self.offsets[k]]
+
+    def fetch(self, i, dst):
+        dst[...] = self.load(i)
 
 
 class FileSource:
-    """Image files decoded on demand (PIL); every image must have the size of the first one (edges2*: 256 x 512, celebA: 218 x 178)."""
+    """Image files decoded on demand (PIL).  Sizes may differ from file to file -- the reference resizes every image on its own
+    (dataset.py:61,246) -- and a file that cannot be decoded is reported and REPLACED, like the reference's dataset class does
+    (dataset.py:255-258: message + a uniform random image of the output size): ``load`` returns None for it."""
 
     def __init__(self, paths):
         self.paths = list(paths)
-        self.shape = decode_rgb(self.paths[0]).shape
 
     def __len__(self):
         return len(self.paths)
 
     def fetch(self, i, dst):
-        im = decode_rgb(self.paths[i])
-        if im.shape != self.shape:
-            raise ValueError(f"{self.paths[i]}: size {im.shape} differs from the dataset's {self.shape}; use read_images for mixed sizes")
-        dst[...] = im
+        dst[...] = decode_rgb(self.paths[i])
+
+    def load(self, i):
+        try:
+            return decode_rgb(self.paths[i])
+        except Exception as e:      # noqa: BLE001
+            print(f"image load failed: {self.paths[i]}: {e} -- a random image takes its place (dataset.py:255-258)")
+            return None
 
 
 class DeviceLoader:
     """One epoch of (A, B) float device batches from two sources (FileSource / ShardSource), given the epoch's index batches.
 
-    Stage k+1 (decode / gather into pinned uint8 memory by a thread pool, H2D on the copy stream, dg_image_prep on the copy
-    stream) runs while the caller trains on stage k; two staging slots per domain.  The consumer's stream waits on the
-    slot's event before it reads the batch, and the copy stream waits on the consumer's release event before it overwrites
-    the slot's tensors (reference: DataLoader(num_workers=4, pin_memory=True) + ``.to(device)``,
-    distributed_image_translation.py:209-216,462-463)."""
+    Stage k+1 (decode / gather by a thread pool, pack into pinned uint8 memory grouped by image size, ONE H2D copy per domain on the
+    copy stream, one dg_image_prep launch per image size) runs while the caller trains on stage k; two staging slots per domain.
+    The consumer's stream waits on the slot's event before it reads the batch, and the copy stream waits on the consumer's release
+    event before it overwrites the slot's tensors (reference: DataLoader(num_workers=4, pin_memory=True) + ``.to(device)``,
+    distributed_image_translation.py:209-216,462-463).  An exception in the background stage (a domain rule that does not fit an
+    image, a copy or kernel error) is re-raised in the consumer before the failed batch could be yielded -- never a stale batch."""
 
     def __init__(self, source_A, source_B, domains, image_size, batches, device="cuda", workers=4, transform=None):
         self.src = (source_A, source_B)
@@ -323,9 +332,11 @@ class DeviceLoader:
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = []
         for _ in range(2):
-            slot = dict(ready=None, released=None, out=[None, None])
-            slot["pinned"] = [torch.empty((self.bmax,) + tuple(s.shape), dtype=torch.uint8).pin_memory() for s in self.src]
-            slot["dev_u8"] = [torch.empty((self.bmax,) + tuple(s.shape), dtype=torch.uint8, device=self.device) for s in self.src]
+            slot = dict(ready=None, released=None, out=[None, None], error=None)
+            # staging bytes grow on demand (image sizes are only known once decoded); shards know theirs
+            cap = [self.bmax * int(np.prod(getattr(s, "shape", (0,)))) for s in self.src]
+            slot["pinned"] = [torch.empty(max(c, 1), dtype=torch.uint8).pin_memory() for c in cap]
+            slot["dev_u8"] = [torch.empty(max(c, 1), dtype=torch.uint8, device=self.device) for c in cap]
             slot["dev_f32"] = [torch.empty((self.bmax, 3, self.S, self.S), dtype=torch.float32, device=self.device) for _ in self.src]
             self.slots.append(slot)
 
@@ -334,26 +345,61 @@ class DeviceLoader:
 
     def _stage(self, k):
         slot = self.slots[k % 2]
+        try:
+            self._stage_impl(k, slot)
+        except BaseException as e:      # noqa: BLE001 -- handed to the consumer, which re-raises it (see __iter__)
+            slot["error"] = e
+
+    def _stage_impl(self, k, slot):
         if slot["ready"] is not None:
             slot["ready"].synchronize()                  # the slot's previous H2D copy has left the pinned rows (host-side wait)
+        # a failed stage must never be mistaken for a finished one: the slot holds nothing until this stage completes
+        slot["ready"], slot["out"], slot["error"] = None, [None, None], None
         torch.cuda.set_device(self.device)               # (worker thread: the current device is per thread)
-        futs = []
+        futs = [[self.pool.submit(self.src[d].load, int(i)) for i in self.batches[k][d]] for d in range(2)]
+        imgs = [[f.result() for f in fd] for fd in futs]          # decode / gather finished
+        plans = []
         for d in range(2):
-            idx = self.batches[k][d]
-            rows = slot["pinned"][d].numpy()
-            futs += [self.pool.submit(self.src[d].fetch, int(i), rows[j]) for j, i in enumerate(idx)]
-        for f in futs:
-            f.result()                                   # decode / gather finished: the pinned rows are complete
+            groups = {}                                  # image size -> positions in the batch, in order
+            for j, im in enumerate(imgs[d]):
+                if im is not None:
+                    if im.ndim != 3 or im.shape[2] != 3 or im.dtype != np.uint8:
+                        raise ValueError(f"decoded image must be uint8 [H, W, 3], got {im.dtype} {im.shape}")
+                    groups.setdefault(im.shape, []).append(j)
+            need = sum(len(pos) * int(np.prod(shape)) for shape, pos in groups.items())
+            if need > slot["pinned"][d].numel():
+                slot["pinned"][d] = torch.empty(need, dtype=torch.uint8).pin_memory()
+                slot["dev_u8"][d] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            rows, off, plan = slot["pinned"][d].numpy(), 0, []
+            for shape, pos in groups.items():
+                per = int(np.prod(shape))
+                view = rows[off:off + len(pos) * per].reshape((len(pos),) + shape)
+                for r, j in enumerate(pos):
+                    view[r] = imgs[d][j]
+                plan.append((shape, pos, off))
+                off += len(pos) * per
+            plans.append((plan, off, [j for j, im in enumerate(imgs[d]) if im is None]))
         with torch.cuda.stream(self.copy_stream):
             if slot["released"] is not None:             # the consumer of this slot's previous batch has finished reading
                 self.copy_stream.wait_event(slot["released"])
             for d in range(2):
                 n = len(self.batches[k][d])
-                slot["dev_u8"][d][:n].copy_(slot["pinned"][d][:n], non_blocking=True)
-                out = prepare_batch(slot["dev_u8"][d][:n], self.domains[d], self.S, out=slot["dev_f32"][d][:n])
+                plan, used, missing = plans[d]
+                out = slot["dev_f32"][d][:n]
+                if used:
+                    slot["dev_u8"][d][:used].copy_(slot["pinned"][d][:used], non_blocking=True)
+                for shape, pos, off in plan:             # one launch per image size (a batch of one size: one launch, in place)
+                    src = slot["dev_u8"][d][off:off + len(pos) * int(np.prod(shape))].view((len(pos),) + shape)
+                    if len(pos) == n:
+                        prepare_batch(src, self.domains[d], self.S, out=out)
+                    else:
+                        out[torch.tensor(pos, device=self.device)] = prepare_batch(src, self.domains[d], self.S)
+                for j in missing:                        # unreadable file: the reference substitutes np.random.rand(3, S, S)
+                    out[j].copy_(torch.from_numpy(np.random.rand(3, self.S, self.S).astype(np.float32)))
                 slot["out"][d] = self.transform(out) if self.transform else out
-            slot["ready"] = torch.cuda.Event()
-            slot["ready"].record(self.copy_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            slot["ready"] = ev
 
     def __iter__(self):
         if not self.batches:
@@ -362,6 +408,9 @@ class DeviceLoader:
         self._stage(0)
         for k in range(len(self.batches)):
             slot = self.slots[k % 2]
+            if slot["error"] is not None:                # the stage of THIS batch failed (in the background thread for k >= 1)
+                err, slot["error"] = slot["error"], None
+                raise err
             if k + 1 < len(self.batches):                # stage the next batch in the background while this one trains
                 stager = threading.Thread(target=self._stage, args=(k + 1,), daemon=True)
                 stager.start()

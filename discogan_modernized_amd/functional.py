@@ -58,29 +58,6 @@ def _final(ctx_flag, *params):
             FINAL_HOOK(p)
 
 
-# Auxiliary HIP stream for weight-gradient kernels (set by the trainer).  dgrad feeds the next BN-backward
-# on the chain's own stream; wgrad only feeds Adam at the end of the iteration, so it is launched on this
-# stream behind an event and fills the matrix pipes while the chain runs its HBM-bound BN-backward kernels.
-WGRAD_STREAM = None
-
-
-def _launch_wgrad(fn, *tensors):
-    """Run fn() (a wgrad that accumulates into the flat gradient buffer) on WGRAD_STREAM, after the work
-    already queued on the current stream; keeps the tensors it reads alive for that stream."""
-    aux = WGRAD_STREAM
-    if aux is None:
-        fn()
-        return
-    cur = torch.cuda.current_stream()
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    aux.wait_event(ev)
-    with torch.cuda.stream(aux):
-        fn()
-    for t in tensors:
-        t.record_stream(aux)
-
-
 def _release_unless_wgrad(ctx, x):
     """Forward of an interior conv: the layer input's bf16 shadow / plane triple is read again only by this layer's weight
     gradient.  No weight gradient coming (no_grad generator passes of a D-step, frozen discriminators of a G-step) -> the
@@ -90,10 +67,8 @@ def _release_unless_wgrad(ctx, x):
 
 
 def _release_after_backward(dy, x):
-    """Backward of an interior conv: input-grad and weight-grad were the last readers of dy's and x's derived copies (with
-    the weight gradient on a third stream the copies stay until the trainer clears the tables)."""
-    if WGRAD_STREAM is None:
-        ops.derived_release(dy, x)
+    """Backward of an interior conv: input-grad and weight-grad were the last readers of dy's and x's derived copies."""
+    ops.derived_release(dy, x)
 
 
 class ConvFn(Function):
@@ -133,7 +108,7 @@ class ConvFn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
-                _launch_wgrad(lambda: ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True), dy, x)
+                ops.conv_wgrad(dy, x, stride, pad, out=fg, accumulate=True)
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(dy, x, stride, pad)
@@ -183,7 +158,7 @@ class ConvTransposeFn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None:
-                _launch_wgrad(lambda: ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True), dy, x)
+                ops.conv_wgrad(x, dy, stride, pad, out=fg, accumulate=True)
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.conv_wgrad(x, dy, stride, pad)
@@ -220,7 +195,7 @@ class ConvC3Fn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
-                _launch_wgrad(lambda: ops.c3_wgrad(g, x, out=fg, accumulate=True, **fuse), g, x)
+                ops.c3_wgrad(g, x, out=fg, accumulate=True, **fuse)
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.c3_wgrad(g, x, **fuse)
@@ -249,7 +224,7 @@ class ConvTransposeC3Fn(Function):
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)
             if fg is not None and fg.is_contiguous():
-                _launch_wgrad(lambda: ops.c3_wgrad(x, g, out=fg, accumulate=True), g, x)
+                ops.c3_wgrad(x, g, out=fg, accumulate=True)
                 _final(ctx.final, ctx.wref)
             else:
                 dw = ops.c3_wgrad(x, g)

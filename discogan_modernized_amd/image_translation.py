@@ -154,10 +154,14 @@ def open_data(args, device, rank=0, world_size=1):
         elif getattr(args, "shard_A", None) and getattr(args, "shard_B", None):
             src = "shards"
         else:
-            try:
+            # the synthetic stand-in is for the bare command line on a machine without datasets ONLY: a run that names its data
+            # (--data_root, --style_A / --style_B / --constraint) or whose dataset root exists raises what the reference raises
+            # (a mistyped style: KeyError, an empty directory: ValueError, a wrong root: FileNotFoundError) instead of training on noise
+            named = any(getattr(args, k, None) for k in ("data_root", "style_A", "style_B", "constraint"))
+            if named or os.path.isdir(getattr(args, "data_root", None) or "./datasets"):
                 ds.get_data(args)
                 src = "files"
-            except (FileNotFoundError, ValueError, KeyError, TypeError):
+            else:
                 src = "synthetic"
     domains = ds.task_domains(args.task_name)
     workers = getattr(args, "loader_workers", 4)

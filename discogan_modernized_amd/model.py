@@ -308,8 +308,18 @@ def _run_fused_steps(layers, x):
 # group_discriminators run ``g`` such passes -- different networks of the same architecture, or the same network on different inputs
 # -- layer by layer with ONE launch per kernel for all of them (functional.*GroupFn -> ops.*_g -> dg_*_g).  Training mode, fp32
 # tensors, exact-fp32 or register-staged f32x3 arithmetic (ops.group_ok()); results per pass are bitwise those of net(x).
+def _fire_forward_hooks(records):
+    """Forward hooks registered on the fused modules (BatchNorm2d, the first Conv2d: tests/kink_probe.py records activation patterns
+    through them) see the same calls as in the one-pass form: problem by problem, layer by layer -- the order net(x) would have fired them."""
+    for rec in records:
+        for mod, inp, out in rec:
+            for hook in list(mod._forward_hooks.values()):
+                hook(mod, (inp,), out)
+
+
 def _group_layers(layer_lists, xs):
     g, n = len(xs), len(layer_lists[0])
+    records = [[] for _ in range(g)]
     i = 0
     while i < n:
         convs = [L[i] for L in layer_lists]
@@ -329,8 +339,13 @@ def _group_layers(layer_lists, xs):
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(ys[0].shape)}")
             xs = F.BatchNormActGroupFn.apply(g, bns[0].eps, bns[0].momentum, act, slope, *ys, *[b.weight for b in bns], *[b.bias for b in bns],
                                              *[b.running_mean for b in bns], *[b.running_var for b in bns], *[b.num_batches_tracked for b in bns])
+            for k in range(g):
+                records[k].append((bns[k], ys[k], xs[k]))
         elif isinstance(conv, Conv2d) and conv.in_channels == 3 and act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
+            ins = xs
             xs = F.ConvC3GroupFn.apply(g, act, slope, *xs, *ws)                 # conv1 + LeakyReLU in one kernel
+            for k in range(g):
+                records[k].append((convs[k], ins[k], xs[k]))
         elif isinstance(conv, ConvTranspose2d) and conv.out_channels == 3 and act in (ops.ACT_SIGMOID, ops.ACT_NONE):
             xs = F.ConvTransposeC3GroupFn.apply(g, act, *xs, *ws)               # last convT + Sigmoid in one kernel
         else:
@@ -339,6 +354,7 @@ def _group_layers(layer_lists, xs):
                 xs = F.ActGroupFn.apply(g, act, slope, *xs)
         xs = list(xs)
         i = j + (1 if act_mod is not None else 0)
+    _fire_forward_hooks(records)
     return xs
 
 
@@ -356,6 +372,7 @@ def group_discriminators(nets, xs):
     d0 = nets[0]
     hs = list(F.ConvC3GroupFn.apply(g, ops.ACT_LEAKY, d0.relu1.negative_slope, *xs, *[d.conv1.weight for d in nets]))
     feats = [[] for _ in range(g)]
+    records = [[(nets[k].conv1, xs[k], hs[k])] for k in range(g)]
     for i in range(2, d0.n_stages + 1):
         convs = [getattr(d, f"conv{i}") for d in nets]
         bns = [getattr(d, f"bn{i}") for d in nets]
@@ -367,9 +384,11 @@ def group_discriminators(nets, xs):
                                               *[b.running_var for b in bns], *[b.num_batches_tracked for b in bns]))
         for k in range(g):
             feats[k].append(hs[k])
+            records[k].append((bns[k], ys[k], hs[k]))
     heads = [getattr(d, f"conv{d0.n_stages + 1}") for d in nets]
     ys = F.ConvGroupFn.apply(g, heads[0].stride, heads[0].padding, False, *hs, *[c.weight for c in heads])
     outs = F.ActGroupFn.apply(g, ops.ACT_SIGMOID, 0.0, *ys)
+    _fire_forward_hooks(records)
     return [(outs[k], feats[k]) for k in range(g)]
 
 

@@ -76,35 +76,15 @@ class use:
 PROFILE = None
 
 
-class _MfmaTurns:
-    """Cross-stream turn taking for the MFMA-bound conv kernels.  The trainer issues its two independent network
-    chains layer by layer in lock step on two HIP streams; with ``enabled`` every big conv launch first waits for
-    the previous big conv launch of the OTHER stream, so the chains alternate on the matrix cores
-    (A.conv_l | B.conv_l | A.conv_l+1 ...) and each chain's HBM-bound BatchNorm / reduction kernels run under the
-    other chain's conv instead of both chains idling the matrix cores at the same time."""
-    enabled = False
-    event = None
-    stream = None
-    min_flops = 1e9
-
-
-TURNS = _MfmaTurns()
-
-
 class _prof:
     def __init__(self, name, flops):
         self.on = PROFILE is not None
-        self.turn = TURNS.enabled and flops >= TURNS.min_flops
         if self.on:
             self.name, self.flops = name, flops
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
-        if self.turn:
-            cur = torch.cuda.current_stream()
-            if TURNS.event is not None and TURNS.stream != cur:
-                cur.wait_event(TURNS.event)
         if self.on:
             self.e0.record()
         return self
@@ -113,11 +93,6 @@ class _prof:
         if self.on:
             self.e1.record()
             PROFILE.append((self.name, self.flops, self.e0, self.e1))
-        if self.turn:
-            cur = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            TURNS.event, TURNS.stream = ev, cur
         return False
 
 
@@ -1350,6 +1325,14 @@ class _OpsModule(_types.ModuleType):
     @ACT16.setter
     def ACT16(self, v):
         _CUR.act16 = bool(v)
+
+    @property
+    def _PLANE_TAB(self):           # (the current context's tables, under their pre-round-4 names: op tests look into them)
+        return _CUR.plane_tab
+
+    @property
+    def _SHADOW_TAB(self):
+        return _CUR.shadow_tab
 
     @property
     def X3(self):

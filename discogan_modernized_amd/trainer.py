@@ -52,8 +52,7 @@ def default_args(**over):
 
 class DiscoGANTrainer:
     def __init__(self, args=None, device="cuda", image_size=64, seed=1234, process_group=None,
-                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, async_wgrad=False,
-                 cu_partition=None, mfma_turns=False, skew_steps=0, mfma_dtype="f32", comm="auto",
+                 use_graph=False, skip_dead_work=True, two_streams=True, overlap_comm=None, mfma_dtype="f32", comm="auto",
                  bucket_mb=128.0, act_dtype="f32", x3_planes=None, group_launch=None, group_plan="launch"):
         self.args = args or default_args()
         for k, v in DEFAULTS.items():
@@ -99,12 +98,9 @@ class DiscoGANTrainer:
         # stream, which keeps its two calls per iteration (and its BN running-stat updates) ordered.
         self.two_streams = two_streams
         self.side_stream = torch.cuda.Stream(device=self.device) if two_streams else None
-        # cu_partition: give each chain its own half of the compute units (CU-masked HIP streams) instead of
-        # letting two full-chip queues time-slice.  "xcd": XCDs 0-3 | 4-7, "half": CUs 0-127 | 128-255.
-        # mfma_turns: the chains take turns on the matrix cores (ops.TURNS).  Measured SLOWER (15.5 vs 14.1 ms at
-        # 64 px / batch 256: a cross-queue event per conv costs more than the overlap it buys) -> off.
-        self.mfma_turns = bool(mfma_turns) and two_streams
-        self.skew_steps = int(skew_steps)
+        # (Round 1-2 experiments on top of the two streams -- CU-masked streams per chain, turn taking on the matrix cores, a phase skew
+        # between the chains, weight gradients on a third stream -- all measured slower or equal and were
+        # removed in round 4.)
         # mfma_dtype "bf16": the interior conv GEMMs round their operands to bf16 and run on the bf16 matrix path
         # with fp32 accumulation (BASELINE configs[4]); tensors, BatchNorm, losses, master weights, Adam stay fp32.
         # "f32x3": fp32-accurate products on the bf16 matrix path -- every operand is split into three bf16 planes
@@ -154,7 +150,7 @@ class DiscoGANTrainer:
         # problem, another (fixed) summation order; "single": every problem keeps the plan of its own launch = bitwise the
         # ungrouped step (test_grouped_training_step_is_bitwise_the_ungrouped_one).
         can_group = (mfma_dtype == "f32" or (mfma_dtype == "f32x3" and not self.x3_planes)) and act_dtype == "f32" and \
-            self.args.model_arch == "discogan" and skip_dead_work and not async_wgrad and not mfma_turns and not skew_steps and not cu_partition
+            self.args.model_arch == "discogan" and skip_dead_work
         # Measured, same box, 64 px, images/s ungrouped -> grouped (tools/ab_group_64.sh): batch 64 12.7 k -> 14.6 k (f32), 15.4 k -> 17.4 k
         # (f32x3); batch 128 16.6 k -> 17.7 k, 21.5 k -> 22.0 k; batch 256 19.3 k -> 19.4 k, 25.7 k -> 24.5 k: with 4x the rows per launch the
         # two-chain schedule's overlap of one chain's BatchNorm under the other's conv is worth more than the saved launches.  So the
@@ -166,16 +162,7 @@ class DiscoGANTrainer:
         if group_launch and not can_group:
             raise ValueError("group_launch needs mfma_dtype f32 (or f32x3 without planes), act_dtype f32, model_arch discogan, skip_dead_work")
         self.group_launch = bool(group_launch)
-        self.cu_partition = cu_partition if two_streams else None
-        self.part_main = None
-        if self.cu_partition:
-            self.side_stream, self.part_main = self._masked_streams(self.cu_partition)
-            self.use_graph = False                        # hipGraph kernel nodes do not carry a CU mask
         self._one = torch.ones((), device=self.device, dtype=torch.float32)
-        # optional: weight-gradient kernels on a third stream (functional.WGRAD_STREAM), off the backward
-        # critical path.  Bitwise neutral; measured 15.04 vs 14.80 ms/step (eager, 64 px) -> off by default.
-        self.async_wgrad = bool(async_wgrad)
-        self.wgrad_stream = torch.cuda.Stream(device=self.device) if async_wgrad else None
         # Data-parallel exchange overlap: after a D-step the all-reduce of the D gradients and the D Adam
         # step run on a communication stream while the NEXT iteration's generator passes run; the
         # discriminator passes wait on the event.  (A G-step's update is needed by the very next kernel,
@@ -197,27 +184,6 @@ class DiscoGANTrainer:
         # pass through its layers has been issued (functional.FINAL_HOOK), while the rest of the backward runs.
         self._buckets = _GradBuckets(self, bucket_mb) if self.overlap_comm else None
         self._eager_until = self.args.update_interval      # first cycle runs eagerly (warm-up)
-
-    def _masked_streams(self, mode):
-        import ctypes
-        from . import _lib
-        lib = _lib.load()
-        ncu = lib.dg_device_cu_count()
-        nw = (ncu + 31) // 32
-        if mode == "xcd":          # CU index i sits on XCD i % 8
-            lo = [0x0F0F0F0F] * nw
-        elif mode == "half":
-            lo = [0xFFFFFFFF if w < nw // 2 else 0 for w in range(nw)]
-        else:
-            raise ValueError(f"cu_partition must be 'xcd' or 'half', got {mode!r}")
-        hi = [(~w) & 0xFFFFFFFF for w in lo]
-        streams = []
-        for words in (lo, hi):
-            arr = (ctypes.c_uint32 * nw)(*words)
-            h = ctypes.c_void_p()
-            _lib.check(lib.dg_stream_create_cu_mask(arr, nw, ctypes.byref(h)), "dg_stream_create_cu_mask")
-            streams.append(torch.cuda.ExternalStream(h.value, device=self.device))
-        return streams
 
     # ---------------------------------------------------------------------------------------------
     def active_ranges(self, dstep):
@@ -269,15 +235,11 @@ class DiscoGANTrainer:
             for t_ in (A, B, lv):
                 t_.record_stream(side)
         # The A-side chain (G_A, D_A) is issued on `side`, the B-side chain (G_B, D_B) on `main`, layer by layer
-        # in lock step (model.forward_steps): host issue order A.l1, B.l1, A.l2, B.l2, ...  With ops.TURNS the big
-        # conv kernels then alternate between the streams and each chain's BatchNorm / reduction kernels run
-        # under the other chain's conv.  autograd replays nodes in reverse creation order, so the backward pass
-        # is interleaved the same way.
-        skew = self.two_streams and self.skew_steps > 0
+        # in lock step (model.forward_steps): host issue order A.l1, B.l1, A.l2, B.l2, ...  autograd replays nodes in reverse
+        # creation order, so the backward pass is interleaved the same way.
 
         def pair(gen_a, gen_b):
             ra = rb = pend = object()
-            k = 0
             while ra is pend or rb is pend:
                 if ra is pend:
                     with on_side():
@@ -285,13 +247,6 @@ class DiscoGANTrainer:
                             next(gen_a)
                         except StopIteration as e:
                             ra = e.value
-                k += 1
-                if skew and k == self.skew_steps:
-                    # hold the B chain back by the A chain's first step(s): the chains are symmetric, so without
-                    # this they run in phase (both in conv, then both in BatchNorm with idle matrix cores)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    main.wait_event(ev)
                 if rb is pend:
                     try:
                         next(gen_b)
@@ -460,10 +415,7 @@ class DiscoGANTrainer:
         else:
             self.optim_gen.zero_grad()                   # image_translation.py:336-339
             self.optim_dis.zero_grad()
-        from . import functional as _F
         from . import ops as _ops
-        _F.WGRAD_STREAM = self.wgrad_stream
-        _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = self.mfma_turns, None, None
         # (the attributes may have been switched between iterations: tests run one trainer in several arithmetics)
         self.ctx.prec = {"f32": _ops.PREC_F32, "bf16": _ops.PREC_BF16, "f32x3": _ops.PREC_F32X3}[self.mfma_dtype]
         self.ctx.shadow, self.ctx.act16, self.ctx.x3 = bool(self.bf16_shadow), self.act_dtype == "bf16", bool(self.x3_planes)
@@ -473,14 +425,10 @@ class DiscoGANTrainer:
                 out = self.forward_losses(A, B, iters, need_losses)
                 (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
-            _F.WGRAD_STREAM = None
-            _ops.TURNS.enabled, _ops.TURNS.event, _ops.TURNS.stream = False, None, None
             self.ctx.clear()
         if self.skip_dead_work and not dstep:
             for p in self.optim_dis.params:               # a G-step froze the D parameters: give them back
                 p.requires_grad_(True)
-        if self.async_wgrad and self.wgrad_stream is not None:      # (bench.py's instrumented single-stream pass takes the stream away)
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         if self.two_streams:
             # the backward kernels of the A-side chain ran on the side stream and wrote the flat gradient
             # buffer directly (no AccumulateGrad leaf for autograd to sync): join before Adam / all-reduce
@@ -530,16 +478,9 @@ class DiscoGANTrainer:
         """One full iteration; returns the namespace of (device) loss scalars.  need_losses=False tells the
         trainer that this iteration's loss values will not be read (no log line): a D-step then skips the two
         reconstruction passes, which feed only the log (weights and optimiser state are unaffected)."""
-        if self.part_main is not None and torch.cuda.current_stream(self.device) != self.part_main:
-            caller = torch.cuda.current_stream(self.device)
-            self.part_main.wait_stream(caller)
-            with torch.cuda.stream(self.part_main):
-                out = self.train_iteration(A, B, iters, do_step, need_losses)
-            caller.wait_stream(self.part_main)
-            return out
         dstep = self.is_dis_step(iters)
         opt = self.optim_dis if dstep else self.optim_gen
-        bucketed = self._buckets is not None and not dstep and do_step and self.xg is not None and not self.async_wgrad
+        bucketed = self._buckets is not None and not dstep and do_step and self.xg is not None
         if self.time_comm:
             self.comm_steps["D" if dstep else "G"] += 1
         if bucketed:

@@ -66,6 +66,9 @@ typedef void* dg_stream_t;
 #define DG_MAX_GROUPS 4
 
 int dg_version(void);
+/* 0 = the product library.  bit 0: experiments build (csrc/Makefile EXPERIMENTS=1: kernels that lost their A/B, behind options "x3_mfma",
+ * "dgw_persist" and the window-forward / plane-reader planner codes); bit 1: timing build (TIMING=1: option "dbg_zero"). */
+int dg_build_flags(void);
 const char* dg_last_error(void);
 
 /* ---- tuning knobs (process-global, for benchmarking and tests; 0 = heuristic) ----------------
@@ -82,10 +85,8 @@ const char* dg_last_error(void);
  * "no_dma" 1: convolutions with two bf16 operands stay on the register-staged tiles instead of the LDS-DMA kernel;
  * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one; 1: keep the input-grads with <= 128
  *   output channels on the register-staged tiles instead of the window kernels (same-box A/B);
- * "x3_mfma" 16: the f32x3 plane kernel's 256 x 256 tile on the 16x16x32 MFMA with the planes paired along k instead of the
- *   default 32x32x16 body (same products; measured not faster in the whole step);
- * "dgw_persist" 1: the f32x3 window input-grad kernel as one persistent workgroup per CU when there are more tiles than CUs (the
- *   next tile's first DMA is issued in front of the finished tile's epilogue; bit-identical, measured not faster);
+ * (experiments library only, csrc/Makefile EXPERIMENTS=1: "x3_mfma" 16 = the paired-plane 16x16x32 body of the f32x3 plane kernel,
+ *   "dgw_persist" 1 = the persistent form of the f32x3 window input-grad kernel -- both measured not faster);
  * (The operand-dropping timing switch of earlier rounds exists only in the separate timing build, csrc/Makefile TIMING=1; the product
  *   library has no option that changes results.) */
 int dg_set_option(const char* name, int value);
@@ -293,11 +294,7 @@ int dg_fm_bwd_g(int groups, const float* const* diff, int N, size_t J, const flo
  * (NULL, 0) switches it off.  wall = 100 MHz constant clock, cyc = shader clock. */
 int dg_debug_igemm_stamps(void* buf, size_t bytes);
 
-/* Streams restricted to a subset of the compute units (mask: one bit per CU, 32 per word): the host layer
- * runs its two independent network chains (G_A/D_A and G_B/D_B, image_translation.py:342-365) on disjoint
- * halves of the chip.  Host plumbing, no reference counterpart. */
-int dg_stream_create_cu_mask(const uint32_t* mask, int nwords, dg_stream_t* out);
-int dg_stream_destroy(dg_stream_t s);
+/* number of compute units of the current device (host planning aid) */
 int dg_device_cu_count(void);
 
 /* Curriculum loss mix (image_translation.py:162-166,367-382) over a vector of loss scalars, and the

@@ -16,6 +16,16 @@ from discogan_modernized_amd import _lib, ops  # noqa: E402
 DEV = "cuda"
 
 
+def experiments_built():
+    """The kernels that lost their same-box A/B (window forward kernel, register-staged plane reader, persistent window input-grad,
+    paired-plane 16x16x32 body) live in the experiments build of the library since round 4 (csrc/Makefile EXPERIMENTS=1); their tests
+    run when that build is the one loaded: DG_LIB=discogan_modernized_amd/libdiscogan_hip_experiments.so pytest -m gpu"""
+    return bool(_lib.load().dg_build_flags() & 1)
+
+
+needs_experiments = pytest.mark.skipif("not experiments_built()", reason="experiments library not loaded (make -C csrc EXPERIMENTS=1; DG_LIB=...)")
+
+
 def close(got, ref, rtol=1e-4, atol=1e-5, what=""):
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
@@ -284,7 +294,7 @@ X3_SHAPES = DMA_SHAPES + [
 
 @pytest.mark.parametrize("N,C,K,H", X3_SHAPES)
 @pytest.mark.parametrize("splitk", [0, 1, 3])
-@pytest.mark.parametrize("body", [32, 16])
+@pytest.mark.parametrize("body", [32, pytest.param(16, marks=[needs_experiments, pytest.mark.slow])])
 def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
     """body 16: the 256 x 256 tile on v_mfma_f32_16x16x32_bf16 with the planes PAIRED along k (option "x3_mfma" 16: the same six
     products, two per instruction, so a different summation order -- everything but the bit-identity with the register-staged
@@ -302,11 +312,13 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
     L = _lib.load()
     _lib.set_option("bf16", 2)
     _lib.set_option("splitk", splitk)
-    _lib.set_option("x3_mfma", body)
+    if body != 32:
+        _lib.set_option("x3_mfma", body)
     try:
         yreg, dxreg, dwreg = ops.conv_fwd(xg, wg, 2, 1), ops.conv_dgrad(dyg, wg, (H, H), 2, 1), ops.conv_wgrad(dyg, xg, 2, 1)
         M = N * (H // 2) ** 2
-        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == (1 if (K >= 192 and M >= 192) else 4)     # 4: register-staged tiles read the planes
+        # 4: register-staged tiles read the planes (experiments library; the product library: 0 = operands split in the kernel)
+        assert L.dg_conv_x3_planes_ok(0, N, H, H, C, K, 2, 1) == (1 if (K >= 192 and M >= 192) else (4 if experiments_built() else 0))
         assert L.dg_conv_x3_planes_ok(1, N, H, H, C, K, 2, 1) == int(C >= 192 and M >= 192)
         assert L.dg_conv_x3_planes_ok(2, N, H, H, C, K, 2, 1) == 1
         ops.X3 = True
@@ -332,7 +344,8 @@ def test_conv_f32x3_plane_kernel(N, C, K, H, splitk, body):
         ops.planes_clear()
         _lib.set_option("splitk", 0)
         _lib.set_option("bf16", 0)
-        _lib.set_option("x3_mfma", ops.X3_MFMA)
+        if body != 32:
+            _lib.set_option("x3_mfma", ops.X3_MFMA)
     close(y, y64.float(), what="plane conv fwd")
     close(dx, dx64.float(), rtol=2e-4, what="plane conv dgrad")
     close(dw, dw64.float(), rtol=2e-4, what="plane conv wgrad")
@@ -1070,6 +1083,8 @@ X3_FWW_SHAPES = [
 ]
 
 
+@needs_experiments
+@pytest.mark.slow
 @pytest.mark.parametrize("N,C,K,H", X3_FWW_SHAPES)
 def test_conv_f32x3_forward_window_kernel(N, C, K, H, monkeypatch):
     """Forward with few output channels on plane operands (csrc/igemm_dma_x3_fww.hip): the input window of one (16-channel chunk,
@@ -1233,6 +1248,8 @@ X3_RSP_SHAPES = [
 ]
 
 
+@needs_experiments
+@pytest.mark.slow
 @pytest.mark.parametrize("N,C,K,H", X3_RSP_SHAPES)
 @pytest.mark.parametrize("splitk", [0, 1])
 def test_conv_f32x3_register_staged_tiles_read_planes(N, C, K, H, splitk, monkeypatch):
@@ -1266,6 +1283,8 @@ def test_conv_f32x3_register_staged_tiles_read_planes(N, C, K, H, splitk, monkey
     assert torch.equal(y, yreg), "plane reader vs in-kernel split"
 
 
+@needs_experiments
+@pytest.mark.slow
 @pytest.mark.parametrize("N,C,K,H,splitk", [(8, 64, 128, 256, 0), (16, 128, 256, 128, 0), (40, 64, 64, 64, 2), (5, 40, 64, 256, 0)])
 def test_window_input_grad_persistent_workgroups(N, C, K, H, splitk):
     """Option "dgw_persist" 1, more tiles than CUs: the f32x3 window input-grad kernel runs ONE persistent workgroup per CU that walks
