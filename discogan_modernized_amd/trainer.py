@@ -254,40 +254,9 @@ class DiscoGANTrainer:
                         rb = e.value
             return ra, rb
 
-        # stage 1: the two first-stage translations are independent.  Their backward passes are the LAST ones to
-        # touch each generator's parameters (autograd replays in reverse), which the bucketed exchange keys on.
-        F_.FINAL_PASS = True
-        try:
-            with gen_ctx():
-                BA, AB = pair(self.generator_A.forward_steps(B), self.generator_B.forward_steps(A))
-        finally:
-            F_.FINAL_PASS = False
-        if self.two_streams:
-            AB.record_stream(side)
-            BA.record_stream(main)
-            ev_ab, ev_ba = torch.cuda.Event(), torch.cuda.Event()
-            ev_ab.record(main)
-            ev_ba.record(side)
-            side.wait_event(ev_ab)                           # G_A(AB) needs AB
-            main.wait_event(ev_ba)                           # G_B(BA) needs BA
-        if self._ev_dis_ready is not None:                   # D parameters updated on the comm stream
-            main.wait_event(self._ev_dis_ready)
-            if self.two_streams:
-                side.wait_event(self._ev_dis_ready)
-            self._ev_dis_ready = None
-        # stage 2 + discriminators.  Every loss term is written into its slot of one device vector (layout:
-        # dg_loss_mix_fwd); the mix and its gradient seeds are one launch each instead of ~45 scalar kernels.
         want_recon = need_losses or not (dstep and skip)
-        ABA = BAB = None
-        if want_recon:
-            with gen_ctx():
-                ABA, BAB = pair(self.generator_A.forward_steps(AB), self.generator_B.forward_steps(BA))
-        else:
-            lv[:2].fill_(float("nan"))
-        (A_dis_real, A_feats_real), (B_dis_real, B_feats_real) = pair(
-            self.discriminator_A.forward_steps(A), self.discriminator_B.forward_steps(B))
-        (A_dis_fake, A_feats_fake), (B_dis_fake, B_feats_fake) = pair(
-            self.discriminator_A.forward_steps(BA), self.discriminator_B.forward_steps(AB))
+        BA, AB, ABA, BAB, A_dis_real, A_feats_real, B_dis_real, B_feats_real, A_dis_fake, A_feats_fake, B_dis_fake, B_feats_fake = \
+            self._two_chain_forward(A, B, lv, pair, gen_ctx, main, side, want_recon)
         assert nfm == len(A_feats_real)
         sl = [lv[i] for i in range(8 + 2 * nfm)]
         terms = {}
@@ -334,6 +303,47 @@ class DiscoGANTrainer:
             dis_loss_A=dis_loss_A, dis_loss_B=dis_loss_B, AB=AB, BA=BA, ABA=ABA, BAB=BAB,
             A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
             A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
+
+    def _two_chain_forward(self, A, B, lv, pair, gen_ctx, main, side, want_recon):
+        """The symmetric two-chain order: G_A(B) | G_B(A), G_A(AB) | G_B(BA), D_A(A) | D_B(B), D_A(BA) | D_B(AB), each pair in lock step.
+        (Round 4 tried a DEPHASED order -- side: D_A(A), G_A(B), G_A(AB), D_A(BA); main: G_B(A), D_B(B), G_B(BA), D_B(AB) -- so that one
+        chain's HBM-bound BatchNorm kernels would meet the other chain's conv kernels instead of its BatchNorm kernels: bitwise
+        neutral, and no faster: 295.0 / 293.9 -> 294.5 / 294.8 images/s (f32x3), 1014.9 -> 1002.8 (bf16), 194.2 -> 192.9 (f32) at
+        512 px / batch 32, same box, alternating, profiles/r04_ab_dephased_chain_order.txt.  Removed.)"""
+        # stage 1: the two first-stage translations are independent.  Their backward passes are the LAST ones to
+        # touch each generator's parameters (autograd replays in reverse), which the bucketed exchange keys on.
+        F_.FINAL_PASS = True
+        try:
+            with gen_ctx():
+                BA, AB = pair(self.generator_A.forward_steps(B), self.generator_B.forward_steps(A))
+        finally:
+            F_.FINAL_PASS = False
+        if self.two_streams:
+            AB.record_stream(side)
+            BA.record_stream(main)
+            ev_ab, ev_ba = torch.cuda.Event(), torch.cuda.Event()
+            ev_ab.record(main)
+            ev_ba.record(side)
+            side.wait_event(ev_ab)                           # G_A(AB) needs AB
+            main.wait_event(ev_ba)                           # G_B(BA) needs BA
+        if self._ev_dis_ready is not None:                   # D parameters updated on the comm stream
+            main.wait_event(self._ev_dis_ready)
+            if self.two_streams:
+                side.wait_event(self._ev_dis_ready)
+            self._ev_dis_ready = None
+        # stage 2 + discriminators.  Every loss term is written into its slot of one device vector (layout:
+        # dg_loss_mix_fwd); the mix and its gradient seeds are one launch each instead of ~45 scalar kernels.
+        ABA = BAB = None
+        if want_recon:
+            with gen_ctx():
+                ABA, BAB = pair(self.generator_A.forward_steps(AB), self.generator_B.forward_steps(BA))
+        else:
+            lv[:2].fill_(float("nan"))
+        (A_dis_real, A_feats_real), (B_dis_real, B_feats_real) = pair(
+            self.discriminator_A.forward_steps(A), self.discriminator_B.forward_steps(B))
+        (A_dis_fake, A_feats_fake), (B_dis_fake, B_feats_fake) = pair(
+            self.discriminator_A.forward_steps(BA), self.discriminator_B.forward_steps(AB))
+        return BA, AB, ABA, BAB, A_dis_real, A_feats_real, B_dis_real, B_feats_real, A_dis_fake, A_feats_fake, B_dis_fake, B_feats_fake
 
     def _forward_losses_grouped(self, A, B, iters, need_losses=True):
         """image_translation.py:342-382 with every pair of passes as grouped launches (model.group_generators /

@@ -82,6 +82,13 @@ def _masked64_grads(onet, masks, run):
 
 GRAD_ATOL_REL = 1e-4      # floor of the per-tensor gradient tolerance (relative L2)
 NOISE_MULT = 4            # x the reference's own fp32-vs-fp64 error on the same piecewise-linear function
+# 512 px / batch 2 only: DESIGN.md section 1 measured, for SIX summation orders of the same products (exact fp32 as shipped, 2 / 4 / 8 / 16
+# slabs, the f32x3 plane path), worst per-tensor ratios between 0.47 and 5.06 -- at batch 2 the generators' bottleneck BatchNorm normalises
+# over two samples and the discriminators' last one over 32, and ONE accumulation-noise draw entering there is propagated upstream amplified
+# 1e3-1e4 x (every tensor upstream of it carries the same ratio; the reference itself moves single tensors 4.6 x between 1 and 8 oneDNN
+# threads).  The written bound for that size is therefore 6 x, as DESIGN.md states it; batch 32 (the benchmark's) is pinned by the reference
+# fixtures at 2e-3 / 5e-3 of the tensor norm, and every smaller size keeps 4 x.
+NOISE_MULT_512_N2 = 6
 
 
 @pytest.mark.parametrize("S,N", [(16, 4), (64, 3)])
@@ -328,7 +335,7 @@ _NOISE_FIX = {}
 
 
 def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, need_noise=True, mfma_dtype="f32", rows_out=None,
-                    noise_cache=None, noise_key=None):
+                    noise_cache=None, noise_key=None, noise_mult=NOISE_MULT):
     """Every iteration starts from the ORACLE's current weights/buffers; gradients are compared with an fp64 run of
     the oracle that differentiates the SAME activation sign pattern the implementation used (tests/kink_probe.py),
     so no kink term is left and the bound is max(1e-4, 4 x the reference's own fp32 error).
@@ -380,7 +387,7 @@ def _teacher_forced(S, N, n_iters, tr=None, st=None, iter_list=None, step=True, 
                 if rows_out is not None:
                     rows_out.append(dict(iter=it, tensor=f"{name}.{pn}", numel=po_[pn].numel(), err_hip=e, err_reference_fp32=noise,
                                          ratio=e / max(noise, 1e-30)))
-                assert e < max(GRAD_ATOL_REL, NOISE_MULT * noise), \
+                assert e < max(GRAD_ATOL_REL, noise_mult * noise), \
                     f"iter {it} grad {name}.{pn}: rel err {e:.2e} vs fp64 on the same activation pattern (reference fp32: {noise:.2e})"
         flips = {k: sum(int((a.cpu() != b.cpu()).sum()) for a, b in zip(mh[k], m32[k])) for k in mh}
         table.append((it, "D" if dstep else "G", worst, flips))
@@ -447,13 +454,26 @@ def test_teacher_forced_iterations_512_f32x3():
     """The HEADLINE configuration's arithmetic (BASELINE configs[3] network: 512 px; mfma_dtype="f32x3" on plane operands,
     quad-chunk planes, plane-only BatchNorm outputs, fused statistics) teacher-forced through iterations 0..3 -- D, G, G, D,
     the post-Adam saturated-discriminator regime included -- at the bounds of the small sizes: losses 2e-4, D outputs 2e-3,
-    every gradient tensor within max(1e-4, 4 x the reference arithmetic's own fp32 error) of the fp64 oracle on the same
-    activation pattern, BatchNorm buffers, Adam op-wise (iterations 2-3 at 512 px)."""
+    BatchNorm buffers, Adam op-wise; every gradient tensor within max(1e-4, 6 x the reference arithmetic's own fp32 error) of the
+    fp64 oracle on the same activation pattern (NOISE_MULT_512_N2: the bound DESIGN.md section 1 writes for 512 px / batch 2; the
+    run's own worst ratios are printed and, with DG_TABLE_DIR, written out).  """
     tr = DiscoGANTrainer(default_args(), device=DEV, image_size=512, seed=1234, mfma_dtype="f32x3")
     assert tr.x3_planes
-    _teacher_forced(512, 2, 4, tr=tr, mfma_dtype="f32x3", noise_key="512x2")
+    rows = []
+    table = _teacher_forced(512, 2, 4, tr=tr, mfma_dtype="f32x3", noise_key="512x2", noise_mult=NOISE_MULT_512_N2, rows_out=rows)
     tr.close()
     torch.cuda.empty_cache()
+    # the margin of THIS run, for the next reader: worst ratio per iteration (and, with DG_TABLE_DIR set, every tensor's row)
+    summary = [dict(iter=it, step=kind, worst_err_hip=w[0], worst_err_reference_fp32=w[1], worst_ratio=w[2], bound=NOISE_MULT_512_N2)
+               for it, kind, w, _ in table]
+    print("512 px / batch 2, f32x3 plane path, teacher-forced: " + json.dumps(summary))
+    outdir = os.environ.get("DG_TABLE_DIR")
+    if outdir:
+        os.makedirs(outdir, exist_ok=True)
+        with open(os.path.join(outdir, "teacher_forced_512px_n2_f32x3_worst_ratio.json"), "w") as f:
+            json.dump(dict(note="error of every gradient tensor against fp64 on the implementation's own activation pattern / the reference "
+                                "arithmetic's own fp32 error (tests/golden/oracle_fp32_noise.json); bound = 6 x at this size (DESIGN.md section 1)",
+                           per_iteration=summary, per_tensor=rows), f, indent=1)
 
 
 def test_f32x3_plane_step_is_graph_neutral_and_deterministic():
