@@ -72,7 +72,7 @@ def parse(argv=None):
     ap.add_argument("--group_plan", default="launch", choices=["launch", "single"],
                     help="split-K plan of a grouped conv launch: sized for the whole launch (default) or per problem (bitwise the ungrouped step)")
     ap.add_argument("--comm", default="auto", choices=["auto", "capi", "c10d"], help="data-parallel transport (dp.ExchangeGroup)")
-    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off", "graph"],
                     help="data-parallel exchange overlapped with compute (eager dispatch) or behind a replayed hipGraph")
     a = ap.parse_args(argv)
     if a.batch_size is None:
@@ -296,7 +296,7 @@ def also_figures(a, head, extra):
 
 def make_trainer(a, dev, pg, image_size, mfma_dtype=None, graph=None, overlap=None, comm=None, act_dtype=None, group=None):
     from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args
-    ov = {"auto": None, "on": True, "off": False}[a.overlap] if overlap is None else overlap
+    ov = {"auto": None, "on": True, "off": False, "graph": "graph"}[a.overlap] if overlap is None else overlap
     kw = dict(device=dev, image_size=image_size, seed=1234, process_group=pg,
               use_graph=(not a.no_graph) if graph is None else graph, two_streams=not a.single_stream,
               mfma_dtype=mfma_dtype or a.mfma_dtype, overlap_comm=ov,
@@ -326,7 +326,8 @@ def measure(a, tr, A, B, batch, world, steps, warmup, roofline=True, split_cycle
     warmup = warmup + (phase - warmup) % ui
     dt, it = timed_run(tr, A, B, steps, warmup, world)
     res = dict(images_per_sec=round(batch * world * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
-               warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=bool(tr.overlap_comm), grouped_launches=bool(tr.group_launch))
+               warmup=warmup, hipgraph=bool(tr.use_graph), allreduce_overlap=("graph" if tr.graph_overlap else bool(tr.overlap_comm)),
+               grouped_launches=bool(tr.group_launch))
     live = LIVE_GFLOP_PER_IMAGE.get(image_size or tr.image_size)
     if live:
         res["whole_step_tflops"] = round(batch * steps / dt * live / 1e3, 2)
@@ -481,9 +482,12 @@ def main():
         # hipGraph replay + exchange behind it vs eager dispatch with the exchange overlapped
         side("64px_bs64_dp_graph_mode", 64, 64, 30, 9, mfma_dtype="f32", graph=True, overlap=False, comm="capi")
         side("64px_bs64_dp_eager_overlap_mode", 64, 64, 30, 9, mfma_dtype="f32", graph=False, overlap=True, comm="capi")
+        side("64px_bs64_dp_graph_overlap_mode", 64, 64, 30, 9, mfma_dtype="f32", graph=True, overlap="graph", comm="capi")
         extra["note_dp_modes"] = ("64 px / 64 per GPU (BASELINE configs[2] per-GPU shape) on ONE GPU with a 1-rank RCCL communicator: "
                                   "the exchange path runs for real, the collectives move nothing. Eager dispatch is host-bound at this "
-                                  "size, so data parallelism below 256 px defaults to graph replay + exchange behind it.")
+                                  "size; graph_overlap = the default of data-parallel runs below 256 px since round 4: the iteration replays as "
+                                  "a sequence of hipGraphs with gaps, D-step exchange + Adam under the next iteration's first graph, the "
+                                  "generators' decoder halves under the encoder half of the backward (trainer._SegCapture).")
         extra["note_side"] = ("side measurements, NOT the headline value; bf16 = conv operands rounded to bf16 on the bf16 MFMA path, fp32 "
                               "accumulate/BatchNorm/weights/Adam (configs[4] arithmetic); f32x3 = fp32-ACCURATE conv products on the bf16 "
                               "MFMA path: each fp32 operand split into three bf16 planes (24 significand bits; by the tensor's producer / once per tensor, "

@@ -358,11 +358,19 @@ def _group_layers(layer_lists, xs):
     return xs
 
 
-def group_generators(nets, xs):
-    """[net(x) for net, x in zip(nets, xs)] for generators of one architecture, every layer as one grouped launch per kernel."""
+def group_generators(nets, xs, cut_at_bottleneck=False):
+    """[net(x) for net, x in zip(nets, xs)] for generators of one architecture, every layer as one grouped launch per kernel.
+    cut_at_bottleneck: the autograd graph is CUT at the encoders' outputs (the [N, 100, 1, 1] bottleneck activations): the decoders run
+    on detached leaves; returns (outputs, encoder outputs, the leaves).  loss.backward() then stops at the leaves -- every decoder
+    gradient is complete -- and ``torch.autograd.backward(encoder outputs, [leaf.grad ...])`` continues through the encoders: the point
+    at which the trainer sends the decoder gradients off while the encoder half still runs (trainer.py, overlap_comm="graph")."""
     if any(n_.main is not None for n_ in nets):
         raise RuntimeError("grouped passes need the encoder / decoder form of the generators")
-    return _group_layers([list(n_.encoder) + list(n_.decoder) for n_ in nets], list(xs))
+    if not cut_at_bottleneck:
+        return _group_layers([list(n_.encoder) + list(n_.decoder) for n_ in nets], list(xs))
+    hs = _group_layers([list(n_.encoder) for n_ in nets], list(xs))
+    leaves = [h.detach().requires_grad_(True) for h in hs]
+    return _group_layers([list(n_.decoder) for n_ in nets], leaves), hs, leaves
 
 
 def group_discriminators(nets, xs):

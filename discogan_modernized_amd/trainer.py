@@ -172,11 +172,27 @@ class DiscoGANTrainer:
         # host-bound there (8.77 ms/step vs 4.86 under hipGraph replay), so the default for small images keeps the
         # captured graph and runs exchange + Adam behind it; from 256 px the kernels are long enough for eager
         # dispatch and the overlapped exchange is the default.
+        # overlap_comm="graph" (round 4; default for data-parallel runs below 256 px on the grouped schedule): the exchange overlaps
+        # UNDER hipGraph replay.  The iteration is captured as a SEQUENCE of graphs with host-side gaps between them (_SegCapture):
+        #   D-step: one graph; behind it all-reduce + Adam of the discriminators go to the communication stream and run under the
+        #           NEXT iteration's first graph (zero_grad + G_A(B) | G_B(A)), whose successor waits for them in the gap;
+        #   G-step: [zero_grad + stage-1 forward] gap(wait for the D update) [stage-2 + discriminator passes + losses + the backward pass
+        #           down to the stage-1 bottleneck] gap(all-reduce + Adam slices of both DECODERS leave on the communication stream)
+        #           [backward of the stage-1 encoders]; the encoders' all-reduce + Adam slices are the only exposed part.
+        # The backward is cut with two autograd calls (gradients w.r.t. the bottleneck activations, then from there): the kernels write
+        # the parameter gradients into the flat buffer as a side effect, so the first call completes every decoder gradient.
         if overlap_comm is None:
-            overlap_comm = self.world_size > 1 and image_size >= 256
-        self.overlap_comm = bool(overlap_comm) and skip_dead_work
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap_comm else None
+            overlap_comm = (True if image_size >= 256 else ("graph" if (self.group_launch and use_graph) else False)) if self.world_size > 1 else False
+        self.graph_overlap = overlap_comm == "graph"
+        if self.graph_overlap and not (self.group_launch and skip_dead_work):
+            raise ValueError("overlap_comm='graph' needs the grouped schedule (group_launch) and skip_dead_work")
+        self.overlap_comm = bool(overlap_comm) and skip_dead_work and not self.graph_overlap
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.overlap_comm or self.graph_overlap) else None
         self._ev_dis_ready = None
+        self._cap = None                                   # the _SegCapture being recorded, if any
+        self._split_backward, self._dec_done = True, False
+        if self.graph_overlap:
+            self._group_auto = False                       # the gaps sit in the grouped schedule: grouped at every batch size
         if self.overlap_comm:
             self.use_graph = False
         # G-step exchange overlap: the generators' flat gradient buffer is cut into buckets of whole layers; a
@@ -364,11 +380,18 @@ class DiscoGANTrainer:
         terms = {}
         F_.FINAL_PASS = True        # the backward of these two passes is the last to touch each generator's parameters
         try:
+            cut = None
             with gen_ctx():
-                BA, AB = group_generators([gA, gB], [B, A])
+                if self.graph_overlap and not dstep and self._split_backward:
+                    (BA, AB), hs, leaves = group_generators([gA, gB], [B, A], cut_at_bottleneck=True)
+                    cut = (hs, leaves)
+                else:
+                    BA, AB = group_generators([gA, gB], [B, A])
         finally:
             F_.FINAL_PASS = False
-        if self._ev_dis_ready is not None:                   # D parameters updated on the communication stream
+        if self.graph_overlap:
+            self._cut("dis_ready")                           # (a gap between two captured graphs: the wait happens at replay)
+        elif self._ev_dis_ready is not None:                 # D parameters updated on the communication stream
             main.wait_event(self._ev_dis_ready)
             self._ev_dis_ready = None
         if self.two_streams:
@@ -411,7 +434,67 @@ class DiscoGANTrainer:
             fm_loss_A=fm_loss_A, fm_loss_B=fm_loss_B, recon_loss_A=terms[0], recon_loss_B=terms[1],
             dis_loss_A=dis_loss_A, dis_loss_B=dis_loss_B, AB=AB, BA=BA, ABA=ABA, BAB=BAB,
             A_dis_real=A_dis_real, A_dis_fake=A_dis_fake, B_dis_real=B_dis_real, B_dis_fake=B_dis_fake,
-            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv)
+            A_feats_real=A_feats_real, B_feats_fake=B_feats_fake, lossvec=lv, backward_cut=cut)
+
+    # ---- the iteration as a sequence of graphs with gaps (overlap_comm="graph") --------------------------------------------------
+    def _cut(self, name):
+        """A point of the iteration where the host must act between kernels: while a _SegCapture records, the current graph ends
+        here and the next one begins (the action runs in the gap at every replay); in eager dispatch the action runs right away."""
+        if self._cap is not None:
+            self._cap.cut(name)
+        else:
+            self._gap(name)
+
+    def _gap(self, name):
+        main = torch.cuda.current_stream(self.device)
+        if name == "dis_ready":
+            if self._ev_dis_ready is not None:               # the discriminators' all-reduce + Adam of the last D-step (communication stream)
+                main.wait_event(self._ev_dis_ready)
+                self._ev_dis_ready = None
+        elif name == "dec_bucket":
+            # every gradient of both decoders is final: their exchange + Adam slices leave while the encoders' backward replays
+            opt = self.optim_gen
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self._adam_begin(opt)
+                self._exchange_and_step_ranges(opt, self._gen_ranges()[1], "G")
+            self._dec_done = True
+        else:
+            raise ValueError(name)
+
+    def _gen_ranges(self):
+        """(encoder ranges, decoder ranges) of the generators in the flat buffer of optim_gen."""
+        if getattr(self, "_gen_rng", None) is None:
+            enc = self.optim_gen.ranges_of([self.generator_A.encoder, self.generator_B.encoder])
+            dec = self.optim_gen.ranges_of([self.generator_A.decoder, self.generator_B.decoder])
+            self._gen_rng = (enc, dec)
+        return self._gen_rng
+
+    def _adam_begin(self, opt):
+        g = opt.param_groups[0]
+        opt._sync_foreign_grads()
+        from . import ops
+        ops.adam_advance(opt.state, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+
+    def _exchange_and_step_ranges(self, opt, ranges, kind):
+        """all-reduce(sum) + Adam of flat ranges on the current stream (the step state was advanced by _adam_begin)."""
+        from . import ops
+        g = opt.param_groups[0]
+        for b, e in ranges:
+            scale = 1.0
+            if self.xg is not None:
+                if self.time_comm:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    scale = self.xg.all_reduce_sum_(opt.flat_g[b:e])
+                    e1.record()
+                    self.comm_events[kind].append((e0, e1))
+                else:
+                    scale = self.xg.all_reduce_sum_(opt.flat_g[b:e])
+            ops.adam_step_flat(opt.flat_p[b:e], opt.flat_g[b:e], opt.exp_avg[b:e], opt.exp_avg_sq[b:e], opt.state,
+                               float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(scale))
 
     def _fwd_bwd(self, A, B, iters, need_losses=True):
         dstep = self.is_dis_step(iters)
@@ -419,7 +502,7 @@ class DiscoGANTrainer:
         if self.skip_dead_work:
             # only the stepped side's gradients are written this iteration; the other flat buffer is
             # left alone (it may still be in flight on the communication stream)
-            if dstep and self._ev_dis_ready is not None:
+            if dstep and self._ev_dis_ready is not None and self._cap is None:
                 torch.cuda.current_stream(self.device).wait_event(self._ev_dis_ready)
             (self.optim_dis if dstep else self.optim_gen).zero_grad()
         else:
@@ -433,7 +516,19 @@ class DiscoGANTrainer:
         try:
             with _ops.use(self.ctx):           # this trainer's arithmetic / operand forms ride with every call
                 out = self.forward_losses(A, B, iters, need_losses)
-                (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
+                cut = getattr(out, "backward_cut", None)
+                if cut is not None:
+                    # backward in two calls: down to the stage-1 bottleneck leaves (completes every decoder gradient of both
+                    # generators -- stage-2 passes included --, written into the flat buffer by the kernels), gap, then the encoders
+                    out.gen_loss.backward(gradient=self._one)
+                    if self.two_streams:
+                        torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+                    self._cut("dec_bucket")
+                    hs, leaves = cut
+                    torch.autograd.backward(list(hs), [l.grad for l in leaves])
+                    out.backward_cut = None
+                else:
+                    (out.dis_loss if dstep else out.gen_loss).backward(gradient=self._one)
         finally:
             self.ctx.clear()
         if self.skip_dead_work and not dstep:
@@ -462,11 +557,21 @@ class DiscoGANTrainer:
         key = self._graph_key(A, B, iters, need_losses)
         ent = self._graphs.get(key)
         if ent is None:
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                out = self._fwd_bwd(sA, sB, iters, need_losses)
-            ent = (g, out)
+            if self.graph_overlap:
+                cap = _SegCapture(self)
+                self._cap = cap
+                try:
+                    with cap:
+                        out = self._fwd_bwd(sA, sB, iters, need_losses)
+                finally:
+                    self._cap = None
+                ent = (cap, out)
+            else:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    out = self._fwd_bwd(sA, sB, iters, need_losses)
+                ent = (g, out)
             self._graphs[key] = ent
         ent[0].replay()
         return ent[1]
@@ -490,6 +595,8 @@ class DiscoGANTrainer:
         reconstruction passes, which feed only the log (weights and optimiser state are unaffected)."""
         dstep = self.is_dis_step(iters)
         opt = self.optim_dis if dstep else self.optim_gen
+        if self.graph_overlap:
+            return self._train_iteration_graph_overlap(A, B, iters, do_step, need_losses)
         bucketed = self._buckets is not None and not dstep and do_step and self.xg is not None
         if self.time_comm:
             self.comm_steps["D" if dstep else "G"] += 1
@@ -521,6 +628,43 @@ class DiscoGANTrainer:
         scale = self._exchange(opt, "D" if dstep else "G")
         if do_step:
             opt.step(grad_scale=scale, active=self.active_ranges(dstep))
+        return out
+
+    def _train_iteration_graph_overlap(self, A, B, iters, do_step, need_losses):
+        """overlap_comm="graph": see __init__.  Results are bitwise those of the plain schedule: the all-reduce and the Adam kernel are
+        elementwise, the slices share one step state."""
+        dstep = self.is_dis_step(iters)
+        opt = self.optim_dis if dstep else self.optim_gen
+        main = torch.cuda.current_stream(self.device)
+        if self.time_comm:
+            self.comm_steps["D" if dstep else "G"] += 1
+        if dstep and self._ev_dis_ready is not None:          # (a D-step right behind a D-step: update_interval 1)
+            main.wait_event(self._ev_dis_ready)
+            self._ev_dis_ready = None
+        self._split_backward, self._dec_done = bool(do_step), False
+        if self.use_graph and iters >= self._eager_until and do_step:
+            out = self._fwd_bwd_graphed(A, B, iters, need_losses)
+        else:
+            out = self._fwd_bwd(A, B, iters, need_losses)
+        if not do_step:
+            return out
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            if dstep:
+                scale = self._exchange(opt, "D")
+                opt.step(grad_scale=scale, active=self.active_ranges(dstep))
+                self._ev_dis_ready = torch.cuda.Event()
+                self._ev_dis_ready.record(self.comm_stream)
+            else:
+                enc, dec = self._gen_ranges()
+                if not self._dec_done:                        # (the backward was not cut: everything goes now)
+                    self._adam_begin(opt)
+                    enc = enc + dec
+                self._exchange_and_step_ranges(opt, enc, "G")                       # the encoders: the exposed part
+        if not dstep:
+            main.wait_stream(self.comm_stream)                # the next iteration's first kernels read the generators' weights
         return out
 
     def comm_ms(self):
@@ -584,6 +728,55 @@ class DiscoGANTrainer:
             torch.cuda.synchronize(self.device)
             self.xg.close()
             self.xg = None
+
+
+class _SegCapture:
+    """One training iteration captured as a SEQUENCE of hipGraphs sharing a memory pool, with named host-side gaps between them
+    (trainer._cut): at replay the graphs are launched in order and the trainer's gap action (an event wait, a hand-over to the
+    communication stream) runs between two of them -- what a single graph cannot hold, because a captured stream cannot wait on an
+    event recorded outside the capture.  Mirrors torch.cuda.graph's protocol (side capture stream, global capture error mode)."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.graphs, self.gaps = [], []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device=trainer.device)
+        self._ctx = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode="global")
+        self.graphs.append(g)
+
+    def __enter__(self):
+        import gc
+        torch.cuda.synchronize(self.tr.device)
+        gc.collect()
+        torch.cuda.empty_cache()
+        self.stream.wait_stream(torch.cuda.current_stream(self.tr.device))
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        self._begin()
+        return self
+
+    def cut(self, name):
+        self.graphs[-1].capture_end()
+        self.gaps.append(name)
+        self._begin()
+
+    def __exit__(self, et, ev, tb):
+        try:
+            self.graphs[-1].capture_end()
+        finally:
+            self._ctx.__exit__(et, ev, tb)
+        torch.cuda.current_stream(self.tr.device).wait_stream(self.stream)
+        return False
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.gaps):
+                self.tr._gap(self.gaps[i])
 
 
 class _GradBuckets:

@@ -4,8 +4,11 @@ path: HIP kernels, flat gradient buffer, 1/W folded into the Adam kernel, in all
   overlap : eager dispatch; D-step all-reduce + Adam on the communication stream under the next iteration's generator
             passes, G-step all-reduce per gradient BUCKET as soon as the bucket's last backward kernel is queued
   plain   : eager dispatch, one message per step behind the backward pass
-  graph   : hipGraph replay of forward+backward, one message + Adam behind it (the default below 256 px)
-All three must agree bitwise (the all-reduce is elementwise, bucketing cannot change a sum of two ranks), replicas
+  graph   : hipGraph replay of forward+backward, one message + Adam behind it
+  seggraph: overlap_comm="graph" (the default below 256 px since round 4): the iteration replays as a SEQUENCE of hipGraphs with gaps --
+            the discriminators' all-reduce + Adam run under the next iteration's first graph, the generators' decoder halves leave
+            while the encoder half of the backward replays (trainer._SegCapture)
+All four must agree bitwise (the all-reduce is elementwise, bucketing cannot change a sum of two ranks), replicas
 must stay identical, and rank 0 is checked against the oracle's single-process emulation of DDP semantics
 (rank-local BN statistics, averaged gradients)."""
 import os
@@ -20,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 S, N, W, ITERS = 16, 4, 2, 7
 MODES = dict(overlap=dict(overlap_comm=True, use_graph=False, bucket_mb=0.05), plain=dict(overlap_comm=False, use_graph=False),
-             graph=dict(overlap_comm=False, use_graph=True))
+             graph=dict(overlap_comm=False, use_graph=True), seggraph=dict(overlap_comm="graph", use_graph=True))
 
 
 def _worker(rank, world, initfile, outdir, mode):
@@ -35,7 +38,8 @@ def _worker(rank, world, initfile, outdir, mode):
         tr = DiscoGANTrainer(default_args(), device="cuda:0", image_size=S, seed=1234, process_group=dist.group.WORLD,
                              **MODES[mode])
         assert tr.world_size == world and tr.xg is not None and tr.xg.transport == "c10d"
-        assert tr.overlap_comm == MODES[mode]["overlap_comm"] and tr.use_graph == MODES[mode]["use_graph"]
+        assert tr.overlap_comm == (MODES[mode]["overlap_comm"] is True) and tr.use_graph == MODES[mode]["use_graph"]
+        assert tr.graph_overlap == (mode == "seggraph")
         A, B = synthetic_batch(N, S, dp.rank_data_seed(rank), "cuda:0")
         losses = []
         for it in range(ITERS):
@@ -44,6 +48,9 @@ def _worker(rank, world, initfile, outdir, mode):
         torch.cuda.synchronize()
         if mode == "overlap":
             assert tr._buckets.launched > 0
+        if mode == "seggraph":       # the G-step graph really is a sequence: [stage 1] gap [rest + decoder half of the backward] gap [encoders]
+            caps = [v[0] for k, v in tr._graphs.items() if k[0] == "G"]
+            assert caps and all(len(c.graphs) == 3 and c.gaps == ["dis_ready", "dec_bucket"] for c in caps)
         torch.save(dict(losses=losses, gen=tr.optim_gen.flat_p.cpu(), dis=tr.optim_dis.flat_p.cpu(),
                         rm=tr.generator_A.encoder[3].running_mean.cpu()), os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
@@ -60,7 +67,7 @@ def test_two_rank_trainer_on_one_gpu_matches_ddp_emulation():
         with tempfile.TemporaryDirectory() as d:
             mp.spawn(_worker, args=(W, os.path.join(d, "init"), d, mode), nprocs=W, join=True)
             runs[mode] = [torch.load(os.path.join(d, f"rank{k}.pt")) for k in range(W)]
-    for mode in ("plain", "graph"):           # bucketed / graph-replayed exchange == one eager message, bit for bit
+    for mode in ("plain", "graph", "seggraph"):           # bucketed / graph-replayed / segmented exchange == one eager message, bit for bit
         assert runs[mode][0]["losses"] == runs["overlap"][0]["losses"], mode
         assert torch.equal(runs[mode][0]["gen"], runs["overlap"][0]["gen"]) and torch.equal(runs[mode][0]["dis"], runs["overlap"][0]["dis"]), mode
     r = runs["overlap"]
