@@ -743,8 +743,11 @@ extern "C" int dg_c3_fwd_mfma_launch_g(int groups, const float* const* x_tab, co
     if (ngroups >= (1L << 30)) return dg_fail(DG_ERR_INVALID, "dg_conv4x4s2_c3_fwd: too many pixels");
     // 8 groups per wave and one workgroup per CU (96 KB of LDS reserved so the dispatcher spreads the grid):
     // measured 26 us vs 34 us at 4 groups / 2 workgroups per CU (256 x 3 x 64 x 64 -> 64 ch); the fixed
-    // per-workgroup prologue (weights, first gather) is what the longer waves amortise
-    long wgs = (ngroups + 31) / 32;
+    // per-workgroup prologue (weights, first gather) is what the longer waves amortise.  Small launches (64 px / batch 64: 2048 groups
+    // per problem = 64 such workgroups) leave most CUs idle: fewer groups per wave until the launch has a workgroup per CU
+    long per = 32;
+    while (per > 4 && ((ngroups + per - 1) / per) * groups < 256) per >>= 1;
+    long wgs = (ngroups + per - 1) / per;
     if (wgs > 4096) wgs = 4096;
     if (wgs < 1) wgs = 1;
 #define CF_LAUNCH(ACT, O16)                                                                                          \
