@@ -214,7 +214,7 @@ def pmc_traffic(image_size, batch, mfma_dtype="f32"):
     """HBM-side bytes per launch of the dominant instantiation of the conv family from the committed rocprofv3 PMC passes
     (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see profiles/README.md); only for the profiled workloads."""
     tag, prefix = PMC_KERNEL[mfma_dtype]
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_per_launch_{image_size}px_bs{batch}{tag}.json")
         if not os.path.exists(path):
             continue

@@ -1461,8 +1461,11 @@ static int c3_wgrad_run(const char* who, int groups, int share, const float* con
     hipLaunchKernelGGL((c3_wgrad_mfma_kernel<B, F>), grid, dim3(256), 0, st, pdy, px, pws, N, H, W, \
                        K, dg_ilog2(H / 2), dg_ilog2(W / 2), npix, ppw, pao, slope)
     if (io_bf16 && !buf) return dg_fail(DG_ERR_INVALID, "%s: bf16 operands need tensors < 1 GiB", who);
-    if (!io_bf16 && buf && dg_cur_prec() == 2 && W >= 32 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
-        // f32x3 path: fp32-accurate plane products on the bf16 MFMA, image rows staged through LDS (fp32)
+    // f32x3 path: fp32-accurate plane products on the bf16 MFMA, image rows staged through LDS (fp32) -- from 256-pixel rows on.  On
+    // shorter rows its one workgroup of four waves per CU is latency-bound and the exact-fp32 MFMA kernel below (at least as accurate)
+    // is faster: same-box, ms per call f32 MFMA / this kernel: 64 px batch 64 0.026 / 0.039, batch 256 0.047 / 0.078, 128 px batch 64
+    // 0.047 / 0.056, 256 px batch 32 0.076 / 0.075, 512 px batch 32 0.296 / 0.254 (tools/bench_ops.py, round 4)
+    if (!io_bf16 && buf && dg_cur_prec() == 2 && W >= 256 && W / 2 <= CWL_WOMAX && dg_get_option(DG_OPT_KT) != 16) {
         const int nrows = N * (H / 2);
         const int rpw = (nrows + nb - 1) / nb;
         if (fact)

@@ -181,18 +181,21 @@ class DiscoGANTrainer:
         #           [backward of the stage-1 encoders]; the encoders' all-reduce + Adam slices are the only exposed part.
         # The backward is cut with two autograd calls (gradients w.r.t. the bottleneck activations, then from there): the kernels write
         # the parameter gradients into the flat buffer as a side effect, so the first call completes every decoder gradient.
+        # On the two-chain schedule (from 256 px, or group_launch=False) the same mode has ONE gap: behind G_A(B) | G_B(A), where the two
+        # streams meet anyway -- enough for the D-step half (at 512 px the discriminators' Adam is 1.4-2 ms of HBM-bound work that then runs
+        # under the next iteration's first generator passes, also on ONE rank); the G-step update stays behind the backward pass.
         if overlap_comm is None:
             overlap_comm = (True if image_size >= 256 else ("graph" if (self.group_launch and use_graph) else False)) if self.world_size > 1 else False
         self.graph_overlap = overlap_comm == "graph"
-        if self.graph_overlap and not (self.group_launch and skip_dead_work):
-            raise ValueError("overlap_comm='graph' needs the grouped schedule (group_launch) and skip_dead_work")
+        if self.graph_overlap and not skip_dead_work:
+            raise ValueError("overlap_comm='graph' needs skip_dead_work")
         self.overlap_comm = bool(overlap_comm) and skip_dead_work and not self.graph_overlap
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.overlap_comm or self.graph_overlap) else None
         self._ev_dis_ready = None
         self._cap = None                                   # the _SegCapture being recorded, if any
         self._split_backward, self._dec_done = True, False
-        if self.graph_overlap:
-            self._group_auto = False                       # the gaps sit in the grouped schedule: grouped at every batch size
+        if self.graph_overlap and self.group_launch:
+            self._group_auto = False                       # the backward cut sits in the grouped schedule: grouped at every batch size
         if self.overlap_comm:
             self.use_graph = False
         # G-step exchange overlap: the generators' flat gradient buffer is cut into buckets of whole layers; a
@@ -337,6 +340,15 @@ class DiscoGANTrainer:
         if self.two_streams:
             AB.record_stream(side)
             BA.record_stream(main)
+        if self.graph_overlap:
+            # a gap between two captured graphs (the wait for the discriminators' update happens there at replay): the chains join
+            # in front of it and fork again behind it, which is also the hand-over of AB / BA
+            if self.two_streams:
+                main.wait_stream(side)
+            self._cut("dis_ready")
+            if self.two_streams:
+                side.wait_stream(main)
+        elif self.two_streams:
             ev_ab, ev_ba = torch.cuda.Event(), torch.cuda.Event()
             ev_ab.record(main)
             ev_ba.record(side)
@@ -648,6 +660,11 @@ class DiscoGANTrainer:
             out = self._fwd_bwd(A, B, iters, need_losses)
         if not do_step:
             return out
+        if not dstep and not self._dec_done:
+            # the backward was not cut (two-chain schedule): the generators' update is needed by the very next kernel -- main stream
+            scale = self._exchange(opt, "G")
+            opt.step(grad_scale=scale, active=self.active_ranges(dstep))
+            return out
         ev = torch.cuda.Event()
         ev.record(main)
         self.comm_stream.wait_event(ev)
@@ -658,11 +675,7 @@ class DiscoGANTrainer:
                 self._ev_dis_ready = torch.cuda.Event()
                 self._ev_dis_ready.record(self.comm_stream)
             else:
-                enc, dec = self._gen_ranges()
-                if not self._dec_done:                        # (the backward was not cut: everything goes now)
-                    self._adam_begin(opt)
-                    enc = enc + dec
-                self._exchange_and_step_ranges(opt, enc, "G")                       # the encoders: the exposed part
+                self._exchange_and_step_ranges(opt, self._gen_ranges()[0], "G")      # the encoders: the exposed part
         if not dstep:
             main.wait_stream(self.comm_stream)                # the next iteration's first kernels read the generators' weights
         return out

@@ -1123,9 +1123,10 @@ def test_conv_f32x3_forward_window_kernel(N, C, K, H, monkeypatch):
     assert e3 <= 2.0 * max(e32, ereg) + 2e-7, f"window forward: {e3:.2e} vs fp64 (exact-fp32 MFMA kernel {e32:.2e}, register-staged f32x3 {ereg:.2e})"
 
 
-@pytest.mark.parametrize("N,S", [(2, 64), (3, 128), (1, 512)])
+@pytest.mark.parametrize("N,S", [(2, 64), (3, 128), (2, 256), (1, 512)])
 def test_edge_wgrad_on_the_f32x3_path(N, S):
-    """Option "bf16" = 2: conv1's weight gradient (and, roles swapped, the last transposed conv's) with the image rows staged through
+    """(From 256-pixel rows on; shorter rows run the exact-fp32 MFMA kernel on this path too, which is faster there -- round 4.)
+    Option "bf16" = 2: conv1's weight gradient (and, roles swapped, the last transposed conv's) with the image rows staged through
     LDS in fp32 and both operands split into three bf16 planes in front of the MFMAs (c3_wgrad_lds_kernel<., X3>): at least as close
     to the fp64 result as the fp32-MFMA kernel (<= 2x its distance), with the fused LeakyReLU backward and accumulation."""
     x, dy = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(1)), rnd(N, 64, S // 2, S // 2, seed=3)

@@ -55,10 +55,12 @@ def main():
     global ITERS
     ITERS = a.iters
     _lib.set_option("bf16", a.bf16)
-    _lib.set_option("dbg_zero", a.dbg_zero)
+    if a.dbg_zero:          # exists in the timing build only (make -C discogan_modernized_amd/csrc TIMING=1; DG_LIB=.../libdiscogan_hip_timing.so)
+        _lib.set_option("dbg_zero", a.dbg_zero)
     _lib.set_option("no_dma", a.no_dma)
     _lib.set_option("dma_mfma", a.dma_mfma)
-    _lib.set_option("x3_mfma", a.x3_mfma)
+    if a.x3_mfma:           # exists in the experiments build only (make EXPERIMENTS=1)
+        _lib.set_option("x3_mfma", a.x3_mfma)
     ops.SHADOW = bool(a.shadow)
     ops.X3 = bool(a.x3planes)
     only = {int(v) for v in a.layers.split(",") if v}
