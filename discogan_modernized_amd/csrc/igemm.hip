@@ -1313,6 +1313,10 @@ static void make_plan(int op, const ConvGeom& g, Plan* pl, int a16 = 0, int b16 
         ((pl->mode == MODE_FWD && g.C % 16 == 0) || (pl->mode == MODE_DGRAD_S2 && g.K % 16 == 0) || pl->mode == MODE_WGRAD)) {
         if (a.Ng >= 192 && a.M >= 192) { pl->dma = 2; pl->wm = 2; pl->wn = 4; }
         else if (pl->mode == MODE_WGRAD && a.M >= 96 && a.Ng >= 192) { pl->dma = 2; pl->wm = 1; pl->wn = 4; }
+#ifdef DG_TIMING_KNOBS
+        // timing experiment (dbg_zero bit 5): the 256 x 128 tile for a forward with 96..191 output channels
+        else if ((dg_get_option(DG_OPT_DBG_ZERO) & 32) && pl->mode == MODE_FWD && g.stride == 2 && a.Ng >= 96 && a.M >= 192 && g.C % 64 == 0) { pl->dma = 2; pl->wm = 2; pl->wn = 2; }
+#endif
         // input-grad with <= 128 output channels: all parity classes of a 256-pixel tile in one workgroup, the gradient window in
         // LDS (igemm_dma_x3_dgw.hip); whole image rows per tile, a 32-pixel block inside one row
         else if (pl->mode == MODE_DGRAD_S2 && g.C <= 128 && g.Wo >= 32 && g.Wo <= 128 && g.Ho * g.Wo >= 256 &&

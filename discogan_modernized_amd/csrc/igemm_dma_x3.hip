@@ -171,6 +171,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
                     const int ox = m & (Wo - 1), oy = (m >> lgWo) & (Ho - 1), n = m >> lgHW;
                     const int ay = oy * p.stride - p.pad, ax = ox * p.stride - p.pad;
                     a_ob[i] = (((n * H + ay) * W + ax) * Cc + g * 8) * 2;
+#ifdef DG_TIMING_KNOBS
+                    // timing experiment (dbg_zero bit 4, WRONG results): the A rows of a K-tile are one contiguous run of 32-byte
+                    // pieces -- what a parity-split chunk-major plane layout would give the forward form
+                    if (p.dbg_zero & 16) a_ob[i] = (m * 16 + g * 8) * 2;
+#endif
                     int colok = 0, okmask = 0;
 #pragma unroll
                     for (int sx = 0; sx < 4; ++sx) colok |= ((unsigned)(ax + sx) < (unsigned)W) ? (1 << sx) : 0;
@@ -289,7 +294,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_dma_x3_kernel(const Ige
     auto a_voff = [&](int i) -> int {
         if (MODE == MODE_FWD) {
             const int r = fwd_r(), sx = fwd_s();
-            const int soff = ((r * W + sx) * Cc + coff()) * 2;                 // wave-uniform
+            int soff = ((r * W + sx) * Cc + coff()) * 2;                 // wave-uniform
+#ifdef DG_TIMING_KNOBS
+            if (p.dbg_zero & 16) soff = ((dt & 7) * p.M) * 32;         // (8 distinct 32 M-byte regions of the plane, revisited)
+            // bit 6 (with bit 4): the regions a parity-split chunk-major layout [chunk16][class][pixel][16] would touch: one per
+            // (16-channel chunk, input-parity class of the tap); the taps of a class revisit it (shifted by a pixel / a row)
+            if (p.dbg_zero & 64) soff = ((sub * 4 + ((((r + 1) & 1) << 1) | ((sx + 1) & 1))) * p.M) * 32 + (((r >> 1) * Wo + (sx >> 1)) * 32) % 4096;
+#endif
             return (a_ob[i] + soff) | -((a_inv[i] >> (r * 4 + sx)) & 1);
         } else if (MODE == MODE_DGRAD_S2) {
             const int ty = tap >> 1, tx = tap & 1;
@@ -695,6 +706,9 @@ int dg_igemm_dma_x3_launch(int mode, int wm, int wn, const IgemmArgs& a, int zmu
     if (wm == 2 && wn == 4 && body == 16) return x3_launch_tile<2, 4, 3, true>(mode, a, grid, st);
 #endif
     if (wm == 2 && wn == 4) return x3_launch_tile<2, 4, 2, false>(mode, a, grid, st);
+#ifdef DG_TIMING_KNOBS
+    if (wm == 2 && wn == 2 && mode == MODE_FWD) return x3_launch_tile<2, 2, 2, false>(mode, a, grid, st);     // timing experiment only
+#endif
     if (wm == 1 && wn == 4 && mode == MODE_WGRAD) {
         hipLaunchKernelGGL((igemm_dma_x3_kernel<MODE_WGRAD, false, 1, 4, 2>), dim3(grid), dim3(256), 0, st, a);
         return 1;
