@@ -325,6 +325,11 @@ X3_CM = __import__("os").environ.get("DG_X3_CM", "1") != "0"
 # bits (hi + mid + lo == the fp32 value), the fp32 tensor stays allocated but unwritten and is flagged ``_dg_planes_only`` --
 # every op wrapper that would read fp32 memory refuses such a tensor.  model.py decides per layer; DG_X3_PLANES_ONLY=0: off (A/B).
 X3_PLANES_ONLY = __import__("os").environ.get("DG_X3_PLANES_ONLY", "1") != "0"
+# POISON_PLANES_ONLY (debug aid, DG_POISON_PLANES_ONLY=1; round-3 advisor finding): the fp32 memory of a plane-only tensor is never written
+# and its only protection is the ``_dg_planes_only`` attribute, which a view / a torch-native reader does not carry.  With the switch on that
+# memory is filled with NaN, so anything that reads it (instead of the planes) turns the losses NaN instead of using stale allocator bytes;
+# tests/test_model_gpu.py runs a training step under it and requires the results bitwise unchanged.
+POISON_PLANES_ONLY = __import__("os").environ.get("DG_POISON_PLANES_ONLY", "0") == "1"
 # X3_FWW: forward convolutions with <= 128 output channels on the window forward kernel (csrc/igemm_dma_x3_fww.hip; planner code 3:
 # needs the transposed weight planes).  OFF by default: built, parity-tested and measured at the benchmark shape (64 -> 128 channels,
 # 512 px / batch 32) at 0.923 ms against 0.927 ms for the register-staged f32x3 tiles -- its window pixels are every OTHER pixel of a
@@ -786,6 +791,8 @@ def bn_act_fwd(y, saved, gamma, beta, act, slope=0.2, planes_cm=False, planes_on
         planes_put(z, z3, cm)
         if po:
             z._dg_planes_only = True
+            if POISON_PLANES_ONLY:
+                z.fill_(float("nan"))
         return z
     if _CUR.shadow and c % 8 == 0:
         z16 = empty_nhwc_bf16(n, c, h, w, y.device)
@@ -836,6 +843,8 @@ def bn_act_bwd(dz, y, saved, gamma, beta, act, slope=0.2, need_param_grads=True,
         planes_put(dy, dy3, cm)
         if po:
             dy._dg_planes_only = True
+            if POISON_PLANES_ONLY:
+                dy.fill_(float("nan"))
         return dy, dgamma, dbeta
     if _CUR.shadow and c % 8 == 0:
         dy16 = empty_nhwc_bf16(n, c, h, w, y.device)

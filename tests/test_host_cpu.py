@@ -36,6 +36,38 @@ def test_library_exports_every_declared_symbol():
     assert L.dg_set_option(b"nonsense", 1) != 0 and b"unknown option" in L.dg_last_error()
 
 
+def test_grouped_entry_points_validate_their_arguments():
+    """The *_g entry points reject bad groups / tables / precision before anything is launched (no GPU needed): negative status,
+    message from dg_last_error, nothing thrown across the ABI."""
+    import ctypes as C
+    L = _lib.load()
+    P = C.c_void_p
+    one = (P * 1)(None)
+    tab4 = (P * 4)(8, 8, 8, 8)                      # non-null dummies: validation fails before they are dereferenced
+    # groups out of range
+    assert L.dg_conv_fwd_g(0, tab4, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 1, None, 0, tab4, 0, None) < 0 and b"groups" in L.dg_last_error()
+    assert L.dg_conv_fwd_g(5, tab4, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 1, None, 0, tab4, 0, None) < 0
+    # precision out of range
+    assert L.dg_conv_fwd_g(2, tab4, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 7, 1, None, 0, tab4, 0, None) < 0 and b"prec" in L.dg_last_error()
+    # null problem pointer / null table
+    assert L.dg_conv_fwd_g(1, one, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 1, None, 0, tab4, 0, None) < 0 and b"null" in L.dg_last_error()
+    assert L.dg_conv_dgrad_g(2, None, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 1, None, 0, tab4, 0, None) < 0
+    # share: only the weight gradient, groups % share == 0, members naming ONE output
+    assert L.dg_conv_wgrad_g(3, 2, tab4, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 1, 1, tab4, 0, None) < 0 and b"share" in L.dg_last_error()
+    mixed = (P * 4)(8, 16, 8, 8)
+    assert L.dg_conv_wgrad_g(4, 2, tab4, tab4, mixed, 2, 8, 8, 64, 128, 2, 1, 0, 1, 1, tab4, 0, None) < 0 and b"same dw" in L.dg_last_error()
+    # plan_groups is 1 or groups
+    assert L.dg_conv_fwd_g(2, tab4, tab4, tab4, 2, 8, 8, 64, 128, 2, 1, 0, 3, None, 0, tab4, 0, None) < 0 and b"plan_groups" in L.dg_last_error()
+    # unsupported geometry is reported the same way
+    assert L.dg_conv_fwd_g(2, tab4, tab4, tab4, 2, 9, 8, 64, 128, 2, 1, 0, 1, None, 0, tab4, 0, None) < 0 and b"powers of two" in L.dg_last_error()
+    # BatchNorm / loss tables
+    assert L.dg_bn_act_fwd_g(0, tab4, tab4, 16, 64, tab4, tab4, tab4, 1, 0.2, None) < 0
+    assert L.dg_bn_train_stats_g(2, 1, None, 16, 64, 1e-5, 0.1, None, None, None, tab4, tab4, 0, None) < 0
+    assert L.dg_mse_fwd_g(2, tab4, None, 16, tab4, tab4, 8192, None) < 0 and b"null pointer table" in L.dg_last_error()
+    assert L.dg_bce_fwd_g(9, tab4, 4, None, tab4, None) < 0
+    assert L.dg_build_flags() == 0                  # the product library: no experiments, no timing switches
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdiscogan_hip.so")

@@ -542,6 +542,14 @@ def test_f32x3_plane_only_batchnorm_outputs_are_bitwise_neutral(monkeypatch):
         monkeypatch.setattr(ops, "planes_put", orig)
     assert used[0] == 0 and used[1] > 0, f"plane-only tensors: {used}"
     assert runs[0][0] == runs[1][0] and all(torch.equal(a, b) for a, b in zip(runs[0][1:], runs[1][1:]))
+    # the unwritten fp32 memory of a plane-only tensor is really read by NOBODY: filled with NaN (ops.POISON_PLANES_ONLY) the run is unchanged
+    monkeypatch.setattr(ops, "X3_PLANES_ONLY", True)
+    monkeypatch.setattr(ops, "POISON_PLANES_ONLY", True)
+    tr = DiscoGANTrainer(default_args(), device=DEV, image_size=128, seed=1234, mfma_dtype="f32x3", x3_planes=True)
+    vals = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(6)]
+    torch.cuda.synchronize()
+    assert vals == runs[1][0] and torch.equal(tr.optim_gen.flat_p, runs[1][1]) and torch.equal(tr.optim_dis.flat_p, runs[1][2])
+    tr.close()
 
 
 def test_masked_fp64_gradient_parity_512():
