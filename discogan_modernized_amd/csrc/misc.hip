@@ -55,6 +55,7 @@ extern "C" int dg_set_option(const char* name, int value) {
 #ifdef DG_EXPERIMENTS
     // experiments library only (make EXPERIMENTS=1): kernels that were built, verified and measured not faster
     else if (!strcmp(name, "x3_mfma")) g_options[DG_OPT_X3_MFMA] = value;   // 16: the f32x3 plane kernel's 16x16x32 body (planes paired along k) instead of 32x32x16
+    else if (!strcmp(name, "understory")) g_options[DG_OPT_UNDERSTORY] = value;   // 16 | 8 | 4: dg_act_fwd through the LDS-DMA-fed low-register streaming kernel with that many 1-KiB pieces in flight per wave (tools/probe_corun.py)
     else if (!strcmp(name, "dgw_persist")) g_options[DG_OPT_DGW_PERSIST] = value;   // 1: the f32x3 window input-grad kernel as one persistent workgroup per CU
 #endif
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)

@@ -812,7 +812,11 @@ __global__ __launch_bounds__(256) void act_bwd16_kernel(const __bf16* __restrict
 
 static int stream_grid(long total4) {
     long g = (total4 + 255) / 256;
-    if (g > 2048) g = 2048;
+    long cap = 2048;
+#ifdef DG_EXPERIMENTS
+    if (const int v = dg_get_option(DG_OPT_UNDERSTORY); v < 0) cap = -(long)v;      // probe: another cap on the workgroups of a streaming pass
+#endif
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -1079,11 +1083,92 @@ extern "C" int dg_bn_act_bwd_t(const void* dz, const void* y, void* dy, int io_b
     return bn_act_bwd_impl<float>(1, 1, G, M, C, act, slope, accumulate, ws_bytes, stream);
 }
 
+#ifdef DG_EXPERIMENTS
+#include <utility>
+template <int... Q, typename F>
+__device__ __forceinline__ void bn_static_for(std::integer_sequence<int, Q...>, F&& f) {
+    (f(std::integral_constant<int, Q>{}), ...);
+}
+// "Understory" form of a streaming kernel (experiment; tools/probe_corun.py): can an HBM-bound pass run BENEATH a saturating MFMA conv
+// kernel instead of taking turns with it?  The conv kernels hold 2 waves x 217-240 registers per SIMD and 96-128 KB of LDS, so what is
+// left on a CU is ONE wave of <= 32 registers per SIMD and 32-64 KB of LDS -- far too few registers for the loads in flight that HBM
+// latency needs (the plain kernels reach 1 TB/s beside a conv kernel).  Here the loads in flight live in LDS: every wave keeps NP 1-KiB
+// pieces under way with `buffer_load_dwordx4 ... lds` (no registers), takes the oldest with ONE ds_read_b128 per lane, and re-issues
+// the slot.  A workgroup = 4 waves (one per SIMD), 4 NP KiB of LDS; vmcnt counts the DMA loads and the stores in issue order.
+template <int NP>
+__global__ __launch_bounds__(256) void act_fwd_understory_kernel(const float* __restrict__ x, float* __restrict__ y, long nbytes, long wgbytes, int act,
+                                                                 float slope) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * NP * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long base = (long)blockIdx.x * wgbytes;                       // this workgroup's byte range [base, base + span)
+    const long left = nbytes - base;
+    const int span = (int)(left < wgbytes ? left : wgbytes);
+    const int npc = (span + 1023) >> 10;                                // 1-KiB pieces of the range; wave w takes pieces w, w + 4, ...
+    const int cnt = npc > wave ? (npc - wave + 3) >> 2 : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x + base), 0, span, 0x00020000);
+    const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem + (unsigned)wave * NP * 1024;
+    constexpr int OOR = (int)0x80000000;
+    auto dma = [&](int slot, int voff) {
+        unsigned keep;
+        const unsigned dst = lds_w + (unsigned)slot * 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rx), "s"(dst)
+                     : "memory");
+    };
+    auto off_of = [&](int i) -> int { return i < cnt ? ((wave + 4 * i) << 10) + lane * 16 : OOR; };
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dma(k, off_of(k));
+    for (int i = 0; i < cnt; ++i) {
+        // piece i's DMA is followed by (issue order) the rest of the prologue and one store + one DMA per earlier iteration
+        if (i >= NP - 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NP - 1)) : "memory");
+        } else {
+            bn_static_for(std::make_integer_sequence<int, NP - 1>{}, [&](auto q) {
+                if (i == q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1 + (int)q) : "memory");
+            });
+        }
+        const int slot = i % NP;
+        f32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_w + (unsigned)slot * 1024 + (unsigned)lane * 16) : "memory");
+        const int o = off_of(i);
+        dma(slot, off_of(i + NP));
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = act == DG_ACT_SIGMOID ? 1.f / (1.f + expf(-v[j])) : dg_apply_act(v[j], act, slope);
+        if (o + 16 <= span) *(f32x4*)((char*)y + base + o) = r;
+        else asm volatile("s_nop 0");                                  // (the skipped store only makes the next waits stricter than needed: never looser)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the zero-fill DMAs of the tail still target this workgroup's LDS
+}
+template <int NP>
+static int act_fwd_understory(const float* x, float* y, size_t n, int act, float slope, hipStream_t st, int wgs) {
+    const long nbytes = (long)n * 4;
+    long wgbytes = 4L * NP * 1024 * 4;                                   // >= 4 rounds of the ring per workgroup
+    if (wgs > 0) wgbytes = ((nbytes + wgs - 1) / wgs + 4095) / 4096 * 4096;      // a fixed number of long-lived workgroups (one per CU: 256)
+    else while ((nbytes + wgbytes - 1) / wgbytes > 2048) wgbytes *= 2;
+    DG_CHECK_ARG(wgbytes < (1L << 31), "act_fwd_understory: range per workgroup");
+    const int grid = (int)((nbytes + wgbytes - 1) / wgbytes);
+    hipLaunchKernelGGL((act_fwd_understory_kernel<NP>), dim3(grid), dim3(256), 0, st, x, y, nbytes, wgbytes, act, slope);
+    DG_CHECK_LAUNCH("act_fwd_understory");
+    return DG_OK;
+}
+#endif
+
 extern "C" int dg_act_fwd_g(int groups, const float* const* x, float* const* y, size_t n, int act, float slope, dg_stream_t stream) {
     DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && x && y, "dg_act_fwd: bad group / null table");
     for (int i = 0; i < groups; ++i) DG_CHECK_ARG(x[i] && y[i], "dg_act_fwd: null pointer");
     DG_CHECK_ARG(act >= DG_ACT_NONE && act <= DG_ACT_SIGMOID, "dg_act_fwd: bad act %d", act);
     if (n == 0) return DG_OK;
+#ifdef DG_EXPERIMENTS
+    if (const int np = dg_get_option(DG_OPT_UNDERSTORY); np && groups == 1 && n % 4 == 0) {
+        const int wgs = np / 100, q = np % 100;                          // e.g. 25616: 256 long-lived workgroups, 16 pieces per wave
+        if (q == 16) return act_fwd_understory<16>(x[0], y[0], n, act, slope, (hipStream_t)stream, wgs);
+        if (q == 8) return act_fwd_understory<8>(x[0], y[0], n, act, slope, (hipStream_t)stream, wgs);
+        return act_fwd_understory<4>(x[0], y[0], n, act, slope, (hipStream_t)stream, wgs);
+    }
+#endif
     const long total4 = (long)((n + 3) / 4);
     hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(total4), groups), dim3(256), 0, (hipStream_t)stream, dg_ptrs((const void* const*)x, groups),
                        dg_ptrs((const void* const*)y, groups), total4, (long)n, act, slope);
