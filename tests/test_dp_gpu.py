@@ -86,6 +86,68 @@ def test_two_rank_trainer_on_one_gpu_matches_ddp_emulation():
             assert abs(got[k] - v) <= rtol * abs(v) + 1e-6, f"iter {it} {k}: {got[k]} vs {v}"
 
 
+# ---- the metric's data-parallel configurations at their per-GPU shapes, two ranks (round-3 verdict, weak 3) ----------------------------------
+# BASELINE configs[2]: 64 px, 64 images per GPU, exact fp32; configs[4]: 512 px, bf16 matrix path with bf16 feature maps (batch 2 per rank
+# here: two 512 px replicas and the oracle's emulation of them have to fit one card / finish in seconds).  Default dispatch of a
+# data-parallel trainer at that size (64 px: the segmented-graph exchange; 512 px: eager with bucketed overlap) against the plain
+# one-message exchange -- bitwise --, replicas identical, rank 0 against the oracle's DDP emulation.
+SHAPES = {
+    "configs2_64px_64_per_rank_f32": dict(size=64, n=64, iters=4, kw=dict(mfma_dtype="f32"), ref_iters=2, rtol0=1e-4, rtol=3e-2),
+    "configs4_512px_bf16_maps_bf16": dict(size=512, n=2, iters=3, kw=dict(mfma_dtype="bf16", act_dtype="bf16"), ref_iters=1, rtol0=2e-2, rtol=2e-2),
+}
+
+
+def _shape_worker(rank, world, initfile, outdir, shape, plain):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        from discogan_modernized_amd import dp
+        from discogan_modernized_amd.trainer import DiscoGANTrainer, default_args, synthetic_batch
+        cfg = SHAPES[shape]
+        torch.cuda.set_device(0)
+        kw = dict(cfg["kw"], **(dict(overlap_comm=False, use_graph=False) if plain else dict(use_graph=True)))    # use_graph: the CLI's default
+        tr = DiscoGANTrainer(default_args(), device="cuda:0", image_size=cfg["size"], seed=1234, process_group=dist.group.WORLD, **kw)
+        if not plain:                                           # what a data-parallel run gets without being told anything
+            assert tr.graph_overlap == (cfg["size"] < 256) and (tr.overlap_comm is True) == (cfg["size"] >= 256)
+        A, B = synthetic_batch(cfg["n"], cfg["size"], dp.rank_data_seed(rank), "cuda:0")
+        losses = [tr.losses_to_floats(tr.train_iteration(A, B, it)) for it in range(cfg["iters"])]
+        tr.finish()
+        torch.cuda.synchronize()
+        torch.save(dict(losses=losses, gen=tr.optim_gen.flat_p.cpu(), dis=tr.optim_dis.flat_p.cpu()), os.path.join(outdir, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_two_ranks_at_the_metric_shapes(shape):
+    from oracle import discogan_ref as O
+    from discogan_modernized_amd import dp
+    cfg = SHAPES[shape]
+    runs = {}
+    for plain in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_shape_worker, args=(W, os.path.join(d, "init"), d, shape, plain), nprocs=W, join=True)
+            runs[plain] = [torch.load(os.path.join(d, f"rank{k}.pt")) for k in range(W)]
+    dflt, plain = runs[False], runs[True]
+    assert dflt[0]["losses"] == plain[0]["losses"] and torch.equal(dflt[0]["gen"], plain[0]["gen"]) and torch.equal(dflt[0]["dis"], plain[0]["dis"])
+    assert torch.equal(dflt[0]["gen"], dflt[1]["gen"]) and torch.equal(dflt[0]["dis"], dflt[1]["dis"])          # replicas identical
+    assert dflt[0]["losses"] != dflt[1]["losses"]                                                                # different shards
+    for v in dflt[0]["losses"]:
+        assert all(torch.isfinite(torch.tensor(x)) for x in v.values())
+    st = O.build_state(image_size=cfg["size"], seed=1234)
+    shards = [O.synthetic_batch(cfg["n"], cfg["size"], seed=dp.rank_data_seed(k)) for k in range(W)]
+    for it in range(cfg["ref_iters"]):
+        ref = O.losses_to_floats(O.dp_emulated_iteration(st, [s[0] for s in shards], [s[1] for s in shards], it))
+        got = dflt[0]["losses"][it]
+        rtol = cfg["rtol0"] if it == 0 else cfg["rtol"]
+        for k, v in ref.items():
+            assert abs(got[k] - v) <= rtol * abs(v) + 1e-6, f"{shape} iter {it} {k}: {got[k]} vs {v}"
+
+
 # ---- the guarded bootstrap of the library's RCCL communicator on hardware (dp.guarded_bootstrap) -------------------------------
 def _capi_worker(rank, world, initfile, outdir, fail_rank):
     import sys
