@@ -51,7 +51,7 @@ struct DgPlanScope {
     explicit DgPlanScope(int plan_groups);
     ~DgPlanScope();
 };
-enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_DGW_PERSIST = 11, DG_OPT_UNDERSTORY = 12, DG_OPT_COUNT = 13 };
+enum { DG_OPT_SPLITK = 0, DG_OPT_KT = 1, DG_OPT_TARGET_WGS = 2, DG_OPT_RESERVED = 3, DG_OPT_SPLIT_BELOW = 4, DG_OPT_POINTER_PATH = 5, DG_OPT_BF16 = 6, DG_OPT_DBG_ZERO = 7, DG_OPT_NO_DMA = 8, DG_OPT_DMA_MFMA = 9, DG_OPT_X3_MFMA = 10, DG_OPT_DGW_PERSIST = 11, DG_OPT_UNDERSTORY = 12, DG_OPT_BN_ITEMS = 13, DG_OPT_COUNT = 14 };
 
 // ---- grouped launches (round 4): one tensor per problem, picked by a block index (wave-uniform: scalar loads) ------------------
 struct DgPtrs {

@@ -58,6 +58,7 @@ extern "C" int dg_set_option(const char* name, int value) {
     else if (!strcmp(name, "understory")) g_options[DG_OPT_UNDERSTORY] = value;   // 16 | 8 | 4: dg_act_fwd through the LDS-DMA-fed low-register streaming kernel with that many 1-KiB pieces in flight per wave (tools/probe_corun.py)
     else if (!strcmp(name, "dgw_persist")) g_options[DG_OPT_DGW_PERSIST] = value;   // 1: the f32x3 window input-grad kernel as one persistent workgroup per CU
 #endif
+    else if (!strcmp(name, "bn_items")) g_options[DG_OPT_BN_ITEMS] = value;   // 1: the fp32 BatchNorm apply passes on the item kernels instead of the row-geometry ones (tests, A/B: same results)
     else if (!strcmp(name, "pointer_path")) g_options[DG_OPT_POINTER_PATH] = value;   // 1: 64-bit addressing kernels (tests)
     else return dg_fail(DG_ERR_INVALID, "dg_set_option: unknown option '%s'", name);
     return DG_OK;

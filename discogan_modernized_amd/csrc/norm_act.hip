@@ -47,6 +47,12 @@ __device__ __forceinline__ void bn_st(__bf16* p, const float (&v)[8]) {
     *(bf16x8_n*)p = __builtin_convertvector(t, bf16x8_n);
 }
 
+template <int V>
+__device__ __forceinline__ void bn_stp(float* p, const float (&v)[V]) {
+#pragma unroll
+    for (int h = 0; h < V / 4; ++h) *(f32x4*)(p + 4 * h) = (f32x4){v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+}
+
 __device__ __forceinline__ float bn_norm(float y, float mean, float gs, float beta) { return fmaf(y - mean, gs, beta); }
 
 // Grouped launches (dg_bn_*_g; round 4): the problems of one launch -- the same BatchNorm layer of the A-side and the B-side network, a
@@ -430,6 +436,79 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnGroup G, long t
     }
 }
 
+// fp32 storage in the reduction passes' geometry (round 4): fixed channels per thread -- mean / invstd / gamma / beta loaded ONCE instead
+// of four 16-byte loads per item, no 64-bit index arithmetic per item --, BN_U rows in flight.  The per-element arithmetic is the
+// item kernel's above, expression for expression: results are bitwise the same.  With the plane outputs of the f32x3 path the item
+// kernel ran at 3.5 TB/s of its 10 B per element (five load and three store instructions per item) against 4.9 for the plain split
+// kernel; this form: see DESIGN.md 3.3.  Plane element index of (row, c): pixel-major row * C + c; quad-chunk
+// [M / 4][C / 16][4 pixels][16 channels].  For the quad-chunk layout the host picks TX = 16, so a wave is 4 pixels x 64 channels: whole
+// 128-byte lines of every plane (rows_per is a multiple of 4).
+__device__ __forceinline__ long bn_plane_index(int row, int c, int C, int cm) {
+    if (!cm) return (long)row * C + c;
+    return ((((long)(row >> 2)) * (C >> 4) + (c >> 4)) * 4 + (row & 3)) * 16 + (c & 15);
+}
+typedef __bf16 bf16x8_p __attribute__((ext_vector_type(8)));
+// stores the three planes of V (4 | 8) consecutive channels: one 8- or 16-byte store per plane
+template <int V>
+__device__ __forceinline__ void bn_put_planes(__bf16* p3, long pstride, long pi, const float (&o)[V]) {
+    dg_bf16x4_t h[V / 4], md[V / 4], l[V / 4];
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) dg_split3((f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]}, h[q], md[q], l[q]);
+    if constexpr (V == 4) {
+        *(dg_bf16x4_t*)(p3 + pi) = h[0];
+        *(dg_bf16x4_t*)(p3 + pstride + pi) = md[0];
+        *(dg_bf16x4_t*)(p3 + 2 * pstride + pi) = l[0];
+    } else {
+        *(bf16x8_p*)(p3 + pi) = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *(bf16x8_p*)(p3 + pstride + pi) = __builtin_shufflevector(md[0], md[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *(bf16x8_p*)(p3 + 2 * pstride + pi) = __builtin_shufflevector(l[0], l[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+// V = channels per thread: 4, or 8 with plane outputs (two 16-byte loads, ONE 16-byte store per plane: the plane stores of the V = 4
+// form were 8-byte stores, three per item)
+template <int Z16, int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const BnGroup G, int M, int C, int rows_per, int TX, int act, float slope, long pstride, int cm) {
+    constexpr int U = V == 4 ? BN_U : BN_U / 2;
+    const BnProb& P = G.p[blockIdx.z];
+    const float* __restrict__ y = (const float*)P.y;
+    float* __restrict__ z = (float*)P.out;
+    __bf16* __restrict__ z16 = (__bf16*)P.out16;
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * V;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float mean[V], gs[V], b[V];
+    bn_ldp<V>(P.saved + c, mean);
+    bn_ldp<V>(P.saved + C + c, b);         // invstd for now
+    bn_ldp<V>(P.gamma + c, gs);
+#pragma unroll
+    for (int j = 0; j < V; ++j) gs[j] = gs[j] * b[j];
+    bn_ldp<V>(P.beta + c, b);
+    auto put = [&](int row, const float (&v)[V]) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = dg_apply_act(bn_norm(v[j], mean[j], gs[j], b[j]), act, slope);
+        if (Z16 != 3 || z != nullptr) bn_stp<V>(z + (long)row * C + c, o);      // plane-only output (f32x3 path): the fp32 copy has no reader
+        if constexpr (Z16 == 1) *(bf16x4_n*)(z16 + (long)row * C + c) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (Z16 == 3) bn_put_planes<V>(z16, pstride, bn_plane_index(row, c, C, cm), o);
+    };
+    const float* py = y + c;
+    int r = r0 + ty;
+    for (; r + (U - 1) * TY < r1; r += U * TY) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) bn_ldp<V>(py + (long)(r + u * TY) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) put(r + u * TY, v[u]);
+    }
+    for (; r < r1; r += TY) {
+        float v[V];
+        bn_ldp<V>(py + (long)r * C, v);
+        put(r, v);
+    }
+}
+
 // bf16 storage, forward apply with the reduction passes' geometry: fixed channels per thread (parameters loaded once, no
 // 64-bit modulo per access), U rows in flight
 __global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const BnGroup G, int M, int C, int rchunks, int TX, int act, float slope) {
@@ -756,6 +835,88 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnGroup G, long
     }
 }
 
+// the fp32-storage backward apply in the same geometry (see bn_act_fwd_rows_kernel): per-channel constants -- the four parameters and the
+// two fp64 coefficients -- once per thread instead of six 16-byte and eight 8-byte loads per item; the item kernel's fp64 expression.
+template <int D16, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnGroup G, int M, int C, int rows_per, int TX, int coef_rchunks, int act, float slope,
+                                                                long pstride, int cm) {
+    constexpr int U = V == 4 ? BN_U / 2 : BN_U / 4;
+    const BnProb& P = G.p[blockIdx.z];
+    const float* __restrict__ dz = (const float*)P.dz;
+    const float* __restrict__ y = (const float*)P.y;
+    float* __restrict__ dy = (float*)P.out;
+    __bf16* __restrict__ dy16 = (__bf16*)P.out16;
+    const double* __restrict__ coef = (const double*)P.ws + (size_t)2 * coef_rchunks * C;
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = (blockIdx.x * TX + tx) * V;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float mean[V], istd[V], g[V], b[V], gs[V];
+    double c1[V], c2[V];
+    bn_ldp<V>(P.saved + c, mean);
+    bn_ldp<V>(P.saved + C + c, istd);
+    bn_ldp<V>(P.gamma + c, g);
+    bn_ldp<V>(P.beta + c, b);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        gs[j] = g[j] * istd[j];
+        c1[j] = coef[c + j];
+        c2[j] = coef[C + c + j];
+    }
+    auto put = [&](int row, const float (&v)[V], const float (&d)[V]) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float u = bn_norm(v[j], mean[j], gs[j], b[j]);
+            const double gg = (double)(d[j] * act_grad(u, act, slope));
+            const double xhat = ((double)v[j] - (double)mean[j]) * (double)istd[j];
+            o[j] = (float)((double)g[j] * (double)istd[j] * (gg - c1[j] - xhat * c2[j]));
+        }
+        if (D16 != 3 || dy != nullptr) bn_stp<V>(dy + (long)row * C + c, o);   // plane-only output (f32x3 path): the fp32 copy has no reader
+        if constexpr (D16 == 1) *(bf16x4_n*)(dy16 + (long)row * C + c) = __builtin_convertvector((f32x4){o[0], o[1], o[2], o[3]}, bf16x4_n);
+        if constexpr (D16 == 3) bn_put_planes<V>(dy16, pstride, bn_plane_index(row, c, C, cm), o);
+    };
+    const float* py = y + c;
+    const float* pd = dz + c;
+    int r = r0 + ty;
+    for (; r + (U - 1) * TY < r1; r += U * TY) {
+        float v[U][V], d[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bn_ldp<V>(py + (long)(r + u * TY) * C, v[u]);
+            bn_ldp<V>(pd + (long)(r + u * TY) * C, d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) put(r + u * TY, v[u], d[u]);
+    }
+    for (; r < r1; r += TY) {
+        float v[V], d[V];
+        bn_ldp<V>(py + (long)r * C, v);
+        bn_ldp<V>(pd + (long)r * C, d);
+        put(r, v, d);
+    }
+}
+// geometry of the two kernels above: TX channel lanes (16 for quad-chunk planes: a wave = 4 pixels x 64 channels), row chunks of a multiple of
+// 8 rows.  Shapes they do not take (C not a multiple of 64, M not of 8) stay on the item kernels.
+struct BnRows { int ok, tx, cchunks, rchunks, rows_per; };
+static BnRows bn_rows(int M, int C, int cm, int V) {
+    BnRows g = {0, 0, 0, 0, 0};
+    if (C % 64 != 0 || M % 8 != 0 || dg_get_option(DG_OPT_BN_ITEMS)) return g;
+    g.ok = 1;
+    g.tx = 64 / V;                                  // quad-chunk planes: a wave = 4 (8) pixels x 64 channels
+    if (!cm) while (g.tx < C / V && g.tx < 64) g.tx <<= 1;
+    g.cchunks = C / (V * g.tx);
+    const int ty = 256 / g.tx;
+    long rc = M / ((long)ty * BN_U);
+    long cap = 4096 / g.cchunks;
+    if (rc > cap) rc = cap;
+    if (rc < 1) rc = 1;
+    g.rows_per = (int)(((M + rc - 1) / rc + 7) / 8 * 8);
+    g.rchunks = (M + g.rows_per - 1) / g.rows_per;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const DgPtrs xs, const DgPtrs ys, long total4, long n, int act, float slope) {
     const float* __restrict__ x = dg_pick<const float>(xs, blockIdx.y);
     float* __restrict__ y = dg_pick<float>(ys, blockIdx.y);
@@ -933,6 +1094,20 @@ static int bn_act_fwd_impl(int groups, const BnGroup& G, int M, int C, int act, 
         DG_CHECK_LAUNCH("bn_act_fwd16");
         return DG_OK;
     }
+    if constexpr (V == 4) {
+        const bool planes = z16 && pstride > 0;
+        if (const BnRows rg = bn_rows(M, C, plane_cm, planes ? 8 : 4); rg.ok) {
+            const dim3 rgrid(rg.cchunks, rg.rchunks, groups);
+            if (planes)
+                hipLaunchKernelGGL((bn_act_fwd_rows_kernel<3, 8>), rgrid, dim3(256), 0, (hipStream_t)stream, G, M, C, rg.rows_per, rg.tx, act, slope, pstride, plane_cm);
+            else if (z16)
+                hipLaunchKernelGGL((bn_act_fwd_rows_kernel<1, 4>), rgrid, dim3(256), 0, (hipStream_t)stream, G, M, C, rg.rows_per, rg.tx, act, slope, 0L, 0);
+            else
+                hipLaunchKernelGGL((bn_act_fwd_rows_kernel<0, 4>), rgrid, dim3(256), 0, (hipStream_t)stream, G, M, C, rg.rows_per, rg.tx, act, slope, 0L, 0);
+            DG_CHECK_LAUNCH("bn_act_fwd_rows");
+            return DG_OK;
+        }
+    }
     const dim3 grid(stream_grid(totalv), groups);
     if constexpr (V == 4) {
         if (z16 && pstride > 0) {
@@ -1010,6 +1185,20 @@ static int bn_act_bwd_impl(int groups, int share, const BnGroup& G, int M, int C
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FIN_CH - 1) / BN_FIN_CH, groups / share), dim3(256), 0, st, G, share, M, C, rc, accumulate);
     DG_CHECK_LAUNCH("bn_bwd_finalize");
     const long totalv = (long)M * C / V;
+    if constexpr (V == 4) {
+        const bool planes = dy16 && pstride > 0;
+        if (const BnRows rg = bn_rows(M, C, plane_cm, planes ? 8 : 4); rg.ok) {
+            const dim3 rgrid(rg.cchunks, rg.rchunks, groups);
+            if (planes)
+                hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<3, 8>), rgrid, dim3(256), 0, st, G, M, C, rg.rows_per, rg.tx, rc, act, slope, pstride, plane_cm);
+            else if (dy16)
+                hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<1, 4>), rgrid, dim3(256), 0, st, G, M, C, rg.rows_per, rg.tx, rc, act, slope, 0L, 0);
+            else
+                hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<0, 4>), rgrid, dim3(256), 0, st, G, M, C, rg.rows_per, rg.tx, rc, act, slope, 0L, 0);
+            DG_CHECK_LAUNCH("bn_bwd_apply_rows");
+            return DG_OK;
+        }
+    }
     const dim3 grid(stream_grid(totalv), groups);
     if constexpr (V == 4) {
         if (dy16 && pstride > 0) {

@@ -83,10 +83,13 @@ const char* dg_last_error(void);
  * 3-channel edge layers also round their operands and run on the bf16 MFMA ("kt" 16 keeps their fp32-MFMA kernels);
  * "bf16" 2: fp32-accurate products from three bf16 planes per operand (f32x3);
  * "no_dma" 1: convolutions with two bf16 operands stay on the register-staged tiles instead of the LDS-DMA kernel;
+ * "bn_items" 1: the fp32 BatchNorm apply passes (forward and backward) on the per-item kernels instead of the row-geometry ones
+ *   (same results bit for bit; same-box A/B and the test that says so);
  * "dma_mfma" 32: the LDS-DMA kernel's 32x32x16 body instead of the default 16x16x32 one; 1: keep the input-grads with <= 128
  *   output channels on the register-staged tiles instead of the window kernels (same-box A/B);
  * (experiments library only, csrc/Makefile EXPERIMENTS=1: "x3_mfma" 16 = the paired-plane 16x16x32 body of the f32x3 plane kernel,
- *   "dgw_persist" 1 = the persistent form of the f32x3 window input-grad kernel -- both measured not faster);
+ *   "dgw_persist" 1 = the persistent form of the f32x3 window input-grad kernel -- both measured not faster, DESIGN.md 3.1;
+ *   "understory" = probe forms of dg_act_fwd for tools/probe_corun.py);
  * (The operand-dropping timing switch of earlier rounds exists only in the separate timing build, csrc/Makefile TIMING=1; the product
  *   library has no option that changes results.) */
 int dg_set_option(const char* name, int value);

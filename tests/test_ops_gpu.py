@@ -675,6 +675,60 @@ def test_batchnorm_writes_plane_triples(N, C, H, act):
         ops.planes_clear()
 
 
+@pytest.mark.parametrize("N,C,H", [(4, 64, 16), (3, 256, 8), (1, 128, 6), (5, 1024, 2), (2, 2048, 4), (32, 64, 64)])
+def test_batchnorm_row_geometry_kernels_equal_item_kernels(N, C, H):
+    """The fp32 BatchNorm apply passes run in the reduction passes' geometry (fixed channels per thread; csrc/norm_act.hip
+    bn_act_fwd_rows_kernel / bn_bwd_apply_rows_kernel) wherever C % 64 == 0 and M % 4 == 0; option "bn_items" 1 puts them back on the
+    per-item kernels.  Same expressions: every output -- fp32, bf16 shadow, plane triples in both layouts, grouped launches, ragged row
+    chunks -- must be bitwise the same."""
+    yg, dzg = nhwc(rnd(N, C, H, H, seed=1, scale=2.0) + 0.3), nhwc(rnd(N, C, H, H, seed=4))
+    y2, dz2 = nhwc(rnd(N, C, H, H, seed=11, scale=0.5) - 0.1), nhwc(rnd(N, C, H, H, seed=14))
+    gg, bg = (rnd(C, seed=2) + 1.5).to(DEV), rnd(C, seed=3).to(DEV)
+
+    def run():
+        out = {}
+        saved = ops.bn_train_stats(yg, None, None, None, 1e-5, 0.1)
+        saved2 = ops.bn_train_stats(y2, None, None, None, 1e-5, 0.1)
+        for act in (ops.ACT_LEAKY, ops.ACT_RELU, ops.ACT_NONE):
+            out[("z", act)] = ops.bn_act_fwd(yg, saved, gg, bg, act, 0.2)
+            out[("bwd", act)] = ops.bn_act_bwd(dzg, yg, saved, gg, bg, act, 0.2)
+        zs = ops.bn_act_fwd_g([yg, y2], [saved, saved2], [gg, gg], [bg, bg], ops.ACT_LEAKY, 0.2)
+        out["zg"] = tuple(zs)
+        dgs, dbs = [torch.zeros(C, device=DEV) for _ in range(2)], [torch.zeros(C, device=DEV) for _ in range(2)]
+        out["bwdg"] = (ops.bn_act_bwd_g([dzg, dz2], [yg, y2], [saved, saved2], [gg, gg], [bg, bg], ops.ACT_LEAKY, 0.2, dgs, dbs, False), dgs, dbs)
+        ops.SHADOW = True
+        try:
+            z = ops.bn_act_fwd(yg, saved, gg, bg, ops.ACT_LEAKY, 0.2)
+            dy = ops.bn_act_bwd(dzg, yg, saved, gg, bg, ops.ACT_LEAKY, 0.2)[0]
+            out["shadow"] = (z, ops._SHADOW_TAB[z.data_ptr()][1].clone(), dy, ops._SHADOW_TAB[dy.data_ptr()][1].clone())
+        finally:
+            ops.SHADOW = False
+            ops.shadow_clear()
+        ops.X3 = True
+        try:
+            for cm in ((False, True) if (N * H * H) % 4 == 0 else (False,)):
+                z = ops.bn_act_fwd(yg, saved, gg, bg, ops.ACT_RELU, 0.2, planes_cm=cm, planes_only=True)
+                dy = ops.bn_act_bwd(dzg, yg, saved, gg, bg, ops.ACT_RELU, 0.2, planes_cm=cm, planes_only=True)[0]
+                out[("planes", cm)] = (ops._PLANE_TAB[z.data_ptr()][1].clone(), ops._PLANE_TAB[dy.data_ptr()][1].clone())
+        finally:
+            ops.X3 = False
+            ops.planes_clear()
+        return out
+
+    def flat(v):
+        return [t for x in (v if isinstance(v, (tuple, list)) else (v,)) for t in (flat(x) if isinstance(x, (tuple, list)) else (x,))]
+    rows = run()
+    _lib.set_option("bn_items", 1)
+    try:
+        items = run()
+    finally:
+        _lib.set_option("bn_items", 0)
+    assert rows.keys() == items.keys()
+    for k in rows:
+        for a, b in zip(flat(rows[k]), flat(items[k])):
+            assert torch.equal(a, b), k
+
+
 def test_bn_needs_two_values():
     y = nhwc(rnd(1, 100, 1, 1))
     with pytest.raises(_lib.DiscoganHipError, match="more than 1 value"):
