@@ -19,6 +19,7 @@ prof f32x3_single_stream_eager --no_graph --single_stream
 prof f32_single_stream_eager --mfma_dtype f32 --no_graph --single_stream
 prof bf16_single_stream_eager --mfma_dtype bf16 --act_dtype bf16 --no_graph --single_stream
 cd $R
+[ -n "$NO_PMC" ] && { echo "r04 kernel-stat profiles done (NO_PMC)"; exit 0; }
 bash tools/pmc_round.sh 64 64 r04 "" ""
 bash tools/pmc_round.sh 64 64 r04 "--bf16 2" _f32x3
 echo "r04 profiles done"
