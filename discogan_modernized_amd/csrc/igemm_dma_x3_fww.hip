@@ -106,6 +106,11 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
         const int a = a0 - 1 + wr, b = wc - 1;
         const bool ok = row < WR && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
         w_ob[j] = ok ? ((((n_img * H + 2 * a) * W + 2 * b) * Cc) + g * 8) * 2 : OOR;
+#ifdef DG_TIMING_KNOBS
+        // timing experiment (WRONG results), dbg_zero bit 128: what would the kernel cost if a window were one CONTIGUOUS run of its plane
+        // (a parity-split chunk-major layout)?  Lane L of piece pc fetches granule 64 pc + L of a run that starts at a per-tile offset.
+        if (p.dbg_zero & 128) w_ob[j] = row < WR ? (int)(((long)tm * 16 * WR * 32) % (long)(p.abytes - 17 * 1024 * 17)) + (pc * 64 + lane) * 16 : OOR;
+#endif
     }
     // ---- weight DMA descriptor: stage image per plane = [tap of the pair][16 c][128 k]; this wave's piece = 4 rows of one tap -------
     // lane L lands in (row 4 (w & 3) + L / 16, slot L % 16) of tap w >> 2, fetches granule slot ^ kmswz(row) of wT row (r, s, c0 + row)
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_ptr)smem;
     auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int lds_off, int voff) {
         unsigned keep;
-        const unsigned dst = lds_base + (unsigned)lds_off;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)lds_off);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(voff), "s"(r), "s"(dst)
@@ -130,7 +135,10 @@ __global__ __launch_bounds__(512, 2) void igemm_x3_fww_kernel(const IgemmArgs p)
     // the whole window (three planes) of super-chunk sc into window stage `ast`
     auto issue_window = [&](int ast, int sc) {
         const int c = sc_c(sc), q = sc_q(sc), qy = q >> 1, qx = q & 1;
-        const int scoff = ((qy * W + qx) * Cc + c * KT) * 2;
+        int scoff = ((qy * W + qx) * Cc + c * KT) * 2;
+#ifdef DG_TIMING_KNOBS
+        if (p.dbg_zero & 128) scoff = sc * WR * 32;
+#endif
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
