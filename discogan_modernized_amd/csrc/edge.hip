@@ -1099,6 +1099,13 @@ __global__ __launch_bounds__(256, 2) void c3_wgrad_bf16mfma_kernel(const float* 
 // the six plane products of igemm.hip's PREC 2 -- fp32-accurate, 24 MFMAs of 32 cycles per 16 pixels and wave where the fp32-MFMA
 // kernel above needs 96 of 64, with coalesced image loads instead of its 24-lines-per-instruction gathers.
 #define CWL_WOMAX 256
+template <typename F>
+__device__ __forceinline__ void c3_static_for4(F&& f) {
+    f(std::integral_constant<int, 0>{});
+    f(std::integral_constant<int, 1>{});
+    f(std::integral_constant<int, 2>{});
+    f(std::integral_constant<int, 3>{});
+}
 template <bool FACT, bool X3 = false>
 __global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const DgPtrs dys, const DgPtrs xs, const DgPtrs parts, int N, int H, int W, int K,
                                                               long npix, int rows_per_wg, const DgPtrs act_outs, float slope) {
@@ -1185,8 +1192,11 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const DgP
         }
     };
     // ---- A operand of batch b of row u: 8 pixels per lane, one dword (two channels) each
+    // X3: FOUR register sets -- one workgroup of four waves per CU (101 KB of LDS) is one wave per SIMD, and with one item of 8 x 512 bytes
+    // per wave in flight the kernel moved 2.6 TB/s (4 MB under way on the whole chip); three items ahead: see the deep loop below
+    constexpr int NSET = X3 ? 4 : 2;
     unsigned wa[2][X3 ? 1 : 8], wo[2][(FACT && !X3) ? 8 : 1];
-    f32x2_w fa2[2][X3 ? 8 : 1], fo2[2][(FACT && X3) ? 8 : 1];      // X3: fp32 pairs (channels 2 l31, 2 l31 + 1) of the lane's 8 pixels
+    f32x2_w fa2[NSET][X3 ? 8 : 1], fo2[NSET][(FACT && X3) ? 8 : 1];      // X3: fp32 pairs (channels 2 l31, 2 l31 + 1) of the lane's 8 pixels
     const int nbatch = Wo >> 4;
     auto load_a = [&](int set, int u, int b) {
 #pragma unroll
@@ -1295,6 +1305,26 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const DgP
     }
     load_a(0, u0, wave);
     __syncthreads();
+    if constexpr (X3) {
+        // deep form (rows of 256 output pixels = 4 items per wave and row, the 512 px layer): item j of a row lives in register set j, the
+        // A operand of the item THREE ahead is requested before item j is multiplied.  Same items, same order, same arithmetic.
+        if (nbatch == 16) {
+            load_a(1, u0, wave + 4);
+            load_a(2, u0, wave + 8);
+            for (int u = u0; u < u1; ++u) {
+                const int st = (u - u0) & 1;
+                if (u + 1 < u1) stage_load(u + 1);
+                c3_static_for4([&](auto J_) {
+                    constexpr int J = decltype(J_)::value;
+                    constexpr int JN = (J + 3) & 3;
+                    load_a(JN, J + 3 >= 4 ? u + 1 : u, wave + 4 * JN);
+                    mma_x3(J, st, wave + 4 * J);
+                });
+                if (u + 1 < u1) stage_store(st ^ 1);
+                __syncthreads();
+            }
+        }
+    }
     // this wave's work items: batches wave, wave + 4, ... of every row; while item k is multiplied out of register set (k & 1)
     // the A operand of item k + 1 (of this or the next row) is loaded into the other set
     bool odd = false;
@@ -1304,7 +1334,7 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void c3_wgrad_lds_kernel(const DgP
         load_a(S ^ 1, last ? u + 1 : u, last ? wave : b + 4);
         mma(S, st, b);
     };
-    for (int u = u0; u < u1; ++u) {
+    for (int u = (X3 && nbatch == 16) ? u1 : u0; u < u1; ++u) {
         const int st = (u - u0) & 1;
         if (u + 1 < u1) stage_load(u + 1);                        // the next row's image rows fly under this row's MFMAs
         for (int b = wave; b < nbatch; b += 4) {
