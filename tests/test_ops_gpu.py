@@ -851,6 +851,38 @@ def test_adam_flat_matches_torch():
     assert float(mo.state[0]) == 5.0
 
 
+@pytest.mark.parametrize("n,off", [(8 * 1000 + 5, 0), (4096, 4), (37, 0), (100003, 12), (1 << 20, 0)])
+def test_adam_forms_agree(n, off):
+    """The Adam kernel's three forms -- plain, + bf16 shadow, + three bf16 planes (8 parameters per trip with 16-byte plane stores where
+    the range starts on a 16-byte plane granule, else 4) -- update p / m / v bit for bit alike on ranges of any length and offset; the
+    shadow is the rounded parameter, the planes are dg_f32_to_bf16x3 of it."""
+    tot = n + off + 16
+    base = [torch.randn(tot, generator=torch.Generator().manual_seed(i)).to(DEV) * 0.05 for i in range(4)]
+    base[3].abs_()
+    state = torch.zeros(8, device=DEV, dtype=torch.float64)
+    ops.adam_advance(state, 2e-4, 0.5, 0.999)
+    runs = []
+    for form in range(3):
+        p, g, m, v = (t.clone() for t in base)
+        p16 = torch.zeros(tot, device=DEV, dtype=torch.bfloat16)
+        PE = (tot + 7) // 8 * 8
+        p3 = torch.zeros((3, PE), device=DEV, dtype=torch.bfloat16)
+        sl = slice(off, off + n)
+        kw = {} if form == 0 else (dict(p16=p16[sl]) if form == 1 else dict(p3=(p3.data_ptr() + 2 * off, p3.stride(0))))
+        ops.adam_step_flat(p[sl], g[sl], m[sl], v[sl], state, 0.5, 0.999, 1e-8, 1e-5, **kw)
+        runs.append((p, m, v, p16, p3))
+    for form in (1, 2):
+        for a, b in zip(runs[0][:3], runs[form][:3]):
+            assert torch.equal(a, b), form
+    p = runs[0][0]
+    assert torch.equal(p[:off], base[0][:off]) and torch.equal(p[off + n:], base[0][off + n:])            # nothing outside the range
+    assert torch.equal(runs[1][3][off:off + n], p[off:off + n].bfloat16()) and not bool(runs[1][3][off + n:].float().any())
+    ref3 = torch.zeros((3, n + 8 - n % 8 if n % 8 else n), device=DEV, dtype=torch.bfloat16)
+    ops.f32_to_bf16x3(p[off:off + n].clone(), ref3)
+    got3 = runs[2][4]
+    assert torch.equal(got3[:, off:off + n], ref3[:, :n]) and not bool(got3[:, off + n:].float().any()) and not bool(got3[:, :off].float().any())
+
+
 def test_layout_roundtrip():
     x = rnd(3, 20, 6, 10, seed=5).to(DEV)
     y = ops.as_nhwc(x)
