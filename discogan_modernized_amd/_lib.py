@@ -38,6 +38,8 @@ SIGNATURES = {
     "dg_conv_wgrad_g": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_fwd_p": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dg_conv4x4s2_c3_dgrad_p": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "dg_c3_dgrad_act_ok": (_i, [_i]),
+    "dg_conv4x4s2_c3_dgrad_act_p": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_wgrad_p": (_i, [_p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "dg_conv4x4s2_c3_fwd_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dg_conv4x4s2_c3_dgrad_g": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

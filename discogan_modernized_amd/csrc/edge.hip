@@ -196,9 +196,14 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_mfma_kernel(const float* __re
 // X3 (fp32 dy, option "bf16" = 2, the f32x3 path): the same 16x16x32 GEMM with fp32-ACCURATE products -- a lane's 8 fp32 dy values
 // of a k32 step and the weights are split into their three bf16 planes in registers (24 significand bits), six MFMAs per block
 // (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): 72 MFMAs of 16 cycles per tile and wave instead of 96 of 32.
-template <bool IN16, bool MF16 = false, bool X3 = false>
+// FACT (round 4; dg_conv4x4s2_c3_dgrad_act_p): dy is taken through the backward of the layer's fused LeakyReLU on the way in -- dy * (out > 0 ? 1 :
+// slope) with `out` the layer's saved output, loaded with dy's own offsets one tile ahead and applied to the prefetched register set at
+// the end of the current tile (one more set of 32 registers, not two) -- instead of a stand-alone act_bwd pass that reads both tensors
+// and writes a third (12 B per element at fp32) in front of this kernel.  Same expression as act_bwd_kernel / act_bwd16_kernel (bf16: fp32
+// product rounded to bf16, RNE): the input-gradient is bitwise the unfused one.
+template <bool IN16, bool MF16 = false, bool X3 = false, bool FACT = false>
 __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs dys, const DgPtrs ws_, const DgPtrs dxs, int N, int H, int W, int act,
-                                                                  int tiles_r, int tiles_c, int ntiles, unsigned dybytes) {
+                                                                  int tiles_r, int tiles_c, int ntiles, unsigned dybytes, const DgPtrs aos, float slope) {
     // grouped launch (dg_conv4x4s2_c3_dgrad_g): blockIdx.y = problem
     const float* __restrict__ dy = dg_pick<const float>(dys, blockIdx.y);
     const float* __restrict__ w = dg_pick<const float>(ws_, blockIdx.y);
@@ -250,8 +255,34 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs d
         }
     }
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)(FACT ? dg_pick<const float>(aos, blockIdx.y) : dy), 0, (int)dybytes, 0x00020000);
     constexpr int OOR = (int)0x80000000;
     f32x4 areg[2][2][4];            // [set][row group][4 x float4 = 16 k values]
+    f32x4 oreg[FACT ? 2 : 1][4];    // FACT: the saved activation output at the offsets of the set being prefetched
+    // FACT: areg[set] <- areg[set] * (oreg > 0 ? 1 : slope), element by element (bf16: both halves of every dword, product rounded RNE)
+    auto apply_act = [&](int set) {
+        if constexpr (FACT) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < (IN16 ? 2 : 4); ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (IN16) {
+                            const unsigned dv = __float_as_uint(areg[set][g][j][e]), ov = __float_as_uint(oreg[g][j][e]);
+                            float d0 = __builtin_bit_cast(float, dv << 16), d1 = __builtin_bit_cast(float, dv & 0xffff0000u);
+                            d0 = __builtin_bit_cast(float, ov << 16) > 0.f ? d0 : d0 * slope;
+                            d1 = __builtin_bit_cast(float, ov & 0xffff0000u) > 0.f ? d1 : d1 * slope;
+                            typedef __bf16 bf16x2_a __attribute__((ext_vector_type(2)));
+                            typedef float f32x2_a __attribute__((ext_vector_type(2)));
+                            areg[set][g][j][e] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_a){d0, d1}, bf16x2_a)));
+                        } else {
+                            const float d = areg[set][g][j][e];
+                            areg[set][g][j][e] = oreg[g][j][e] > 0.f ? d : d * slope;
+                        }
+                    }
+        }
+    };
     auto fetch = [&](int t, int set) {
         const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
 #pragma unroll
@@ -260,11 +291,15 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs d
             const bool ok = t < ntiles && (unsigned)a < (unsigned)Ho && (unsigned)b < (unsigned)Wo;
             const int off = ok ? (((n * Ho + a) * Wo + b) * CD_K + ((MF16 || X3) ? 8 : 16) * kq) * (IN16 ? 2 : 4) : OOR;   // out of range reads 0 = zero padding
 #pragma unroll
-            for (int j = 0; j < (IN16 ? 2 : 4); ++j)      // X3: float4 j holds k = 32 (j >> 1) + 8 kq + 4 (j & 1) ..+3
-                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + (X3 ? 128 * (j >> 1) + 16 * (j & 1) : (MF16 ? 64 : 16) * j), 0, 0));
+            for (int j = 0; j < (IN16 ? 2 : 4); ++j) {    // X3: float4 j holds k = 32 (j >> 1) + 8 kq + 4 (j & 1) ..+3
+                const int o = off + (X3 ? 128 * (j >> 1) + 16 * (j & 1) : (MF16 ? 64 : 16) * j);
+                areg[set][g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o, 0, 0));
+                if constexpr (FACT) oreg[g][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rao, o, 0, 0));
+            }
         }
     };
     fetch(blockIdx.x, 0);
+    apply_act(0);
     auto tile = [&](auto SB, int t) {
         constexpr int S = decltype(SB)::value;
         const int tc = t % tiles_c, tr = (t / tiles_c) % tiles_r, n = t / (tiles_c * tiles_r);
@@ -340,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs d
             if (act == DG_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
             if (y < H && x < W) dx[((long)(n * 3 + c) * H + y) * W + x] = v;
         }
+        apply_act(S ^ 1);                         // FACT: the prefetched set, its `out` values have landed with it
     };
     // (Round 4: dealing each XCD a run of CONSECUTIVE tiles, so that the halo rows / columns neighbouring tiles share -- 885 MB per launch
     // by the counters against 637 MB of operands + output -- meet in one L2, changed nothing: 0.252 -> 0.258 ms f32x3, 0.284 -> 0.265 fp32,
@@ -353,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void c3_dgrad_scatter_kernel(const DgPtrs d
 extern "C" size_t dg_c3_dgrad_workspace_bytes(int K) { return K == CD_K ? (size_t)CD_NK * 16 * sizeof(float) : 0; }
 // groups > 1 (dg_conv4x4s2_c3_dgrad_g): the scatter form only (K == 64, fp32 dy)
 static int c3_dgrad_run(int groups, const float* const* dy_nhwc, int dy_bf16, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,
-                        int act, void* ws, size_t ws_bytes, dg_stream_t stream);
+                        int act, void* ws, size_t ws_bytes, dg_stream_t stream, const void* act_out = nullptr, float slope = 0.f);
 extern "C" int dg_conv4x4s2_c3_dgrad(const float* dy_nhwc, const float* w, float* dx_nchw, int N, int H, int W, int K,
                                      int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
     return c3_dgrad_run(1, &dy_nhwc, 0, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
@@ -370,6 +406,18 @@ extern "C" int dg_conv4x4s2_c3_dgrad_p(const void* dy_nhwc, int dy_bf16, const f
     const float* dyp = (const float*)dy_nhwc;
     return c3_dgrad_run(1, &dyp, dy_bf16, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream);
 }
+// 1 when the fused form below exists for this K under the options in force (the scatter kernel: K == 64, option "kt" != 16)
+extern "C" int dg_c3_dgrad_act_ok(int K) { return K == CD_K && dg_get_option(DG_OPT_KT) != 16 ? 1 : 0; }
+// conv1's input-gradient with the backward of the layer's fused LeakyReLU applied to dy in the load path: dx = dgrad(dy * (act_out > 0 ? 1 : slope))
+extern "C" int dg_conv4x4s2_c3_dgrad_act_p(const void* dy_nhwc, int dy_bf16, const void* act_out, int in_act, float slope, const float* w, float* dx_nchw,
+                                           int N, int H, int W, int K, int act, int prec, void* ws, size_t ws_bytes, dg_stream_t stream) {
+    DG_CHECK_ARG(prec >= DG_PREC_DEFAULT && prec <= DG_PREC_F32X3, "dg_conv4x4s2_c3_dgrad_act_p: prec=%d", prec);
+    DG_CHECK_ARG(act_out && in_act == DG_ACT_LEAKY, "dg_conv4x4s2_c3_dgrad_act_p: needs the saved output of a fused LeakyReLU (in_act=%d)", in_act);
+    DG_CHECK_ARG(dg_c3_dgrad_act_ok(K), "dg_conv4x4s2_c3_dgrad_act_p: the fused form is the scatter kernel (K == 64, option kt != 16)");
+    DgPrecScope scope(prec);
+    const float* dyp = (const float*)dy_nhwc;
+    return c3_dgrad_run(1, &dyp, dy_bf16, &w, &dx_nchw, N, H, W, K, act, ws, ws_bytes, stream, act_out, slope);
+}
 extern "C" int dg_conv4x4s2_c3_dgrad_g(int groups, const float* const* dy_nhwc, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,
                                        int act, int prec, dg_stream_t stream) {
     DG_CHECK_ARG(groups >= 1 && groups <= DG_MAX_GROUPS && dy_nhwc && w && dx_nchw, "dg_conv4x4s2_c3_dgrad_g: bad group / null table");
@@ -379,7 +427,8 @@ extern "C" int dg_conv4x4s2_c3_dgrad_g(int groups, const float* const* dy_nhwc, 
     return c3_dgrad_run(groups, dy_nhwc, 0, w, dx_nchw, N, H, W, K, act, nullptr, 0, stream);
 }
 static int c3_dgrad_run(int groups, const float* const* dy_tab, int dy_bf16, const float* const* w_tab, float* const* dx_tab, int N, int H, int W, int K,
-                        int act, void* ws, size_t ws_bytes, dg_stream_t stream) {
+                        int act, void* ws, size_t ws_bytes, dg_stream_t stream, const void* act_out, float slope) {
+    DG_CHECK_ARG(act_out == nullptr || groups == 1, "dg_conv4x4s2_c3_dgrad: the fused activation backward takes one problem");
     for (int i = 0; i < groups; ++i) DG_CHECK_ARG(dy_tab[i] && w_tab[i] && dx_tab[i], "dg_conv4x4s2_c3_dgrad: null pointer");
     const float* dy_nhwc = dy_tab[0];
     const float* w = w_tab[0];
@@ -399,22 +448,23 @@ static int c3_dgrad_run(int groups, const float* const* dy_tab, int dy_bf16, con
             const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512), groups);
             const DgPtrs pd = dg_ptrs((const void* const*)dy_tab, groups), pw = dg_ptrs((const void* const*)w_tab, groups),
                          px = dg_ptrs((const void* const*)dx_tab, groups);
-            if (dy_bf16 && dg_cur_prec() == 1)      // bf16 matrix path: bf16 MFMA
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, true>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
-                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
-            else if (dy_bf16)
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<true, false>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
-                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 2));
-            else if (dg_cur_prec() == 2)           // f32x3 path: fp32-accurate products on the bf16 MFMA
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false, true>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
-                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
-            else
-                hipLaunchKernelGGL((c3_dgrad_scatter_kernel<false, false>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act,
-                                   tiles_r, tiles_c, (int)ntiles, (unsigned)((long)N * Ho * Wo * CD_K * 4));
+            const DgPtrs pa = dg_ptrs1(act_out ? act_out : (const void*)dy_tab[0]);
+            const unsigned dyb = (unsigned)((long)N * Ho * Wo * CD_K * (dy_bf16 ? 2 : 4));
+#define C3_SCATTER(...) hipLaunchKernelGGL((c3_dgrad_scatter_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, pd, pw, px, N, H, W, act, tiles_r, tiles_c, (int)ntiles, dyb, pa, slope)
+            if (dy_bf16 && dg_cur_prec() == 1) {      // bf16 matrix path: bf16 MFMA
+                if (act_out) C3_SCATTER(true, true, false, true); else C3_SCATTER(true, true);
+            } else if (dy_bf16) {
+                if (act_out) C3_SCATTER(true, false, false, true); else C3_SCATTER(true, false);
+            } else if (dg_cur_prec() == 2) {          // f32x3 path: fp32-accurate products on the bf16 MFMA
+                if (act_out) C3_SCATTER(false, false, true, true); else C3_SCATTER(false, false, true);
+            } else {
+                if (act_out) C3_SCATTER(false, false, false, true); else C3_SCATTER(false, false);
+            }
+#undef C3_SCATTER
             DG_CHECK_LAUNCH("c3_dgrad_scatter");
             return DG_OK;
         }
-        DG_CHECK_ARG(groups == 1, "dg_conv4x4s2_c3_dgrad: the gather form takes one problem");
+        DG_CHECK_ARG(groups == 1 && !act_out, "dg_conv4x4s2_c3_dgrad: the gather form takes one problem and no fused activation backward");
         const int tiles_r = (Ho + CD_TR - 1) / CD_TR, tiles_c = (Wo + CD_TC - 1) / CD_TC;
         const long ntiles = (long)N * tiles_r * tiles_c;
         DG_CHECK_ARG(ntiles < (1L << 31), "dg_conv4x4s2_c3_dgrad: too many tiles");
@@ -428,7 +478,7 @@ static int c3_dgrad_run(int groups, const float* const* dy_tab, int dy_bf16, con
         DG_CHECK_LAUNCH("c3_dgrad_mfma");
         return DG_OK;
     }
-    DG_CHECK_ARG(groups == 1, "dg_conv4x4s2_c3_dgrad: the VALU form takes one problem");
+    DG_CHECK_ARG(groups == 1 && !act_out, "dg_conv4x4s2_c3_dgrad: the VALU form takes one problem and no fused activation backward");
     const long nquad = (long)N * Ho * Wo;
     hipLaunchKernelGGL(c3_dgrad_valu_kernel, dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, st, dy_nhwc, w,
                        dx_nchw, N, H, W, K, dg_ilog2(Ho), dg_ilog2(Wo), act);

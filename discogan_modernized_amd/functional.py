@@ -35,6 +35,11 @@ def _bwd(f):
     return staticmethod(w)
 
 
+# ConvC3Fn.backward with an input gradient: take the LeakyReLU backward inside the input-gradient and the weight-gradient kernels (bitwise
+# the same results as the stand-alone act_bwd pass in front of them; False = that pass, for A/B)
+FUSE_C3_DGRAD_ACT = __import__("os").environ.get("DG_FUSE_C3_DGRAD_ACT", "1") != "0"
+
+
 def _flat_grad_of(param):
     """The flat-buffer gradient view of a parameter (optim.Adam installs it) when it is the live .grad:
     backward kernels then accumulate into it directly and autograd gets None for that input, instead of
@@ -183,14 +188,18 @@ class ConvC3Fn(Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         act, slope = ctx.act
-        if ctx.needs_input_grad[0] or act == ops.ACT_NONE:
+        fused_dgrad = FUSE_C3_DGRAD_ACT and act == ops.ACT_LEAKY and ops.c3_dgrad_act_ok(w.shape[0])
+        if act == ops.ACT_NONE or (ctx.needs_input_grad[0] and not fused_dgrad):
             g = ops.act_bwd(dy, y, act, slope) if act != ops.ACT_NONE else ops.as_nhwc(dy)
             fuse = {}
         else:
-            # weight gradient only (image input): the activation backward rides in the wgrad kernel's dy loads
+            # the activation backward rides in the dy loads of the weight-gradient kernel and (round 4) of the input-gradient kernel: no
+            # stand-alone pass that reads dy and the saved output and writes a third tensor of that size
             g = ops.as_nhwc(dy)
             fuse = dict(act_out=y, act=act, slope=slope)
-        dx = ops.c3_dgrad(g, w, ops.ACT_NONE) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.c3_dgrad(g, w, ops.ACT_NONE, act_out=y, in_act=act, slope=slope) if fuse else ops.c3_dgrad(g, w, ops.ACT_NONE)
         dw = None
         if ctx.needs_input_grad[1]:
             fg = _flat_grad_of(ctx.wref)

@@ -688,9 +688,16 @@ def c3_fwd(x_nchw, w, act=ACT_NONE, slope=0.2, want_planes=False):
     return y
 
 
-def c3_dgrad(dy, w, act=ACT_NONE):
-    """dy NHWC-memory [N,K,Ho,Wo], w contiguous [K,3,4,4] -> contiguous NCHW [N,3,2Ho,2Wo] (act fused)."""
-    _check_dev(dy, allow16=True)
+def c3_dgrad_act_ok(k):
+    """Does the input-gradient kernel take the layer's activation backward in its load path (c3_dgrad(..., act_out=...))?"""
+    return bool(_lib.load().dg_c3_dgrad_act_ok(int(k)))
+
+
+def c3_dgrad(dy, w, act=ACT_NONE, act_out=None, in_act=ACT_NONE, slope=0.2):
+    """dy NHWC-memory [N,K,Ho,Wo], w contiguous [K,3,4,4] -> contiguous NCHW [N,3,2Ho,2Wo] (act fused).
+    With ``act_out`` (the saved output of the layer's fused LeakyReLU; needs c3_dgrad_act_ok(K)) dy is taken through the activation
+    backward on the fly -- bitwise c3_dgrad(act_bwd(dy, act_out, in_act, slope), w, act) without the pass in front."""
+    _check_dev(dy, act_out, allow16=True)
     _check_dev(w)
     dy = as_nhwc(dy)
     w = w.contiguous()
@@ -698,6 +705,14 @@ def c3_dgrad(dy, w, act=ACT_NONE):
     dx = torch.empty((n, 3, 2 * ho, 2 * wo), device=dy.device, dtype=torch.float32)
     L = _lib.load()
     ws, wsb = _ws(L.dg_c3_dgrad_workspace_bytes(k), dy.device)
+    if act_out is not None and in_act != ACT_NONE:
+        ao = as_nhwc(act_out)
+        if ao.shape != dy.shape or ao.dtype != dy.dtype or ao.stride() != dy.stride():
+            raise _lib.DiscoganHipError("c3_dgrad: act_out must have dy's shape, type and layout")
+        with _hbm("edge_c3_dgrad", 2.0 * dy.numel() * dy.element_size() + 4.0 * dx.numel()):
+            _lib.check(L.dg_conv4x4s2_c3_dgrad_act_p(_ptr(dy), int(_is16(dy)), _ptr(ao), in_act, float(slope), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k,
+                                                     act, _CUR.cprec, _ptr(ws), wsb, _stream()), "dg_conv4x4s2_c3_dgrad_act_p")
+        return dx
     with _hbm("edge_c3_dgrad", dy.numel() * dy.element_size() + 4.0 * dx.numel()):
         _lib.check(L.dg_conv4x4s2_c3_dgrad_p(_ptr(dy), int(_is16(dy)), _ptr(w), _ptr(dx), n, 2 * ho, 2 * wo, k, act, _CUR.cprec, _ptr(ws), wsb,
                                              _stream()), "dg_conv4x4s2_c3_dgrad_p")

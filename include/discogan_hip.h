@@ -212,6 +212,13 @@ int dg_conv4x4s2_c3_dgrad_p(const void* dy_nhwc, int dy_bf16, const float* w, fl
 int dg_conv4x4s2_c3_wgrad_p(const void* dy_nhwc, const void* act_out_nhwc, int io_bf16, int act, float slope,
                             const float* x_nchw, float* dw, int N, int H, int W, int K, int prec, int accumulate,
                             void* ws, size_t ws_bytes, dg_stream_t s);
+/* The input-gradient of nn.Conv2d(3,K,4,2,1) (model.py:8,80) with the backward of the layer's in-place LeakyReLU (model.py:9,81) applied to
+ * dy on the way in -- dx = dgrad(dy * (act_out > 0 ? 1 : slope)), act_out = the layer's saved output (same layout and type as dy),
+ * in_act = DG_ACT_LEAKY -- instead of a stand-alone dg_act_bwd pass in front of dg_conv4x4s2_c3_dgrad_p; bitwise the unfused result.
+ * Exists where dg_c3_dgrad_act_ok(K) returns 1 (K == 64 on the scatter kernel); other arguments as dg_conv4x4s2_c3_dgrad_p. */
+int dg_c3_dgrad_act_ok(int K);
+int dg_conv4x4s2_c3_dgrad_act_p(const void* dy_nhwc, int dy_bf16, const void* act_out_nhwc, int in_act, float slope, const float* w,
+                                float* dx_nchw, int N, int H, int W, int K, int act, int prec, void* ws, size_t ws_bytes, dg_stream_t s);
 int dg_conv4x4s2_c3_fwd_g(int groups, const float* const* x_nchw, const float* const* w, float* const* y_nhwc, int N, int H, int W, int K,
                           int act, float slope, int prec, dg_stream_t s);
 int dg_conv4x4s2_c3_dgrad_g(int groups, const float* const* dy_nhwc, const float* const* w, float* const* dx_nchw, int N, int H, int W, int K,

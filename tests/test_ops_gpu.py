@@ -1209,6 +1209,39 @@ def test_conv_f32x3_forward_window_kernel(N, C, K, H, monkeypatch):
     assert e3 <= 2.0 * max(e32, ereg) + 2e-7, f"window forward: {e3:.2e} vs fp64 (exact-fp32 MFMA kernel {e32:.2e}, register-staged f32x3 {ereg:.2e})"
 
 
+@pytest.mark.parametrize("N,H", [(2, 16), (3, 64), (1, 256), (5, 32)])
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "bf16_mfma", "bf16_storage"])
+def test_c3_dgrad_takes_the_activation_backward_in_its_load_path(N, H, mode):
+    """dg_conv4x4s2_c3_dgrad_act_p: conv1's input-gradient with dy * (out > 0 ? 1 : slope) applied while dy is loaded (the saved output
+    prefetched with dy's offsets) must be BITWISE the stand-alone act_bwd pass followed by the plain input-gradient -- on the fp32 MFMA,
+    the f32x3 form, the bf16 MFMA with a bf16 dy and the fp32 MFMA with a bf16 dy; ragged tiles and zero padding included."""
+    w = (rnd(64, 3, 4, 4, seed=2) * 0.1).to(DEV)
+    dy, out = rnd(N, 64, H // 2, H // 2, seed=3), rnd(N, 64, H // 2, H // 2, seed=4)
+    out[0, :, 0, 0] = 0.0                                  # out == 0 takes the slope, like leaky_relu_backward on the result
+    if mode.startswith("bf16"):
+        dyg, outg = nhwc16(dy), nhwc16(out)
+    else:
+        dyg, outg = nhwc(dy), nhwc(out)
+    assert ops.c3_dgrad_act_ok(64)
+    _lib.set_option("bf16", {"f32": 0, "f32x3": 2, "bf16_mfma": 1, "bf16_storage": 0}[mode])
+    try:
+        ref = ops.c3_dgrad(ops.act_bwd(dyg, outg, ops.ACT_LEAKY, 0.2), w, ops.ACT_NONE)
+        got = ops.c3_dgrad(dyg, w, ops.ACT_NONE, act_out=outg, in_act=ops.ACT_LEAKY, slope=0.2)
+        refs = ops.c3_dgrad(ops.act_bwd(dyg, outg, ops.ACT_LEAKY, 0.2), w, ops.ACT_SIGMOID)
+        gots = ops.c3_dgrad(dyg, w, ops.ACT_SIGMOID, act_out=outg, in_act=ops.ACT_LEAKY, slope=0.2)
+    finally:
+        _lib.set_option("bf16", 0)
+    assert torch.equal(got, ref) and torch.equal(gots, refs)
+    assert float(ref.abs().max()) > 0
+    _lib.set_option("kt", 16)                              # the gather form has no fused variant: the query says so and the call refuses
+    try:
+        assert not ops.c3_dgrad_act_ok(64)
+        with pytest.raises(_lib.DiscoganHipError, match="scatter kernel"):
+            ops.c3_dgrad(nhwc(dy), w, ops.ACT_NONE, act_out=nhwc(out), in_act=ops.ACT_LEAKY, slope=0.2)
+    finally:
+        _lib.set_option("kt", 0)
+
+
 @pytest.mark.parametrize("N,S", [(2, 64), (3, 128), (2, 256), (1, 512)])
 def test_edge_wgrad_on_the_f32x3_path(N, S):
     """(From 256-pixel rows on; shorter rows run the exact-fp32 MFMA kernel on this path too, which is faster there -- round 4.)
